@@ -1,0 +1,576 @@
+/*
+ * lrf_oracle.c — TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C CPU restatement of the reference's QMF / SVD codec arithmetic
+ * (pashtari/lrf @ 2025-02-15).  It is the checker for the HIP path: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.  The product
+ * (lrf_amd/) never links, imports or calls anything in this directory.
+ *
+ * Every function cites the reference file:line it restates (paths relative to the
+ * reference root).  Floating point is fp32 unless stated, compiled with
+ * -ffp-contract=off so every fma below is explicit.
+ *
+ * Summation orders.  The reference delegates its products to torch CPU kernels; the
+ * orders below were identified by bit-comparison against torch 2.10.0 (MKL 2024.2,
+ * AVX512) run with torch.set_num_threads(1) (tools/pin_oracle.py re-checks them):
+ *   - MKL sgemm, output n >= 2: per output element a k-ordered fma chain, K cut into
+ *     blocks of 384; block sums are added in block order.                 (mm_mkl)
+ *   - ATen native bmm kernel, used when contraction*rows*cols < 400
+ *     (aten/src/ATen/native/LinearAlgebra.cpp baddbmm_cpu_kernel): k-ordered chain of
+ *     separately rounded multiply then add, starting from 0.              (mm_native)
+ *   - MKL with a single output column (the Gauss-Seidel `uu @ bb` product of
+ *     lrf/factorization/qmf.py:115 when it is large enough for MKL): for K <= 6 the
+ *     tree (((fma(a1,b1,a0*b0) + p5) + p3) + (p2 + p4)) with absent terms dropped;
+ *     K >= 7 is NOT pinned (pattern continued).                           (dot_mkl_n1)
+ * With more than one BLAS thread the reference itself changes the order of the long
+ * X^T U reduction, so "the reference" is pinned at one thread.
+ *
+ * The SVD initialisation (lrf/factorization/qmf.py:42-71 uses LAPACK sgesdd) is NOT a
+ * restatement of LAPACK: it is this project's own algorithm (fp64 Gram matrix, cyclic
+ * Jacobi eigen-solve in a fixed parallel order, deterministic sign rule), defined here
+ * and mirrored operation-for-operation by the HIP kernels.  See DESIGN.md.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define LRF_KC 384
+#define LRF_EPS 1e-16f
+
+/* ------------------------------------------------------------------------------------------------
+ * products
+ * ---------------------------------------------------------------------------------------------- */
+
+/* MKL-ordered product: C[m*ldc+n] = sum_k A[m*sam+k*sak] * B[k*sbk+n*sbn]. */
+static void mm_mkl(const float* A, long sam, long sak, const float* B, long sbk, long sbn,
+                   float* C, long ldc, long M, long K, long N)
+{
+    for (long m = 0; m < M; m++)
+        for (long n = 0; n < N; n++) {
+            float acc = 0.f;
+            for (long k0 = 0; k0 < K; k0 += LRF_KC) {
+                long k1 = k0 + LRF_KC < K ? k0 + LRF_KC : K;
+                float s = 0.f;
+                for (long k = k0; k < k1; k++) s = fmaf(A[m * sam + k * sak], B[k * sbk + n * sbn], s);
+                acc = (k0 == 0) ? s : acc + s;
+            }
+            C[m * ldc + n] = acc;
+        }
+}
+
+/* ATen native small-product kernel: acc = 0; acc += a*b (product rounded, then sum rounded). */
+static void mm_native(const float* A, long sam, long sak, const float* B, long sbk, long sbn,
+                      float* C, long ldc, long M, long K, long N)
+{
+    for (long m = 0; m < M; m++)
+        for (long n = 0; n < N; n++) {
+            float acc = 0.f;
+            for (long k = 0; k < K; k++) {
+                float p = A[m * sam + k * sak] * B[k * sbk + n * sbn];
+                acc = acc + p;
+            }
+            C[m * ldc + n] = acc;
+        }
+}
+
+static int aten_uses_native(long contraction, long rows, long cols)
+{
+    return contraction * rows * cols < 400;
+}
+
+/* torch `a @ b` for [1,M,K] @ [1,K,N] as dispatched on CPU (bmm_out_or_baddbmm_). */
+static void mm_torch(const float* A, long sam, long sak, const float* B, long sbk, long sbn,
+                     float* C, long ldc, long M, long K, long N)
+{
+    if (aten_uses_native(K, M, N)) mm_native(A, sam, sak, B, sbk, sbn, C, ldc, M, K, N);
+    else mm_mkl(A, sam, sak, B, sbk, sbn, C, ldc, M, K, N);
+}
+
+/* MKL single-output-column dot of length K (see header).  a, b are K-vectors. */
+static float dot_mkl_n1(const float* a, const float* b, int K)
+{
+    if (K == 0) return 0.f;
+    if (K == 1) return a[0] * b[0];
+    float odd = fmaf(a[1], b[1], a[0] * b[0]);
+    int last_odd = ((K - 1) & 1) ? K - 1 : K - 2;
+    for (int k = last_odd; k >= 3; k -= 2) odd = odd + a[k] * b[k];
+    if (K < 3) return odd;
+    float even = a[2] * b[2];
+    for (int k = 4; k < K; k += 2) even = even + a[k] * b[k];
+    return odd + even;
+}
+
+static float dot_native(const float* a, const float* b, int K)
+{
+    float acc = 0.f;
+    for (int k = 0; k < K; k++) {
+        float p = a[k] * b[k];
+        acc = acc + p;
+    }
+    return acc;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * projection  — lrf/factorization/qmf.py:191-195 (torch.round = ties-to-even, then clamp)
+ * ---------------------------------------------------------------------------------------------- */
+static inline float project(float x, int bounded, float lo, float hi)
+{
+    x = nearbyintf(x);
+    if (bounded) {
+        if (x < lo) x = lo;
+        if (x > hi) x = hi;
+    }
+    return x;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * CoordinateDescent.update_u — lrf/factorization/qmf.py:93-126 with w = [0;1], l1 = l2 = 0
+ * (safe_divide(x-0, 1) and soft_thresholding(., 0) are identities: factorization/utils.py:18-40).
+ *
+ *   X  : rows x depth, element (i,k) at X[i*sxi + k*sxk]     (update_v passes the transposed strides)
+ *   Uo : rows x R row-major, updated in place (Gauss-Seidel over columns, qmf.py:109-119)
+ *   Vf : depth x R row-major, the fixed factor
+ * ---------------------------------------------------------------------------------------------- */
+static void update_factor(const float* X, long sxi, long sxk, long rows, long depth, int R,
+                          float* Uo, const float* Vf, int bounded, float lo, float hi,
+                          float* a_ws /* rows*R */, float* b_ws /* R*R */)
+{
+    /* qmf.py:107  a = x @ v ; b = v.mT @ v */
+    mm_torch(X, sxi, sxk, Vf, R, 1, a_ws, R, rows, depth, R);
+    mm_torch(Vf, 1, R, Vf, R, 1, b_ws, R, R, depth, R);
+
+    if (R == 1) { /* qmf.py:120-124 */
+        for (long i = 0; i < rows; i++)
+            Uo[i] = project((a_ws[i] + LRF_EPS) / (b_ws[0] + 0.f + LRF_EPS), bounded, lo, hi);
+        return;
+    }
+    int native = aten_uses_native(R - 1, rows, 1);
+    float uu[64], bb[64];
+    for (int r = 0; r < R; r++) {
+        int n = 0;
+        for (int j = 0; j < R; j++)
+            if (j != r) bb[n++] = b_ws[j * R + r];      /* qmf.py:114 */
+        float den = (b_ws[r * R + r] + 0.f) + LRF_EPS;  /* qmf.py:117-118 (l2 = 0) */
+        for (long i = 0; i < rows; i++) {
+            n = 0;
+            for (int j = 0; j < R; j++)
+                if (j != r) uu[n++] = Uo[i * R + j];    /* qmf.py:113 (already-updated columns) */
+            float term2 = native ? dot_native(uu, bb, R - 1) : dot_mkl_n1(uu, bb, R - 1); /* :115 */
+            float num = a_ws[i * R + r] - term2;        /* qmf.py:116 */
+            Uo[i * R + r] = project((num + LRF_EPS) / den, bounded, lo, hi); /* :118-119 */
+        }
+    }
+}
+
+/* QMF.decompose iterations — lrf/factorization/qmf.py:207-212 / CoordinateDescent.forward :149-164.
+ * U [M,R], V [N,R] hold the initial factors on entry and the result on return (fp32, integer valued
+ * when num_iters >= 1).  Returns 0, or -1 on allocation failure / R > 64. */
+int lrf_oracle_bcd(const float* X, long M, long N, int R, int num_iters,
+                   int bounded, float lo, float hi, float* U, float* V)
+{
+    if (R > 64 || R < 1) return -1;
+    long mx = M > N ? M : N;
+    float* a_ws = (float*)malloc(sizeof(float) * (size_t)mx * R);
+    float b_ws[64 * 64];
+    if (!a_ws) return -1;
+    if (bounded) { lo = ceilf(lo); hi = floorf(hi); } /* qmf.py:194 math.ceil / math.floor */
+    for (int it = 0; it < num_iters; it++) {
+        update_factor(X, N, 1, M, N, R, U, V, bounded, lo, hi, a_ws, b_ws); /* update_u :159 */
+        update_factor(X, 1, N, N, M, R, V, U, bounded, lo, hi, a_ws, b_ws); /* update_v :161 (x.mT) */
+    }
+    free(a_ws);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * SVD initialisation (this project's algorithm; replaces LAPACK at lrf/factorization/qmf.py:44-48)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* fp64 Gram matrix G = X^T X of an M x N fp32 matrix, N <= 64... general N.
+ * Order: four interleaved accumulators; accumulator w takes the 4-row steps s with s % 4 == w
+ * (rows 4s..4s+3 in order, fma chain); G = ((g0 + g1) + g2) + g3.  Mirrors one workgroup of four
+ * waves on the GPU. */
+void lrf_oracle_gram_f64(const float* X, long M, long N, double* G)
+{
+    double* acc = (double*)calloc((size_t)4 * N * N, sizeof(double));
+    long nsteps = (M + 3) / 4;
+    for (long s = 0; s < nsteps; s++) {
+        double* g = acc + (size_t)(s & 3) * N * N;
+        for (long m = 4 * s; m < 4 * s + 4 && m < M; m++) {
+            const float* x = X + m * N;
+            for (long i = 0; i < N; i++) {
+                double xi = (double)x[i];
+                for (long j = 0; j < N; j++) g[i * N + j] = fma(xi, (double)x[j], g[i * N + j]);
+            }
+        }
+    }
+    for (long i = 0; i < N * N; i++) G[i] = ((acc[i] + acc[N * N + i]) + acc[2 * N * N + i]) + acc[3 * N * N + i];
+    free(acc);
+}
+
+/* Cyclic Jacobi eigen-solve of a symmetric n x n fp64 matrix (n even), round-robin parallel order.
+ * A is destroyed (diagonal = eigenvalues); E (n x n, row-major) receives eigenvectors in columns.
+ * Each round: rotation parameters for the n/2 disjoint pairs from the current A (upper triangle),
+ * then a row phase, then a column phase (A and E).  Returns the number of sweeps used. */
+static void rr_pair(int n, int t, int i, int* p, int* q)
+{
+    int a, b;
+    if (i == 0) { a = n - 1; b = t % (n - 1); }
+    else { a = (t + i) % (n - 1); b = (t - i + (n - 1)) % (n - 1); }
+    if (a < b) { *p = a; *q = b; } else { *p = b; *q = a; }
+}
+
+int lrf_oracle_jacobi_f64(double* A, int n, double* E, int max_sweeps)
+{
+    int np = n / 2;
+    double* cs = (double*)malloc(sizeof(double) * 2 * np);
+    int* pq = (int*)malloc(sizeof(int) * 2 * np);
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) E[i * n + j] = (i == j) ? 1.0 : 0.0;
+    int sweep;
+    for (sweep = 0; sweep < max_sweeps; sweep++) {
+        int rotated = 0;
+        for (int t = 0; t < n - 1; t++) {
+            for (int i = 0; i < np; i++) {
+                int p, q;
+                rr_pair(n, t, i, &p, &q);
+                pq[2 * i] = p; pq[2 * i + 1] = q;
+                double apq = A[p * n + q], app = A[p * n + p], aqq = A[q * n + q];
+                double c = 1.0, s = 0.0;
+                /* skip when apq^2 <= 2^-106 |app aqq| (already negligible) */
+                if (apq * apq > 1.2325951644078309e-32 * fabs(app * aqq)) {
+                    double tau = (aqq - app) / (2.0 * apq);
+                    double tt = 1.0 / (fabs(tau) + sqrt(1.0 + tau * tau));
+                    if (tau < 0.0) tt = -tt;
+                    c = 1.0 / sqrt(1.0 + tt * tt);
+                    s = tt * c;
+                    rotated = 1;
+                }
+                cs[2 * i] = c; cs[2 * i + 1] = s;
+            }
+            for (int i = 0; i < np; i++) { /* row phase: A <- J^T A */
+                int p = pq[2 * i], q = pq[2 * i + 1];
+                double c = cs[2 * i], s = cs[2 * i + 1];
+                if (s == 0.0) continue;
+                for (int k = 0; k < n; k++) {
+                    double gp = A[p * n + k], gq = A[q * n + k];
+                    A[p * n + k] = c * gp - s * gq;
+                    A[q * n + k] = s * gp + c * gq;
+                }
+            }
+            for (int i = 0; i < np; i++) { /* column phase: A <- A J ; E <- E J */
+                int p = pq[2 * i], q = pq[2 * i + 1];
+                double c = cs[2 * i], s = cs[2 * i + 1];
+                if (s == 0.0) continue;
+                for (int k = 0; k < n; k++) {
+                    double gp = A[k * n + p], gq = A[k * n + q];
+                    A[k * n + p] = c * gp - s * gq;
+                    A[k * n + q] = s * gp + c * gq;
+                    double ep = E[k * n + p], eq = E[k * n + q];
+                    E[k * n + p] = c * ep - s * eq;
+                    E[k * n + q] = s * ep + c * eq;
+                }
+                A[p * n + q] = 0.0;
+                A[q * n + p] = 0.0;
+            }
+        }
+        if (!rotated) break;
+    }
+    free(cs);
+    free(pq);
+    return sweep;
+}
+
+/* Top-R factors from the Gram eigen-pairs:
+ *   sigma_r = sqrt(max(lambda_r,0)); s_r = sqrt(sigma_r)
+ *   v0[:,r] = e_r * s_r                 (lrf/factorization/qmf.py:46,48  v = (sqrt(s) Vh)^T)
+ *   w0[:,r] = e_r / s_r  (0 if s_r = 0) so that u0 = X w0 = U sqrt(s)   (qmf.py:46-47)
+ * Eigenvalues are taken in descending order (ties: lower index first).  Column sign: sign[r] if
+ * non-zero, else -1, is imposed on  sum_j (j+1) e_r[j]  (the reference's LAPACK sign is arbitrary;
+ * component 0 comes out negative there, which -1 reproduces).  Columns r >= min(M,N) are zero
+ * (qmf.py:50-52).  G is N x N (destroyed). */
+int lrf_oracle_init_from_gram(double* G, long M, long N, int R, const int8_t* sign, float* v0, float* w0)
+{
+    int n = (int)N;
+    if (n & 1) return -1;
+    double* E = (double*)malloc(sizeof(double) * n * n);
+    lrf_oracle_jacobi_f64(G, n, E, 30);
+    int* order = (int*)malloc(sizeof(int) * n);
+    for (int i = 0; i < n; i++) order[i] = i;
+    for (int i = 1; i < n; i++) { /* stable insertion sort, descending */
+        int o = order[i];
+        double key = G[o * n + o];
+        int j = i - 1;
+        while (j >= 0 && G[order[j] * n + order[j]] < key) { order[j + 1] = order[j]; j--; }
+        order[j + 1] = o;
+    }
+    long rmax = M < N ? M : N;
+    for (int r = 0; r < R; r++) {
+        if (r >= rmax) {
+            for (int j = 0; j < n; j++) { v0[j * R + r] = 0.f; w0[j * R + r] = 0.f; }
+            continue;
+        }
+        int c = order[r];
+        double lam = G[c * n + c];
+        double sigma = sqrt(lam > 0.0 ? lam : 0.0);
+        double sr = sqrt(sigma);
+        double dot = 0.0;
+        for (int j = 0; j < n; j++) dot = fma((double)(j + 1), E[j * n + c], dot);
+        double want = (sign && sign[r]) ? (double)sign[r] : -1.0;
+        double flip = ((dot < 0.0 ? -1.0 : 1.0) == want) ? 1.0 : -1.0;
+        for (int j = 0; j < n; j++) {
+            double e = flip * E[j * n + c];
+            v0[j * R + r] = (float)(e * sr);
+            w0[j * R + r] = (sr > 0.0) ? (float)(e / sr) : 0.f;
+        }
+    }
+    free(order);
+    free(E);
+    return 0;
+}
+
+/* Full init: u0 [M,R], v0 [N,R].  u0 = X w0 with the same k-ordered fma chain as x @ v. */
+int lrf_oracle_svd_init(const float* X, long M, long N, int R, const int8_t* sign, float* u0, float* v0)
+{
+    double* G = (double*)malloc(sizeof(double) * N * N);
+    float* w0 = (float*)malloc(sizeof(float) * N * R);
+    lrf_oracle_gram_f64(X, M, N, G);
+    int rc = lrf_oracle_init_from_gram(G, M, N, R, sign, v0, w0);
+    if (rc == 0) mm_mkl(X, N, 1, w0, R, 1, u0, R, M, N, R);
+    free(G);
+    free(w0);
+    return rc;
+}
+
+/* QMF.decompose — lrf/factorization/qmf.py:197-214 (init + num_iters BCD iterations). */
+int lrf_oracle_qmf_decompose(const float* X, long M, long N, int R, int num_iters, int bounded,
+                             float lo, float hi, const int8_t* sign, float* U, float* V)
+{
+    int rc = lrf_oracle_svd_init(X, M, N, R, sign, U, V);
+    if (rc) return rc;
+    return lrf_oracle_bcd(X, M, N, R, num_iters, bounded, lo, hi, U, V);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * colour, resampling, padding, patches — lrf/compression/utils.py, lrf/compression/qmf.py
+ * ---------------------------------------------------------------------------------------------- */
+
+/* rgb_to_ycbcr — lrf/compression/utils.py:24-47: offset + einsum("ij,j...->i...", T, rgb.float()).
+ * The einsum is an sgemm with K = 3: k-ordered fma chain from 0.  rgb is CHW uint8. */
+void lrf_oracle_rgb_to_ycbcr(const uint8_t* rgb, long H, long W, float* ycc)
+{
+    static const float T[3][3] = {{0.299f, 0.587f, 0.114f},
+                                  {-0.168736f, -0.331264f, 0.5f},
+                                  {0.5f, -0.418688f, -0.081312f}};
+    static const float off[3] = {0.f, 128.f, 128.f};
+    long hw = H * W;
+    for (int i = 0; i < 3; i++)
+        for (long p = 0; p < hw; p++) {
+            float acc = 0.f;
+            for (int j = 0; j < 3; j++) acc = fmaf(T[i][j], (float)rgb[j * hw + p], acc);
+            ycc[i * hw + p] = off[i] + acc;
+        }
+}
+
+/* ycbcr_to_rgb — lrf/compression/utils.py:50-73: einsum(T', ycc + offset). */
+void lrf_oracle_ycbcr_to_rgb(const float* ycc, long H, long W, float* rgb)
+{
+    static const float T[3][3] = {{1.0f, 0.0f, 1.402f}, {1.0f, -0.344136f, -0.714136f}, {1.0f, 1.772f, 0.0f}};
+    static const float off[3] = {0.f, -128.f, -128.f};
+    long hw = H * W;
+    for (int i = 0; i < 3; i++)
+        for (long p = 0; p < hw; p++) {
+            float acc = 0.f;
+            for (int j = 0; j < 3; j++) acc = fmaf(T[i][j], ycc[j * hw + p] + off[j], acc);
+            rgb[i * hw + p] = acc;
+        }
+}
+
+/* F.interpolate(mode="area") = adaptive_avg_pool2d (lrf/compression/utils.py:92-94 called with
+ * scale_factor from lrf/compression/qmf.py:230).  Window [floor(i*H/oh), ceil((i+1)*H/oh));
+ * row-major fp32 sum, then / kh / kw (ATen AdaptiveAvgPoolKernel.cpp). */
+void lrf_oracle_area_downsample(const float* in, long H, long W, long oh, long ow, float* out)
+{
+    for (long i = 0; i < oh; i++) {
+        long h0 = (i * H) / oh, h1 = ((i + 1) * H + oh - 1) / oh;
+        for (long j = 0; j < ow; j++) {
+            long w0 = (j * W) / ow, w1 = ((j + 1) * W + ow - 1) / ow;
+            float sum = 0.f;
+            for (long a = h0; a < h1; a++)
+                for (long b = w0; b < w1; b++) sum = sum + in[a * W + b];
+            out[i * ow + j] = sum / (float)(h1 - h0) / (float)(w1 - w0);
+        }
+    }
+}
+
+/* F.interpolate(mode="nearest", size=...) — lrf/compression/utils.py:101-103 via qmf.py:346-348.
+ * src = min(floor(dst * in/out), in-1) with the scale computed in fp32 (ATen nearest_idx). */
+void lrf_oracle_nearest_upsample(const float* in, long h, long w, long H, long W, float* out)
+{
+    float sh = (float)h / (float)H, sw = (float)w / (float)W;
+    for (long i = 0; i < H; i++) {
+        long si = (long)floorf((float)i * sh);
+        if (si > h - 1) si = h - 1;
+        for (long j = 0; j < W; j++) {
+            long sj = (long)floorf((float)j * sw);
+            if (sj > w - 1) sj = w - 1;
+            out[i * W + j] = in[si * w + sj];
+        }
+    }
+}
+
+static long reflect_idx(long i, long n)
+{
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+    return i;
+}
+
+/* pad_image(reflect) + patchify: lrf/compression/utils.py:108-132, lrf/compression/qmf.py:43-56.
+ * in: C planes of H x W fp32 (CHW).  X: [(Hp/p)*(Wp/q)] x [C*p*q], "c (h p) (w q) -> (h w) (c p q)". */
+void lrf_oracle_pad_patchify(const float* in, long C, long H, long W, long p, long q, float* X)
+{
+    long ph = (p - H % p) % p, pw = (q - W % q) % q;
+    long top = ph / 2, left = pw / 2;
+    long Hp = H + ph, Wp = W + pw, nh = Hp / p, nw = Wp / q, N = C * p * q;
+    for (long hh = 0; hh < nh; hh++)
+        for (long ww = 0; ww < nw; ww++)
+            for (long c = 0; c < C; c++)
+                for (long a = 0; a < p; a++)
+                    for (long b = 0; b < q; b++) {
+                        long y = reflect_idx(hh * p + a - top, H), x = reflect_idx(ww * q + b - left, W);
+                        X[(hh * nw + ww) * N + (c * p + a) * q + b] = in[(c * H + y) * W + x];
+                    }
+}
+
+/* depatchify + unpad_image: lrf/compression/qmf.py:59-75, lrf/compression/utils.py:135-153.
+ * X: [(Hp/p)*(Wp/q)] x [C*p*q] -> out: C planes of H x W (centre crop, start = (Hp-H)//2). */
+void lrf_oracle_depatchify_unpad(const float* X, long C, long Hp, long Wp, long H, long W, long p, long q, float* out)
+{
+    long nw = Wp / q, N = C * p * q;
+    long sh = (Hp - H) / 2, sw = (Wp - W) / 2;
+    for (long c = 0; c < C; c++)
+        for (long y = 0; y < H; y++)
+            for (long x = 0; x < W; x++) {
+                long yy = y + sh, xx = x + sw;
+                long hh = yy / p, a = yy % p, ww = xx / q, b = xx % q;
+                out[(c * H + y) * W + x] = X[(hh * nw + ww) * N + (c * p + a) * q + b];
+            }
+}
+
+/* QMF.reconstruct — lrf/factorization/qmf.py:216-223 with w=None: u @ v.mT (k-ordered fma chain;
+ * exact for the integer factors of the QMF path). */
+void lrf_oracle_reconstruct(const float* U, const float* V, long M, long N, int R, float* X)
+{
+    mm_torch(U, R, 1, V, 1, R, X, N, M, R, N);
+}
+
+/* to_dtype(uint8) — lrf/compression/utils.py:156-182: clamp(0,255) then a truncating cast. */
+void lrf_oracle_to_u8(const float* in, long n, uint8_t* out)
+{
+    for (long i = 0; i < n; i++) {
+        float v = in[i];
+        if (v < 0.f) v = 0.f;
+        if (v > 255.f) v = 255.f;
+        out[i] = (uint8_t)v;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * whole-image helpers for the default branch of qmf_encode / qmf_decode
+ * (color_space="YCbCr", patch=True): lrf/compression/qmf.py:214-262 and :323-351
+ * ---------------------------------------------------------------------------------------------- */
+
+/* sizes of plane c (0 = Y, 1/2 = chroma) for an H x W image, scale 0.5: lrf/compression/qmf.py:230 */
+void lrf_oracle_plane_dims(long H, long W, long p, long q, int c, long* h, long* w, long* hp, long* wp, long* M)
+{
+    long ph = c ? (long)floor((double)H * 0.5) : H, pw = c ? (long)floor((double)W * 0.5) : W;
+    *h = ph; *w = pw;
+    *hp = ph + (p - ph % p) % p;
+    *wp = pw + (q - pw % q) % q;
+    *M = (*hp / p) * (*wp / q);
+}
+
+/* uint8 RGB (CHW) -> the three patch matrices X_Y, X_Cb, X_Cr (row-major [M_c, p*q]). */
+int lrf_oracle_rgb_to_planes(const uint8_t* rgb, long H, long W, long p, long q, float* XY, float* XCb, float* XCr)
+{
+    float* ycc = (float*)malloc(sizeof(float) * 3 * H * W);
+    if (!ycc) return -1;
+    lrf_oracle_rgb_to_ycbcr(rgb, H, W, ycc);
+    lrf_oracle_pad_patchify(ycc, 1, H, W, p, q, XY);
+    long h, w, hp, wp, M;
+    lrf_oracle_plane_dims(H, W, p, q, 1, &h, &w, &hp, &wp, &M);
+    float* ds = (float*)malloc(sizeof(float) * h * w);
+    float* Xc[2] = {XCb, XCr};
+    for (int c = 0; c < 2; c++) {
+        lrf_oracle_area_downsample(ycc + (c + 1) * H * W, H, W, h, w, ds);
+        lrf_oracle_pad_patchify(ds, 1, h, w, p, q, Xc[c]);
+    }
+    free(ds);
+    free(ycc);
+    return 0;
+}
+
+/* int8 factors of the three planes -> uint8 RGB (CHW): lrf/compression/qmf.py:329-351. */
+int lrf_oracle_planes_to_rgb(const int8_t* const U[3], const int8_t* const V[3], const int R[3],
+                             long H, long W, long p, long q, uint8_t* rgb)
+{
+    long N = p * q;
+    float* ycc = (float*)malloc(sizeof(float) * 3 * H * W);
+    float* out = (float*)malloc(sizeof(float) * 3 * H * W);
+    if (!ycc || !out) return -1;
+    for (int c = 0; c < 3; c++) {
+        long h, w, hp, wp, M;
+        lrf_oracle_plane_dims(H, W, p, q, c, &h, &w, &hp, &wp, &M);
+        float* uf = (float*)malloc(sizeof(float) * M * R[c]);
+        float* vf = (float*)malloc(sizeof(float) * N * R[c]);
+        float* X = (float*)malloc(sizeof(float) * M * N);
+        float* pl = (float*)malloc(sizeof(float) * h * w);
+        for (long i = 0; i < M * R[c]; i++) uf[i] = (float)U[c][i];
+        for (long i = 0; i < N * R[c]; i++) vf[i] = (float)V[c][i];
+        lrf_oracle_reconstruct(uf, vf, M, N, R[c], X);
+        lrf_oracle_depatchify_unpad(X, 1, hp, wp, h, w, p, q, pl);
+        if (c == 0) memcpy(ycc, pl, sizeof(float) * H * W);
+        else lrf_oracle_nearest_upsample(pl, h, w, H, W, ycc + c * H * W);
+        free(uf); free(vf); free(X); free(pl);
+    }
+    lrf_oracle_ycbcr_to_rgb(ycc, H, W, out);
+    lrf_oracle_to_u8(out, 3 * H * W, rgb);
+    free(ycc);
+    free(out);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * SVD baseline — lrf/compression/svd.py:179-187 and lrf/compression/utils.py:185-243
+ * ---------------------------------------------------------------------------------------------- */
+
+/* quantize(tensor, uint8): scale = (max-min)/(255-0); q = clamp((t-min)/scale + 0, 0, 255) truncated. */
+void lrf_oracle_quantize_u8(const float* t, long n, uint8_t* qv, float* scale, float* minv)
+{
+    float mn = t[0], mx = t[0];
+    for (long i = 1; i < n; i++) {
+        if (t[i] < mn) mn = t[i];
+        if (t[i] > mx) mx = t[i];
+    }
+    float sc = (mx - mn) / 255.f;
+    for (long i = 0; i < n; i++) {
+        float v = (t[i] - mn) / sc + 0.f;
+        if (v < 0.f) v = 0.f;
+        if (v > 255.f) v = 255.f;
+        qv[i] = (uint8_t)v;
+    }
+    *scale = sc;
+    *minv = mn;
+}
+
+/* dequantize: (q - q.min()) * scale + min_val  (utils.py:241; scale/min are Python floats there,
+ * so the multiply-add runs in fp32 on the tensor with fp32-cast scalars). */
+void lrf_oracle_dequantize_u8(const uint8_t* qv, long n, float scale, float minv, float* t)
+{
+    uint8_t qm = qv[0];
+    for (long i = 1; i < n; i++)
+        if (qv[i] < qm) qm = qv[i];
+    for (long i = 0; i < n; i++) t[i] = ((float)qv[i] - (float)qm) * scale + minv;
+}

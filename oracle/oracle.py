@@ -1,0 +1,188 @@
+"""ctypes front-end of the CPU oracle (oracle/lrf_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module;
+lrf_amd/ never does.  Arrays are numpy; nothing here touches torch or the GPU.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "liblrf_oracle.so")
+_lib = None
+
+c_long = ctypes.c_long
+c_int = ctypes.c_int
+c_float = ctypes.c_float
+_fp = ctypes.POINTER(ctypes.c_float)
+_dp = ctypes.POINTER(ctypes.c_double)
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_i8p = ctypes.POINTER(ctypes.c_int8)
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "lrf_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = ctypes.CDLL(_SO)
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(t)
+
+
+def plane_dims(H, W, p=8, q=8):
+    """[(h, w, hp, wp, M)] for Y, Cb, Cr."""
+    out = []
+    for c in range(3):
+        v = [c_long() for _ in range(5)]
+        lib().lrf_oracle_plane_dims(c_long(H), c_long(W), c_long(p), c_long(q), c_int(c), *[ctypes.byref(x) for x in v])
+        out.append(tuple(int(x.value) for x in v))
+    return out
+
+
+def rgb_to_planes(rgb, p=8, q=8):
+    """uint8 [3,H,W] -> [X_Y, X_Cb, X_Cr] fp32 [M_c, p*q]."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    _, H, W = rgb.shape
+    dims = plane_dims(H, W, p, q)
+    X = [np.empty((d[4], p * q), np.float32) for d in dims]
+    rc = lib().lrf_oracle_rgb_to_planes(_ptr(rgb, _u8p), c_long(H), c_long(W), c_long(p), c_long(q),
+                                        _ptr(X[0], _fp), _ptr(X[1], _fp), _ptr(X[2], _fp))
+    assert rc == 0
+    return X
+
+
+def gram_f64(X):
+    X = _f32(X)
+    M, N = X.shape
+    G = np.empty((N, N), np.float64)
+    lib().lrf_oracle_gram_f64(_ptr(X, _fp), c_long(M), c_long(N), _ptr(G, _dp))
+    return G
+
+
+def jacobi_f64(A, max_sweeps=30):
+    A = np.array(A, dtype=np.float64, order="C")
+    n = A.shape[0]
+    E = np.empty((n, n), np.float64)
+    lib().lrf_oracle_jacobi_f64.restype = c_int
+    sweeps = lib().lrf_oracle_jacobi_f64(_ptr(A, _dp), c_int(n), _ptr(E, _dp), c_int(max_sweeps))
+    return np.diag(A).copy(), E, sweeps
+
+
+def _sign_arg(sign, R):
+    if sign is None:
+        return None, None
+    s = np.ascontiguousarray(sign, dtype=np.int8)
+    assert s.shape == (R,)
+    return s, _ptr(s, _i8p)
+
+
+def svd_init(X, R, sign=None):
+    X = _f32(X)
+    M, N = X.shape
+    u0 = np.empty((M, R), np.float32)
+    v0 = np.empty((N, R), np.float32)
+    keep, sp = _sign_arg(sign, R)
+    rc = lib().lrf_oracle_svd_init(_ptr(X, _fp), c_long(M), c_long(N), c_int(R), sp, _ptr(u0, _fp), _ptr(v0, _fp))
+    assert rc == 0
+    return u0, v0
+
+
+def bcd(X, u0, v0, num_iters, bounds=(-16, 15)):
+    """Runs num_iters BCD iterations from (u0, v0); returns fp32 (U, V)."""
+    X = _f32(X)
+    M, N = X.shape
+    U = np.array(u0, dtype=np.float32, order="C")
+    V = np.array(v0, dtype=np.float32, order="C")
+    R = U.shape[1]
+    assert U.shape == (M, R) and V.shape == (N, R)
+    bounded = bounds is not None and tuple(bounds) != (None, None)
+    lo, hi = (bounds if bounded else (0.0, 0.0))
+    rc = lib().lrf_oracle_bcd(_ptr(X, _fp), c_long(M), c_long(N), c_int(R), c_int(num_iters), c_int(int(bounded)),
+                              c_float(lo), c_float(hi), _ptr(U, _fp), _ptr(V, _fp))
+    assert rc == 0
+    return U, V
+
+
+def qmf_decompose(X, R, num_iters=10, bounds=(-16, 15), sign=None):
+    X = _f32(X)
+    M, N = X.shape
+    U = np.empty((M, R), np.float32)
+    V = np.empty((N, R), np.float32)
+    bounded = bounds is not None and tuple(bounds) != (None, None)
+    lo, hi = (bounds if bounded else (0.0, 0.0))
+    keep, sp = _sign_arg(sign, R)
+    rc = lib().lrf_oracle_qmf_decompose(_ptr(X, _fp), c_long(M), c_long(N), c_int(R), c_int(num_iters),
+                                        c_int(int(bounded)), c_float(lo), c_float(hi), sp, _ptr(U, _fp), _ptr(V, _fp))
+    assert rc == 0
+    return U, V
+
+
+def planes_to_rgb(U, V, H, W, p=8, q=8):
+    """int8 factor lists (3 planes) -> uint8 [3,H,W]."""
+    U = [np.ascontiguousarray(u, dtype=np.int8) for u in U]
+    V = [np.ascontiguousarray(v, dtype=np.int8) for v in V]
+    R = (c_int * 3)(*[u.shape[1] for u in U])
+    Up = (_i8p * 3)(*[_ptr(u, _i8p) for u in U])
+    Vp = (_i8p * 3)(*[_ptr(v, _i8p) for v in V])
+    out = np.empty((3, H, W), np.uint8)
+    rc = lib().lrf_oracle_planes_to_rgb(Up, Vp, R, c_long(H), c_long(W), c_long(p), c_long(q), _ptr(out, _u8p))
+    assert rc == 0
+    return out
+
+
+def pad_patchify(img, p=8, q=8):
+    """fp32 [C,H,W] -> X [M, C*p*q] (reflect pad + patchify)."""
+    img = _f32(img)
+    C, H, W = img.shape
+    hp = H + (p - H % p) % p
+    wp = W + (q - W % q) % q
+    X = np.empty(((hp // p) * (wp // q), C * p * q), np.float32)
+    lib().lrf_oracle_pad_patchify(_ptr(img, _fp), c_long(C), c_long(H), c_long(W), c_long(p), c_long(q), _ptr(X, _fp))
+    return X
+
+
+def depatchify_unpad(X, C, Hp, Wp, H, W, p=8, q=8):
+    X = _f32(X)
+    out = np.empty((C, H, W), np.float32)
+    lib().lrf_oracle_depatchify_unpad(_ptr(X, _fp), c_long(C), c_long(Hp), c_long(Wp), c_long(H), c_long(W),
+                                      c_long(p), c_long(q), _ptr(out, _fp))
+    return out
+
+
+def quantize_u8(t):
+    t = _f32(t)
+    q = np.empty(t.shape, np.uint8)
+    sc, mn = c_float(), c_float()
+    lib().lrf_oracle_quantize_u8(_ptr(t, _fp), c_long(t.size), _ptr(q, _u8p), ctypes.byref(sc), ctypes.byref(mn))
+    return q, float(sc.value), float(mn.value)
+
+
+def dequantize_u8(q, scale, minv):
+    q = np.ascontiguousarray(q, dtype=np.uint8)
+    t = np.empty(q.shape, np.float32)
+    lib().lrf_oracle_dequantize_u8(_ptr(q, _u8p), c_long(q.size), c_float(scale), c_float(minv), _ptr(t, _fp))
+    return t
+
+
+def to_u8(x):
+    x = _f32(x)
+    out = np.empty(x.shape, np.uint8)
+    lib().lrf_oracle_to_u8(_ptr(x, _fp), c_long(x.size), _ptr(out, _u8p))
+    return out
