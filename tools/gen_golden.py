@@ -1,0 +1,146 @@
+"""Generates tests/golden/*.npz by running the REFERENCE (imported from /root/reference) here.
+
+Run:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py
+The reference runs with torch.set_num_threads(1): its long X^T U reduction (MKL sgemm, K = M) is
+summed in a thread-count-dependent order, and one thread is the reproducible one.
+Fixtures hold data only: inputs (or the seed recipe + sha256 for large ones), parameters, the
+reference's encoded bytes, decoded image (or its sha256), PSNR / bpp, the LAPACK column signs of the
+reference's SVD initialisation, and for small planes the initial factors (u0, v0).
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_loader  # noqa: E402
+
+OUT = os.path.join(HERE, "..", "tests", "golden")
+
+
+def make_image(spec):
+    kind = spec["kind"]
+    if kind == "randint":
+        g = torch.Generator().manual_seed(spec["seed"])
+        return torch.randint(0, 256, (3, spec["H"], spec["W"]), dtype=torch.uint8, generator=g)
+    if kind == "smooth":
+        g = torch.Generator().manual_seed(spec["seed"])
+        H, W = spec["H"], spec["W"]
+        base = torch.rand(1, 3, H // 8, W // 8, generator=g) * 255
+        sm = torch.nn.functional.interpolate(base, size=(H, W), mode="bilinear", align_corners=False)[0]
+        return (sm + torch.randn(sm.shape, generator=g) * 4).clamp(0, 255).to(torch.uint8)
+    if kind == "const":
+        return torch.full((3, spec["H"], spec["W"]), spec["value"], dtype=torch.uint8)
+    if kind == "natural":
+        from PIL import Image
+        im = np.asarray(Image.open(os.path.join(ref_loader.REF_ROOT, "figures", "kodim01.png")).convert("RGB"))
+        return torch.from_numpy(im.copy()).permute(2, 0, 1).contiguous()
+    raise ValueError(kind)
+
+
+def wsign(v):
+    """sign of sum_j (j+1) v[j, r] per column — the convention the build's init uses."""
+    w = np.arange(1, v.shape[0] + 1, dtype=np.float64)[:, None]
+    s = np.sign((w * v.astype(np.float64)).sum(0))
+    s[s == 0] = -1
+    return s.astype(np.int8)
+
+
+CASES = [
+    # name, image spec, encoder kwargs, store_image, store_init
+    ("tiny_q7", dict(kind="randint", seed=11, H=64, W=96), dict(quality=7), True, True),
+    ("tiny_r7", dict(kind="randint", seed=11, H=64, W=96), dict(rank=7), True, True),
+    ("tiny_q20", dict(kind="randint", seed=11, H=64, W=96), dict(quality=20), True, False),
+    ("tiny_rank2", dict(kind="randint", seed=11, H=64, W=96), dict(rank=2), True, True),
+    ("tiny_rank1", dict(kind="randint", seed=11, H=64, W=96), dict(rank=1), True, True),
+    ("tiny_it0", dict(kind="randint", seed=11, H=64, W=96), dict(quality=7, num_iters=0), True, False),
+    ("tiny_it1", dict(kind="randint", seed=11, H=64, W=96), dict(quality=7, num_iters=1), True, True),
+    ("tiny_it2", dict(kind="randint", seed=11, H=64, W=96), dict(rank=7, num_iters=2), True, True),
+    ("odd_q7", dict(kind="randint", seed=12, H=173, W=264), dict(quality=7), True, True),
+    ("odd_r7", dict(kind="randint", seed=12, H=173, W=264), dict(rank=7), True, True),
+    ("smooth_q7", dict(kind="smooth", seed=13, H=256, W=384), dict(quality=7), True, False),
+    ("smooth_r7", dict(kind="smooth", seed=13, H=256, W=384), dict(rank=7), True, False),
+    ("zero_q7", dict(kind="const", value=0, H=32, W=48), dict(quality=7), True, False),
+    ("const_q7", dict(kind="const", value=100, H=32, W=48), dict(quality=7), True, False),
+    ("s1_q7", dict(kind="randint", seed=0, H=512, W=768), dict(quality=7), False, False),
+    ("s1_r7", dict(kind="randint", seed=0, H=512, W=768), dict(rank=7), False, False),
+    ("nat_q7", dict(kind="natural"), dict(quality=7), True, False),
+    ("nat_r7", dict(kind="natural"), dict(rank=7), False, False),
+    ("s2odd_q7", dict(kind="randint", seed=14, H=341, W=512), dict(quality=7), False, False),
+]
+
+
+def main():
+    torch.set_num_threads(1)
+    ns = ref_loader.load()
+    os.makedirs(OUT, exist_ok=True)
+    index = {}
+    for name, spec, kw, store_image, store_init in CASES:
+        img = make_image(spec)
+        enc = ns.cqmf.qmf_encode(img, **kw)
+        dec = ns.cqmf.qmf_decode(enc)
+        mse = torch.mean((img.float() - dec.float()) ** 2, dim=(-3, -2, -1))
+        psnr = (20 * torch.log10(255 / torch.sqrt(mse))).item()          # lrf/utils/metrics.py:57-71
+        bpp = len(enc) * 8 / (img.shape[-2] * img.shape[-1])               # lrf/utils/metrics.py:149-162
+        cr = img.numel() * img.element_size() / len(enc)                   # lrf/utils/metrics.py:120-133
+        # the reference's init signs (and small init factors) per plane
+        ycbcr = ns.cutils.rgb_to_ycbcr(img.float())
+        chans = ns.cutils.chroma_downsampling(ycbcr, scale_factor=(0.5, 0.5), mode="area")
+        meta = json.loads(ns.cutils.separate_bytes(enc, 2)[0].decode())
+        arrays = dict(encoded=np.frombuffer(enc, np.uint8), psnr=np.float64(psnr), bpp=np.float64(bpp),
+                      cr=np.float64(cr), spec=np.array(json.dumps(spec)), kwargs=np.array(json.dumps(kw)),
+                      image_sha256=np.array(hashlib.sha256(img.numpy().tobytes()).hexdigest()),
+                      decoded_sha256=np.array(hashlib.sha256(dec.numpy().tobytes()).hexdigest()),
+                      ranks=np.array(meta["rank"], np.int32))
+        for c, ch in enumerate(chans):
+            x = ns.cqmf.patchify(ns.cutils.pad_image(ch, (8, 8), mode="reflect"), (8, 8))
+            R = meta["rank"][c]
+            u0, v0, _ = ns.fqmf.SVDInit(rank=R)(x.unsqueeze(0).float())
+            arrays[f"sign{c}"] = wsign(v0[0].numpy())
+            if store_init:
+                arrays[f"u0_{c}"] = u0[0].numpy()
+                arrays[f"v0_{c}"] = v0[0].numpy()
+        if store_image:
+            arrays["image"] = img.numpy()
+            arrays["decoded"] = dec.numpy()
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
+        index[name] = dict(spec=spec, kwargs=kw, bytes=len(enc), psnr=psnr, bpp=bpp,
+                           enc_sha256=hashlib.sha256(enc).hexdigest()[:16], ranks=meta["rank"])
+        print(name, index[name])
+
+    # SVD baseline (lrf.svd_encode defaults: RGB, uint8-quantised factors)
+    for name, spec, kw in [("svd_tiny_q2p5", dict(kind="randint", seed=11, H=64, W=96), dict(quality=2.5)),
+                           ("svd_smooth_q2p5", dict(kind="smooth", seed=13, H=256, W=384), dict(quality=2.5)),
+                           ("svd_s1_q2p5", dict(kind="randint", seed=0, H=512, W=768), dict(quality=2.5))]:
+        img = make_image(spec)
+        enc = ns.csvd.svd_encode(img, **kw)
+        dec = ns.csvd.svd_decode(enc)
+        mse = torch.mean((img.float() - dec.float()) ** 2, dim=(-3, -2, -1))
+        psnr = (20 * torch.log10(255 / torch.sqrt(mse))).item()
+        meta = json.loads(ns.cutils.separate_bytes(enc, 2)[0].decode())
+        x = ns.csvd.patchify(ns.cutils.pad_image(img.float(), (8, 8), mode="reflect"), (8, 8))
+        s = torch.linalg.svdvals(x.double())
+        arrays = dict(encoded=np.frombuffer(enc, np.uint8), psnr=np.float64(psnr),
+                      bpp=np.float64(len(enc) * 8 / (img.shape[-2] * img.shape[-1])),
+                      spec=np.array(json.dumps(spec)), kwargs=np.array(json.dumps(kw)),
+                      image_sha256=np.array(hashlib.sha256(img.numpy().tobytes()).hexdigest()),
+                      decoded_sha256=np.array(hashlib.sha256(dec.numpy().tobytes()).hexdigest()),
+                      quant_u=np.array(meta["quantization"]["u"], np.float64),
+                      quant_v=np.array(meta["quantization"]["v"], np.float64),
+                      singular_values=s[:16].numpy())
+        if spec["H"] <= 256:
+            arrays["image"] = img.numpy()
+            arrays["decoded"] = dec.numpy()
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
+        index[name] = dict(spec=spec, kwargs=kw, bytes=len(enc), psnr=psnr, quant=meta["quantization"])
+        print(name, index[name])
+    with open(os.path.join(OUT, "index.json"), "w") as f:
+        json.dump(index, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
