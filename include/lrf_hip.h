@@ -1,0 +1,145 @@
+/*
+ * lrf_hip.h — C ABI of liblrf_hip.so: the MI355X (gfx950) implementation of pashtari/lrf's
+ * QMF factorisation hot path.
+ *
+ * The reference has no FFI: it is pure Python on torch CPU tensors.  The seam this library cuts is
+ * the one SURVEY.md §8(b) names, and every entry point cites the reference code it replaces
+ * (paths relative to the reference root).  A maintainer of the reference binds these with ctypes;
+ * INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - Every data pointer is a DEVICE pointer (HBM) unless the parameter name ends in `_host`.
+ *     lrf_malloc / lrf_free / lrf_memcpy_* let a host without any GPU runtime of its own
+ *     (plain ctypes + numpy) move data.  No torch types cross this boundary.
+ *   - Caller owns inputs and outputs.  The library owns only the per-context scratch workspace,
+ *     grown on demand and released by lrf_ctx_destroy.
+ *   - All work is enqueued on the context's HIP stream (lrf_ctx_set_stream); calls return after
+ *     enqueueing unless stated.  lrf_ctx_synchronize waits for the stream.
+ *   - Return value: 0 = ok, negative = LRF_E*.  lrf_last_error() returns a thread-local message.
+ *   - A context is not thread-safe; use one per (host thread, device).  Distinct contexts are
+ *     independent.
+ *   - Factors are int8 (requires -128 <= lo <= hi <= 127; the reference default is (-16, 15),
+ *     lrf/compression/qmf.py:124) in row-major [M,R] / [N,R] layout, exactly the layout
+ *     `u.to(int8)`, `v.to(int8)` have at lrf/compression/qmf.py:258-260.
+ */
+#ifndef LRF_HIP_H
+#define LRF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LRF_OK 0
+#define LRF_EINVAL (-1)      /* bad argument (the reference raises AssertionError / ValueError) */
+#define LRF_ENOTSUP (-2)     /* valid in the reference but not implemented on this path yet */
+#define LRF_EHIP (-3)        /* a HIP runtime call failed; see lrf_last_error() */
+#define LRF_ENOMEM (-4)
+
+#define LRF_MAX_RANK 16      /* largest rank the BCD kernels take in this build */
+#define LRF_PATCH_ELEMS 64   /* N = p*q handled by the kernels in this build (8x8 patches) */
+
+typedef struct lrf_ctx lrf_ctx;
+
+/* ---- runtime ------------------------------------------------------------------------------ */
+const char* lrf_last_error(void);
+int lrf_device_count(void);
+int lrf_version(void);
+
+int lrf_ctx_create(int device, lrf_ctx** out);
+void lrf_ctx_destroy(lrf_ctx* ctx);
+/* hip_stream: a hipStream_t (NULL = the context's own stream, created at lrf_ctx_create). */
+int lrf_ctx_set_stream(lrf_ctx* ctx, void* hip_stream);
+int lrf_ctx_synchronize(lrf_ctx* ctx);
+/* bytes of scratch the context currently holds */
+size_t lrf_ctx_workspace_bytes(const lrf_ctx* ctx);
+
+/* Per-kernel timing with HIP events on the context's stream (off by default; when on, every launch
+ * of the kernels below is bracketed by events).  kernel ids: LRF_K_*.  lrf_ctx_kernel_time
+ * synchronises the stream and returns the accumulated milliseconds and launch count. */
+#define LRF_K_PLANES 0       /* rgb -> patch matrices          */
+#define LRF_K_INIT 1         /* Gram + Jacobi eigen-solve      */
+#define LRF_K_BCD 2          /* U update + X^T U partials      */
+#define LRF_K_VUPDATE 3      /* V update                       */
+#define LRF_K_DECODE 4       /* factors -> rgb                 */
+#define LRF_K_COUNT 5
+int lrf_ctx_profile(lrf_ctx* ctx, int enable);
+int lrf_ctx_kernel_time(lrf_ctx* ctx, int kernel_id, double* total_ms, long* launches);
+int lrf_ctx_profile_reset(lrf_ctx* ctx);
+
+/* ---- memory helpers (for hosts with no GPU runtime of their own) --------------------------- */
+int lrf_malloc(lrf_ctx* ctx, size_t bytes, void** out_dev);
+int lrf_free(lrf_ctx* ctx, void* dev);
+int lrf_memcpy_h2d(lrf_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes); /* synchronous */
+int lrf_memcpy_d2h(lrf_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes); /* synchronous */
+
+/* ---- geometry ------------------------------------------------------------------------------
+ * Plane c (0 = Y, 1 = Cb, 2 = Cr) of an H x W image under the default qmf_encode branch
+ * (color_space="YCbCr", scale_factor=(0.5,0.5), patch 8x8): size after chroma down-sampling
+ * (lrf/compression/qmf.py:230), after reflect padding (lrf/compression/utils.py:108-132) and the
+ * number of patches M (lrf/compression/qmf.py:43-56). */
+int lrf_plane_dims(int64_t H, int64_t W, int c, int64_t* h, int64_t* w, int64_t* hp, int64_t* wp, int64_t* M);
+
+/* ---- the hot path -------------------------------------------------------------------------- */
+
+/*
+ * uint8 RGB images [B,3,H,W] -> patch matrices.  Replaces, for every image, image.float();
+ * rgb_to_ycbcr; chroma_downsampling(mode="area"); pad_image(reflect); patchify:
+ * lrf/compression/qmf.py:227-242, lrf/compression/utils.py:24-47,76-95,108-132.
+ * X: per image the three matrices back to back, [M_Y,64] [M_Cb,64] [M_Cr,64], fp32 row-major
+ * (image stride = (M_Y + M_Cb + M_Cr) * 64 floats).
+ */
+int lrf_qmf_planes_from_rgb_u8(lrf_ctx* ctx, const uint8_t* rgb, int64_t B, int64_t H, int64_t W, float* X);
+
+/*
+ * QMF(rank=R, num_iters=K, bounds=(lo,hi), factor=(0,1)).decompose(x) for a batch of B matrices of
+ * one shape: replaces the call sites lrf/compression/qmf.py:190,209,257,281 and the body
+ * lrf/factorization/qmf.py:197-214 (SVDInit :42-71, CoordinateDescent.update_u/update_v :93-139,
+ * QMF._project :191-195).
+ *   X    [B,M,N] fp32, N == LRF_PATCH_ELEMS, 1 <= R <= LRF_MAX_RANK, K >= 1
+ *   sign optional [B,R] int8 (NULL = default): sign imposed on sum_j (j+1) v0[j,r] of initial
+ *        component r; 0 entries mean default (-1).  The reference's sign is LAPACK's arbitrary
+ *        choice (SURVEY.md §7 hard part 1); passing the reference's signs reproduces its factors.
+ *   U    [B,M,R] int8,  V [B,N,R] int8
+ */
+int lrf_qmf_decompose_f32(lrf_ctx* ctx, const float* X, int64_t B, int64_t M, int64_t N, int R, int K,
+                          int lo, int hi, const int8_t* sign, int8_t* U, int8_t* V);
+
+/*
+ * The K block-coordinate-descent iterations alone, from caller-supplied initial factors: the loop
+ * lrf/factorization/qmf.py:207-212 (CoordinateDescent.forward :149-164).  U0 [B,M,R], V0 [B,N,R] fp32.
+ */
+int lrf_qmf_bcd_f32(lrf_ctx* ctx, const float* X, int64_t B, int64_t M, int64_t N, int R, int K,
+                    int lo, int hi, const float* U0, const float* V0, int8_t* U, int8_t* V);
+
+/*
+ * The initial factors alone (what SVDInit.forward returns, lrf/factorization/qmf.py:42-71):
+ * u0 = U sqrt(s) [B,M,R], v0 = (sqrt(s) Vh)^T [B,N,R], fp32.  Also the arithmetic of svd_encode's
+ * lrf/compression/svd.py:179-183 for N == LRF_PATCH_ELEMS.
+ */
+int lrf_qmf_svd_init_f32(lrf_ctx* ctx, const float* X, int64_t B, int64_t M, int64_t N, int R,
+                         const int8_t* sign, float* U0, float* V0);
+
+/*
+ * Fused encode of B images (default qmf_encode branch, everything between image.float() and the
+ * byte container): lrf/compression/qmf.py:227-262.
+ *   rgb  [B,3,H,W] uint8;  R[3] ranks of (Y, Cb, Cr);  sign optional [B, R[0]+R[1]+R[2]] int8
+ *   U    per image [M_Y,R0] [M_Cb,R1] [M_Cr,R2] int8 back to back; V likewise with 64 rows each.
+ */
+int lrf_qmf_encode_rgb_u8(lrf_ctx* ctx, const uint8_t* rgb, int64_t B, int64_t H, int64_t W, const int R[3],
+                          int K, int lo, int hi, const int8_t* sign, int8_t* U, int8_t* V);
+
+/*
+ * Fused decode of B images: QMF.reconstruct, depatchify, unpad_image, chroma_upsampling(nearest),
+ * ycbcr_to_rgb, to_dtype(uint8): lrf/compression/qmf.py:329-351, lrf/factorization/qmf.py:216-223,
+ * lrf/compression/utils.py:50-73,98-105,135-182.  U, V laid out as lrf_qmf_encode_rgb_u8 writes them.
+ */
+int lrf_qmf_decode_rgb_u8(lrf_ctx* ctx, const int8_t* U, const int8_t* V, int64_t B, int64_t H, int64_t W,
+                          const int R[3], uint8_t* rgb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LRF_HIP_H */

@@ -1,0 +1,230 @@
+"""ctypes binding of liblrf_hip.so (include/lrf_hip.h).  There is no CPU fallback: if the HIP
+library is missing or no GPU is visible, the calls raise."""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblrf_hip.so")
+
+LRF_MAX_RANK = 16
+LRF_K_PLANES, LRF_K_INIT, LRF_K_BCD, LRF_K_VUPDATE, LRF_K_DECODE = range(5)
+KERNEL_NAMES = {LRF_K_PLANES: "k_planes", LRF_K_INIT: "k_init", LRF_K_BCD: "k_bcd",
+                LRF_K_VUPDATE: "k_vupdate", LRF_K_DECODE: "k_decode"}
+
+_lib = None
+_lock = threading.Lock()
+
+c_void_p, c_int, c_i64, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
+
+
+class LrfError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads liblrf_hip.so; raises ImportError when it has not been built (see __graft_entry__.build)."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} not found: build the HIP extension first "
+                              "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+        lib = ctypes.CDLL(LIB_PATH)
+        lib.lrf_last_error.restype = ctypes.c_char_p
+        lib.lrf_ctx_workspace_bytes.restype = c_size_t
+        lib.lrf_ctx_workspace_bytes.argtypes = [c_void_p]
+        lib.lrf_ctx_create.argtypes = [c_int, ctypes.POINTER(c_void_p)]
+        lib.lrf_ctx_destroy.argtypes = [c_void_p]
+        lib.lrf_ctx_destroy.restype = None
+        lib.lrf_ctx_set_stream.argtypes = [c_void_p, c_void_p]
+        lib.lrf_ctx_synchronize.argtypes = [c_void_p]
+        lib.lrf_ctx_profile.argtypes = [c_void_p, c_int]
+        lib.lrf_ctx_profile_reset.argtypes = [c_void_p]
+        lib.lrf_ctx_kernel_time.argtypes = [c_void_p, c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long)]
+        lib.lrf_malloc.argtypes = [c_void_p, c_size_t, ctypes.POINTER(c_void_p)]
+        lib.lrf_free.argtypes = [c_void_p, c_void_p]
+        lib.lrf_memcpy_h2d.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t]
+        lib.lrf_memcpy_d2h.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t]
+        lib.lrf_plane_dims.argtypes = [c_i64, c_i64, c_int] + [ctypes.POINTER(c_i64)] * 5
+        lib.lrf_qmf_planes_from_rgb_u8.argtypes = [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_void_p]
+        lib.lrf_qmf_decompose_f32.argtypes = [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int,
+                                              c_void_p, c_void_p, c_void_p]
+        lib.lrf_qmf_bcd_f32.argtypes = [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int,
+                                        c_void_p, c_void_p, c_void_p, c_void_p]
+        lib.lrf_qmf_svd_init_f32.argtypes = [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p]
+        lib.lrf_qmf_encode_rgb_u8.argtypes = [c_void_p, c_void_p, c_i64, c_i64, c_i64, ctypes.POINTER(c_int), c_int, c_int,
+                                              c_int, c_void_p, c_void_p, c_void_p]
+        lib.lrf_qmf_decode_rgb_u8.argtypes = [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, ctypes.POINTER(c_int),
+                                              c_void_p]
+        _lib = lib
+        return lib
+
+
+EXPORTS = ["lrf_last_error", "lrf_device_count", "lrf_version", "lrf_ctx_create", "lrf_ctx_destroy", "lrf_ctx_set_stream",
+           "lrf_ctx_synchronize", "lrf_ctx_workspace_bytes", "lrf_ctx_profile", "lrf_ctx_kernel_time",
+           "lrf_ctx_profile_reset", "lrf_malloc", "lrf_free", "lrf_memcpy_h2d", "lrf_memcpy_d2h", "lrf_plane_dims",
+           "lrf_qmf_planes_from_rgb_u8", "lrf_qmf_decompose_f32", "lrf_qmf_bcd_f32", "lrf_qmf_svd_init_f32",
+           "lrf_qmf_encode_rgb_u8", "lrf_qmf_decode_rgb_u8"]
+
+
+def check(rc):
+    if rc == 0:
+        return
+    msg = load().lrf_last_error().decode(errors="replace")
+    if rc == -1:
+        raise ValueError(msg)
+    if rc == -2:
+        raise NotImplementedError(msg)
+    if rc == -4:
+        raise MemoryError(msg)
+    raise LrfError(msg)
+
+
+def plane_dims(H, W):
+    """[(h, w, hp, wp, M)] of the Y, Cb, Cr planes of an H x W image (host-only arithmetic)."""
+    out = []
+    for c in range(3):
+        v = [c_i64() for _ in range(5)]
+        check(load().lrf_plane_dims(H, W, c, *[ctypes.byref(x) for x in v]))
+        out.append(tuple(int(x.value) for x in v))
+    return out
+
+
+def _dptr(t):
+    """device pointer of a torch CUDA tensor (must be contiguous) or None"""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "expected a contiguous CUDA tensor"
+    return c_void_p(t.data_ptr())
+
+
+class Context:
+    """One lrf_ctx: a device, a stream and the scratch workspace.  Not thread-safe."""
+
+    def __init__(self, device=0):
+        self._lib = load()
+        self._h = c_void_p()
+        check(self._lib.lrf_ctx_create(int(device), ctypes.byref(self._h)))
+        self.device = int(device)
+
+    def close(self):
+        if self._h:
+            self._lib.lrf_ctx_destroy(self._h)
+            self._h = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def use_torch_stream(self):
+        import torch
+        check(self._lib.lrf_ctx_set_stream(self._h, c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+
+    def synchronize(self):
+        check(self._lib.lrf_ctx_synchronize(self._h))
+
+    def workspace_bytes(self):
+        return int(self._lib.lrf_ctx_workspace_bytes(self._h))
+
+    def profile(self, enable=True):
+        check(self._lib.lrf_ctx_profile(self._h, int(bool(enable))))
+
+    def profile_reset(self):
+        check(self._lib.lrf_ctx_profile_reset(self._h))
+
+    def kernel_time(self, kernel_id):
+        ms, n = ctypes.c_double(), ctypes.c_long()
+        check(self._lib.lrf_ctx_kernel_time(self._h, kernel_id, ctypes.byref(ms), ctypes.byref(n)))
+        return float(ms.value), int(n.value)
+
+    # ---- hot path (torch CUDA tensors in / out) ----
+    def planes_from_rgb(self, rgb):
+        import torch
+        B, C, H, W = rgb.shape
+        assert C == 3 and rgb.dtype == torch.uint8
+        floats = sum(d[4] for d in plane_dims(H, W)) * 64
+        X = torch.empty((B, floats), dtype=torch.float32, device=rgb.device)
+        self.use_torch_stream()
+        check(self._lib.lrf_qmf_planes_from_rgb_u8(self._h, _dptr(rgb), B, H, W, _dptr(X)))
+        return X
+
+    def decompose(self, X, R, K, lo, hi, sign=None):
+        import torch
+        B, M, N = X.shape
+        U = torch.empty((B, M, R), dtype=torch.int8, device=X.device)
+        V = torch.empty((B, N, R), dtype=torch.int8, device=X.device)
+        self.use_torch_stream()
+        check(self._lib.lrf_qmf_decompose_f32(self._h, _dptr(X), B, M, N, R, K, lo, hi, _dptr(sign), _dptr(U), _dptr(V)))
+        return U, V
+
+    def bcd(self, X, U0, V0, K, lo, hi):
+        import torch
+        B, M, N = X.shape
+        R = U0.shape[-1]
+        U = torch.empty((B, M, R), dtype=torch.int8, device=X.device)
+        V = torch.empty((B, N, R), dtype=torch.int8, device=X.device)
+        self.use_torch_stream()
+        check(self._lib.lrf_qmf_bcd_f32(self._h, _dptr(X), B, M, N, R, K, lo, hi, _dptr(U0), _dptr(V0), _dptr(U), _dptr(V)))
+        return U, V
+
+    def svd_init(self, X, R, sign=None):
+        import torch
+        B, M, N = X.shape
+        U0 = torch.empty((B, M, R), dtype=torch.float32, device=X.device)
+        V0 = torch.empty((B, N, R), dtype=torch.float32, device=X.device)
+        self.use_torch_stream()
+        check(self._lib.lrf_qmf_svd_init_f32(self._h, _dptr(X), B, M, N, R, _dptr(sign), _dptr(U0), _dptr(V0)))
+        return U0, V0
+
+    def encode_rgb(self, rgb, ranks, K, lo, hi, sign=None, out=None):
+        """rgb uint8 [B,3,H,W] (CUDA) -> (U int8 [B, sum M_c R_c], V int8 [B, 64 sum R_c])"""
+        import torch
+        B, C, H, W = rgb.shape
+        assert C == 3 and rgb.dtype == torch.uint8
+        dims = plane_dims(H, W)
+        nu = sum(d[4] * r for d, r in zip(dims, ranks))
+        nv = 64 * sum(ranks)
+        if out is None:
+            U = torch.empty((B, nu), dtype=torch.int8, device=rgb.device)
+            V = torch.empty((B, nv), dtype=torch.int8, device=rgb.device)
+        else:
+            U, V = out
+        R = (c_int * 3)(*[int(r) for r in ranks])
+        self.use_torch_stream()
+        check(self._lib.lrf_qmf_encode_rgb_u8(self._h, _dptr(rgb), B, H, W, R, K, lo, hi, _dptr(sign), _dptr(U), _dptr(V)))
+        return U, V
+
+    def decode_rgb(self, U, V, H, W, ranks):
+        import torch
+        B = U.shape[0]
+        rgb = torch.empty((B, 3, H, W), dtype=torch.uint8, device=U.device)
+        R = (c_int * 3)(*[int(r) for r in ranks])
+        self.use_torch_stream()
+        check(self._lib.lrf_qmf_decode_rgb_u8(self._h, _dptr(U), _dptr(V), B, H, W, R, _dptr(rgb)))
+        return rgb
+
+
+_contexts = {}
+
+
+def context(device=None) -> Context:
+    """The cached per-device context of the calling process."""
+    import torch
+    if not torch.cuda.is_available():
+        raise LrfError("lrf_amd needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+    if device is None:
+        device = torch.cuda.current_device()
+    device = torch.device("cuda", device).index if not isinstance(device, int) else device
+    with _lock:
+        ctx = _contexts.get(device)
+    if ctx is None:
+        ctx = Context(device)
+        with _lock:
+            _contexts[device] = ctx
+    return ctx

@@ -1,0 +1,167 @@
+"""qmf_encode / qmf_decode with the reference's signatures (lrf/compression/qmf.py:116-353), running the
+arithmetic on the MI355X.  Python keeps the byte container (JSON metadata + per-column zlib), exactly
+as the reference does on the host."""
+import math
+from typing import Iterable, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .container import (bytes_to_dict, combine_bytes, decode_tensor, dict_to_bytes, encode_tensor, separate_bytes)
+
+
+def qmf_ranks(image_hw, rank=None, quality=None):
+    """The (Y, Cb, Cr) ranks qmf_encode uses: lrf/compression/qmf.py:215-225, 244-250."""
+    H, W = image_hw
+    if not isinstance(rank, Iterable):
+        rank = (None, None, None) if rank is None else (rank, max(rank // 2, 1), max(rank // 2, 1))
+    if not isinstance(quality, Iterable):
+        quality = (None, None, None) if quality is None else (quality, quality / 2, quality / 2)
+    out = []
+    for i, (_, _, _, _, M) in enumerate(_lib.plane_dims(H, W)):
+        if rank[i] is None:
+            assert quality[i] >= 0 and quality[i] <= 100, "'quality' must be between 0 and 100."
+            out.append(max(round(min(M, 64) * quality[i] / 100), 1))
+        else:
+            out.append(rank[i])
+    return out
+
+
+def _check_hip_branch(color_space, scale_factor, patch, patch_size, bounds, dtype, kwargs):
+    if color_space != "YCbCr" or not patch or tuple(patch_size) != (8, 8) or tuple(scale_factor) != (0.5, 0.5):
+        raise NotImplementedError("HIP path covers color_space='YCbCr', patch=True, patch_size=(8,8), "
+                                  "scale_factor=(0.5,0.5) (the other qmf_encode branches are SURVEY.md §8f N3)")
+    if dtype is not torch.int8:
+        raise NotImplementedError("HIP path stores int8 factors only")
+    num_iters = kwargs.pop("num_iters", 10)
+    init_sign = kwargs.pop("init_sign", None)
+    kwargs.pop("verbose", None)
+    extra = {k: v for k, v in kwargs.items() if not (k in ("l2", "l1_ratio") and v in (0, (0, 0))) and
+             not (k == "eps" and v == 1e-16)}
+    if extra:
+        raise NotImplementedError(f"QMF options {sorted(extra)} are not on the HIP path")
+    if num_iters < 1:
+        raise NotImplementedError("num_iters=0 (float SVD factors cast to int8) is not on the HIP path")
+    lo, hi = math.ceil(bounds[0]), math.floor(bounds[1])
+    return num_iters, lo, hi, init_sign
+
+
+def qmf_factorize_batch(images: torch.Tensor, ranks: Sequence[int], num_iters: int = 10, bounds=(-16, 15),
+                        init_sign=None, out=None):
+    """GPU-only part of the encoder for a batch [B,3,H,W] of uint8 images already in HBM.
+
+    Returns (U, V): int8 CUDA tensors [B, sum_c M_c R_c] and [B, 64 sum_c R_c] holding, per image, the factors of
+    the Y, Cb, Cr planes back to back (row-major [M_c, R_c] / [64, R_c])."""
+    assert images.is_cuda and images.dtype == torch.uint8 and images.dim() == 4 and images.shape[1] == 3
+    ctx = _lib.context(images.device.index)
+    sign = None
+    if init_sign is not None:
+        sign = torch.as_tensor(init_sign, dtype=torch.int8).reshape(-1, sum(ranks))
+        sign = sign.expand(images.shape[0], sum(ranks)).contiguous().cuda(images.device)
+    return ctx.encode_rgb(images.contiguous(), list(ranks), num_iters, math.ceil(bounds[0]), math.floor(bounds[1]),
+                          sign, out=out)
+
+
+def split_factors(U_row: np.ndarray, V_row: np.ndarray, image_hw, ranks):
+    """One image's packed factor rows -> [u_y, v_y, u_cb, v_cb, u_cr, v_cr] numpy int8 matrices."""
+    H, W = image_hw
+    out, uo, vo = [], 0, 0
+    for (_, _, _, _, M), R in zip(_lib.plane_dims(H, W), ranks):
+        out.append(U_row[uo:uo + M * R].reshape(M, R))
+        out.append(V_row[vo:vo + 64 * R].reshape(64, R))
+        uo += M * R
+        vo += 64 * R
+    return out
+
+
+def pack_image(factors, image_hw, ranks, bounds, patch_size=(8, 8), dtype_name="uint8") -> bytes:
+    """metadata + six factor blobs -> the reference's byte stream (lrf/compression/qmf.py:157-162,233-254,288-290)."""
+    H, W = image_hw
+    dims = _lib.plane_dims(H, W)
+    metadata = {
+        "dtype": dtype_name,
+        "color space": "YCbCr",
+        "patch": True,
+        "bounds": bounds,
+        "patch size": patch_size,
+        "original size": [[d[0], d[1]] for d in dims],
+        "padded size": [[d[2], d[3]] for d in dims],
+        "rank": list(ranks),
+    }
+    return combine_bytes([dict_to_bytes(metadata), combine_bytes([encode_tensor(f) for f in factors])])
+
+
+def qmf_encode_batch(images: torch.Tensor, rank=None, quality=None, bounds=(-16, 15), num_iters: int = 10,
+                     init_sign=None) -> list:
+    """Batched qmf_encode (default branch) -> list of byte streams, one per image."""
+    assert (rank, quality) != (None, None), "Either 'rank' or 'quality' must be specified."
+    ctx = _lib.context(images.device.index if images.is_cuda else None)
+    dev = images if images.is_cuda else images.cuda(ctx.device)
+    H, W = images.shape[-2:]
+    ranks = qmf_ranks((H, W), rank, quality)
+    U, V = qmf_factorize_batch(dev, ranks, num_iters, bounds, init_sign)
+    Uh, Vh = U.cpu().numpy(), V.cpu().numpy()
+    dtype_name = str(images.dtype).split(".")[-1]
+    return [pack_image(split_factors(Uh[b], Vh[b], (H, W), ranks), (H, W), ranks, bounds, (8, 8), dtype_name)
+            for b in range(images.shape[0])]
+
+
+def qmf_encode(image: torch.Tensor, rank=None, quality=None, color_space: str = "YCbCr",
+               scale_factor=(0.5, 0.5), patch: bool = True, patch_size=(8, 8), bounds=(-16, 15),
+               dtype: torch.dtype = torch.int8, **kwargs) -> bytes:
+    """QMF compression of one image [3,H,W]: same signature and byte stream as the reference's
+    lrf.qmf_encode (lrf/compression/qmf.py:116-292)."""
+    assert (rank, quality) != (None, None), "Either 'rank' or 'quality' must be specified."
+    assert color_space in ("RGB", "YCbCr"), "`color_space` must be one of 'RGB' or 'YCbCr'."
+    num_iters, lo, hi, init_sign = _check_hip_branch(color_space, scale_factor, patch, patch_size, bounds, dtype,
+                                                     dict(kwargs))
+    if image.dtype != torch.uint8:
+        raise NotImplementedError("HIP path takes uint8 images")
+    H, W = image.shape[-2:]
+    ranks = qmf_ranks((H, W), rank, quality)
+    ctx = _lib.context(image.device.index if image.is_cuda else None)
+    dev = (image if image.is_cuda else image.cuda(ctx.device)).unsqueeze(0)
+    U, V = qmf_factorize_batch(dev, ranks, num_iters, (lo, hi), init_sign)
+    factors = split_factors(U[0].cpu().numpy(), V[0].cpu().numpy(), (H, W), ranks)
+    return pack_image(factors, (H, W), ranks, bounds, patch_size, str(image.dtype).split(".")[-1])
+
+
+def parse_stream(encoded_image: bytes):
+    """-> (metadata, [u_y, v_y, u_cb, v_cb, u_cr, v_cr]) for the YCbCr branch (lrf/compression/qmf.py:306-327)."""
+    encoded_metadata, encoded_factors = separate_bytes(encoded_image, 2)
+    metadata = bytes_to_dict(encoded_metadata)
+    if metadata["color space"] != "YCbCr" or not metadata["patch"] or list(metadata["patch size"]) != [8, 8]:
+        raise NotImplementedError("HIP decode covers the YCbCr / 8x8-patch branch only")
+    factors = [decode_tensor(f) for f in separate_bytes(encoded_factors, 6)]
+    return metadata, factors
+
+
+def qmf_decode_batch(streams: Sequence[bytes], device=None) -> torch.Tensor:
+    """Decodes streams of equal geometry and ranks -> uint8 CUDA tensor [B,3,H,W]."""
+    ctx = _lib.context(device)
+    metas, Us, Vs = [], [], []
+    for s in streams:
+        meta, f = parse_stream(s)
+        metas.append(meta)
+        Us.append(np.concatenate([np.ascontiguousarray(f[i], dtype=np.int8).ravel() for i in (0, 2, 4)]))
+        Vs.append(np.concatenate([np.ascontiguousarray(f[i], dtype=np.int8).ravel() for i in (1, 3, 5)]))
+    m0 = metas[0]
+    for m in metas[1:]:
+        assert m["original size"] == m0["original size"] and m["rank"] == m0["rank"], "streams differ in geometry"
+    H, W = m0["original size"][0]
+    dims = _lib.plane_dims(H, W)
+    for c in range(3):  # the stream must describe the geometry the kernels derive from (H, W)
+        if list(m0["original size"][c]) != [dims[c][0], dims[c][1]] or list(m0["padded size"][c]) != [dims[c][2], dims[c][3]]:
+            raise NotImplementedError("stream geometry is not the scale_factor=(0.5,0.5) / 8x8 layout")
+    U = torch.from_numpy(np.stack(Us)).cuda(ctx.device)
+    V = torch.from_numpy(np.stack(Vs)).cuda(ctx.device)
+    if m0["dtype"] != "uint8":
+        raise NotImplementedError("HIP decode writes uint8 images")
+    return ctx.decode_rgb(U, V, H, W, m0["rank"])
+
+
+def qmf_decode(encoded_image: bytes) -> torch.Tensor:
+    """Decode a QMF stream -> uint8 tensor [3,H,W] on the CPU, like the reference's lrf.qmf_decode
+    (lrf/compression/qmf.py:295-353)."""
+    return qmf_decode_batch([encoded_image])[0].cpu()

@@ -1,0 +1,534 @@
+// lrf_api.hip — host side of liblrf_hip.so: context, workspace, launch sequencing, C ABI (include/lrf_hip.h).
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/lrf_hip.h"
+#include "lrf_kernels.hip"
+
+static thread_local char g_err[512] = "";
+
+static int set_err(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) return set_err(LRF_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                                             __FILE__, __LINE__);                                         \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct lrf_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    DevBuf planes, blocks, vf, wf, ppart, x, sign;
+    // host staging for descriptor tables (pinned)
+    void* h_stage = nullptr;
+    size_t h_stage_cap = 0;
+    // profiling
+    bool profile = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[LRF_K_COUNT];
+    std::vector<hipEvent_t> ev_pool;
+    double acc_ms[LRF_K_COUNT] = {0};
+    long acc_n[LRF_K_COUNT] = {0};
+    int init_sweeps = 30;
+};
+
+static int ensure(lrf_ctx* c, DevBuf& b, size_t bytes)
+{
+    if (bytes <= b.cap) return LRF_OK;
+    if (b.p) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t cap = bytes + bytes / 8;
+    hipError_t e = hipMalloc(&b.p, cap);
+    if (e != hipSuccess) return set_err(LRF_ENOMEM, "hipMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
+    b.cap = cap;
+    return LRF_OK;
+}
+
+static int upload(lrf_ctx* c, DevBuf& b, const void* src, size_t bytes)
+{
+    int rc = ensure(c, b, bytes);
+    if (rc) return rc;
+    if (bytes > c->h_stage_cap) {
+        if (c->h_stage) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(hipHostFree(c->h_stage));
+        }
+        HIP_TRY(hipHostMalloc(&c->h_stage, bytes * 2, hipHostMallocDefault));
+        c->h_stage_cap = bytes * 2;
+    }
+    // the staging buffer may still be read by an earlier async copy
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memcpy(c->h_stage, src, bytes);
+    HIP_TRY(hipMemcpyAsync(b.p, c->h_stage, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LRF_OK;
+}
+
+struct Prof {
+    lrf_ctx* c;
+    int id;
+    hipEvent_t a = nullptr, b = nullptr;
+    Prof(lrf_ctx* c_, int id_) : c(c_), id(id_)
+    {
+        if (!c->profile) return;
+        auto get = [&]() {
+            hipEvent_t e;
+            if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); }
+            else (void)hipEventCreate(&e);
+            return e;
+        };
+        a = get();
+        b = get();
+        (void)hipEventRecord(a, c->stream);
+    }
+    ~Prof()
+    {
+        if (!c->profile) return;
+        (void)hipEventRecord(b, c->stream);
+        c->ev[id].push_back({a, b});
+    }
+};
+
+static void fold_events(lrf_ctx* c)
+{
+    for (int k = 0; k < LRF_K_COUNT; k++) {
+        for (auto& pr : c->ev[k]) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+                c->acc_ms[k] += ms;
+                c->acc_n[k] += 1;
+            }
+            c->ev_pool.push_back(pr.first);
+            c->ev_pool.push_back(pr.second);
+        }
+        c->ev[k].clear();
+    }
+}
+
+// ---- geometry ---------------------------------------------------------------------------------
+static void plane_dims(int64_t H, int64_t W, int c, int64_t* h, int64_t* w, int64_t* hp, int64_t* wp, int64_t* M)
+{
+    // F.interpolate(scale_factor=0.5): output size = floor(input * 0.5) (lrf/compression/qmf.py:230)
+    int64_t ph = c ? (int64_t)floor((double)H * 0.5) : H, pw = c ? (int64_t)floor((double)W * 0.5) : W;
+    *h = ph;
+    *w = pw;
+    *hp = ph + (8 - ph % 8) % 8;
+    *wp = pw + (8 - pw % 8) % 8;
+    *M = (*hp / 8) * (*wp / 8);
+}
+
+static int make_geom(int64_t H, int64_t W, ImageGeom* g)
+{
+    long xoff = 0;
+    for (int c = 0; c < 3; c++) {
+        int64_t h, w, hp, wp, M;
+        plane_dims(H, W, c, &h, &w, &hp, &wp, &M);
+        if (h < 1 || w < 1) return set_err(LRF_EINVAL, "image %ldx%ld too small", (long)H, (long)W);
+        // reflect padding needs pad < size (torch raises otherwise)
+        if ((hp - h) / 2 >= h || (hp - h) - (hp - h) / 2 >= h || (wp - w) / 2 >= w || (wp - w) - (wp - w) / 2 >= w)
+            return set_err(LRF_EINVAL, "reflect padding larger than the plane (%ldx%ld)", (long)h, (long)w);
+        PlaneGeom& p = g->p[c];
+        p.h = (int)h; p.w = (int)w; p.hp = (int)hp; p.wp = (int)wp;
+        p.top = (int)((hp - h) / 2); p.left = (int)((wp - w) / 2);
+        p.top_crop = p.top; p.left_crop = p.left;
+        p.nw = (int)(wp / 8);
+        p.M = (int)M;
+        p.xoff = xoff;
+        p.o4 = xoff / 4;
+        xoff += M * 64;
+    }
+    g->img_floats = xoff;
+    g->tot4 = xoff / 4;
+    return LRF_OK;
+}
+
+// ---- descriptor tables ------------------------------------------------------------------------
+struct Tables {
+    std::vector<PlaneDesc> planes;
+    std::vector<BlockDesc> blocks;
+};
+
+static void add_plane(Tables& t, long x_off, long u_off, long v_off, long u0_off, long v0_off, int M, int R, int sign_off)
+{
+    PlaneDesc pd;
+    memset(&pd, 0, sizeof(pd));
+    pd.x_off = x_off; pd.u_off = u_off; pd.v_off = v_off; pd.u0_off = u0_off; pd.v0_off = v0_off;
+    pd.M = M; pd.R = R;
+    pd.blk0 = (int)t.blocks.size();
+    pd.nblk = (M + LRF_KC - 1) / LRF_KC;
+    pd.native_t2_u = ((long)(R - 1) * M < 400) ? 1 : 0;
+    pd.sign_off = sign_off;
+    int pi = (int)t.planes.size();
+    for (int b = 0; b < pd.nblk; b++) t.blocks.push_back(BlockDesc{pi, b * LRF_KC, b, 0});
+    t.planes.push_back(pd);
+}
+
+static int check_params(int64_t M, int64_t N, int R, int K, int lo, int hi)
+{
+    if (N != LRF_PATCH_ELEMS) return set_err(LRF_ENOTSUP, "N=%ld: only N=%d (8x8 patches) is implemented", (long)N, LRF_PATCH_ELEMS);
+    if (R < 1) return set_err(LRF_EINVAL, "rank must be >= 1 (got %d)", R);
+    if (R > LRF_MAX_RANK) return set_err(LRF_ENOTSUP, "rank %d > %d not implemented", R, LRF_MAX_RANK);
+    if (K < 1) return set_err(LRF_ENOTSUP, "num_iters=%d: use lrf_qmf_svd_init_f32 for K=0", K);
+    if (lo > hi || lo < -128 || hi > 127) return set_err(LRF_EINVAL, "bounds (%d,%d) outside int8", lo, hi);
+    if (M < 1) return set_err(LRF_EINVAL, "M must be >= 1");
+    long mx = (long)(abs(lo) > abs(hi) ? abs(lo) : abs(hi));
+    if (mx * mx * (long)M >= (1L << 24))
+        return set_err(LRF_ENOTSUP, "bounds (%d,%d) with M=%ld: U^T U not exact in fp32", lo, hi, (long)M);
+    return LRF_OK;
+}
+
+static int upload_tables(lrf_ctx* c, const Tables& t)
+{
+    int rc = upload(c, c->planes, t.planes.data(), t.planes.size() * sizeof(PlaneDesc));
+    if (rc) return rc;
+    rc = upload(c, c->blocks, t.blocks.data(), t.blocks.size() * sizeof(BlockDesc));
+    if (rc) return rc;
+    size_t np = t.planes.size(), nb = t.blocks.size();
+    if ((rc = ensure(c, c->vf, np * 64 * LRF_RP * sizeof(float)))) return rc;
+    if ((rc = ensure(c, c->wf, np * 64 * LRF_RP * sizeof(float)))) return rc;
+    if ((rc = ensure(c, c->ppart, nb * 64 * LRF_RP * sizeof(float)))) return rc;
+    return LRF_OK;
+}
+
+#define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
+
+static const size_t INIT_LDS = 2 * 64 * 64 * sizeof(double) + 64 * sizeof(double) + 64 * sizeof(int) * 2 + 16;
+
+static int run_init(lrf_ctx* c, const float* X, int nplanes, const int8_t* sign_dev)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_init, hipFuncAttributeMaxDynamicSharedMemorySize, (int)INIT_LDS));
+        attr_set = true;
+    }
+    Prof p(c, LRF_K_INIT);
+    hipLaunchKernelGGL(k_init, dim3(nplanes), dim3(256), INIT_LDS, c->stream, X, (const PlaneDesc*)c->planes.p, sign_dev,
+                       (float*)c->vf.p, (float*)c->wf.p, c->init_sweeps);
+    LAUNCH_CHECK();
+    return LRF_OK;
+}
+
+// mode: 1 = old U from X @ W0 (after run_init), 2 = old U from caller's fp32 U0
+static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, int hi, int first_mode, const float* U0,
+                   int8_t* U, int8_t* V)
+{
+    const PlaneDesc* pl = (const PlaneDesc*)c->planes.p;
+    const BlockDesc* bl = (const BlockDesc*)c->blocks.p;
+    float* vf = (float*)c->vf.p;
+    float* wf = (float*)c->wf.p;
+    float* pp = (float*)c->ppart.p;
+    int nb = (int)t.blocks.size(), np = (int)t.planes.size();
+    float flo = (float)lo, fhi = (float)hi;
+    for (int it = 0; it < K; it++) {
+        {
+            Prof p(c, LRF_K_BCD);
+            if (it == 0 && first_mode == 1)
+                hipLaunchKernelGGL(k_bcd<1>, dim3(nb), dim3(256), 0, c->stream, X, pl, bl, vf, wf, U0, U, pp, flo, fhi);
+            else if (it == 0 && first_mode == 2)
+                hipLaunchKernelGGL(k_bcd<2>, dim3(nb), dim3(256), 0, c->stream, X, pl, bl, vf, wf, U0, U, pp, flo, fhi);
+            else
+                hipLaunchKernelGGL(k_bcd<0>, dim3(nb), dim3(256), 0, c->stream, X, pl, bl, vf, wf, U0, U, pp, flo, fhi);
+            LAUNCH_CHECK();
+        }
+        {
+            Prof p(c, LRF_K_VUPDATE);
+            hipLaunchKernelGGL(k_vupdate, dim3(np), dim3(256), 0, c->stream, pl, (const int8_t*)U, (const float*)pp, vf, V,
+                               flo, fhi, it == K - 1 ? 1 : 0);
+            LAUNCH_CHECK();
+        }
+    }
+    return LRF_OK;
+}
+
+// ---- C ABI ------------------------------------------------------------------------------------
+extern "C" {
+
+const char* lrf_last_error(void) { return g_err; }
+
+int lrf_version(void) { return 1; }
+
+int lrf_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int lrf_ctx_create(int device, lrf_ctx** out)
+{
+    if (!out) return set_err(LRF_EINVAL, "out is NULL");
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return set_err(LRF_EINVAL, "device %d out of range (%d visible)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    lrf_ctx* c = new lrf_ctx();
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return set_err(LRF_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return LRF_OK;
+}
+
+void lrf_ctx_destroy(lrf_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    fold_events(c);
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    DevBuf* bufs[] = {&c->planes, &c->blocks, &c->vf, &c->wf, &c->ppart, &c->x, &c->sign};
+    for (DevBuf* b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int lrf_ctx_set_stream(lrf_ctx* c, void* hip_stream)
+{
+    if (!c) return set_err(LRF_EINVAL, "ctx is NULL");
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    if (s == c->stream) return LRF_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->stream = s;
+    return LRF_OK;
+}
+
+int lrf_ctx_synchronize(lrf_ctx* c)
+{
+    if (!c) return set_err(LRF_EINVAL, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LRF_OK;
+}
+
+size_t lrf_ctx_workspace_bytes(const lrf_ctx* c)
+{
+    if (!c) return 0;
+    return c->planes.cap + c->blocks.cap + c->vf.cap + c->wf.cap + c->ppart.cap + c->x.cap + c->sign.cap;
+}
+
+int lrf_ctx_profile(lrf_ctx* c, int enable)
+{
+    if (!c) return set_err(LRF_EINVAL, "ctx is NULL");
+    c->profile = enable != 0;
+    return LRF_OK;
+}
+
+int lrf_ctx_kernel_time(lrf_ctx* c, int id, double* total_ms, long* launches)
+{
+    if (!c || id < 0 || id >= LRF_K_COUNT) return set_err(LRF_EINVAL, "bad kernel id");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    fold_events(c);
+    if (total_ms) *total_ms = c->acc_ms[id];
+    if (launches) *launches = c->acc_n[id];
+    return LRF_OK;
+}
+
+int lrf_ctx_profile_reset(lrf_ctx* c)
+{
+    if (!c) return set_err(LRF_EINVAL, "ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    fold_events(c);
+    for (int k = 0; k < LRF_K_COUNT; k++) { c->acc_ms[k] = 0; c->acc_n[k] = 0; }
+    return LRF_OK;
+}
+
+int lrf_malloc(lrf_ctx* c, size_t bytes, void** out)
+{
+    if (!c || !out) return set_err(LRF_EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    hipError_t e = hipMalloc(out, bytes ? bytes : 1);
+    if (e != hipSuccess) return set_err(LRF_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return LRF_OK;
+}
+
+int lrf_free(lrf_ctx* c, void* p)
+{
+    if (!c) return set_err(LRF_EINVAL, "ctx is NULL");
+    if (p) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipFree(p));
+    }
+    return LRF_OK;
+}
+
+int lrf_memcpy_h2d(lrf_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    if (!c) return set_err(LRF_EINVAL, "ctx is NULL");
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LRF_OK;
+}
+
+int lrf_memcpy_d2h(lrf_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    if (!c) return set_err(LRF_EINVAL, "ctx is NULL");
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LRF_OK;
+}
+
+int lrf_plane_dims(int64_t H, int64_t W, int c, int64_t* h, int64_t* w, int64_t* hp, int64_t* wp, int64_t* M)
+{
+    if (c < 0 || c > 2 || H < 1 || W < 1 || !h || !w || !hp || !wp || !M) return set_err(LRF_EINVAL, "bad argument");
+    plane_dims(H, W, c, h, w, hp, wp, M);
+    return LRF_OK;
+}
+
+int lrf_qmf_planes_from_rgb_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_t H, int64_t W, float* X)
+{
+    if (!c || !rgb || !X) return set_err(LRF_EINVAL, "NULL argument");
+    if (B < 1 || B > 65535) return set_err(LRF_EINVAL, "B=%ld out of range [1,65535]", (long)B);
+    ImageGeom g;
+    int rc = make_geom(H, W, &g);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    Prof p(c, LRF_K_PLANES);
+    hipLaunchKernelGGL(k_planes, dim3((unsigned)((g.tot4 + 255) / 256), (unsigned)B), dim3(256), 0, c->stream, rgb, (int)H,
+                       (int)W, g, X);
+    LAUNCH_CHECK();
+    return LRF_OK;
+}
+
+static void uniform_tables(Tables& t, int64_t B, int64_t M, int R, bool with_sign)
+{
+    for (int64_t b = 0; b < B; b++)
+        add_plane(t, b * M * 64, b * M * R, b * 64 * R, b * M * R, b * 64 * R, (int)M, R, with_sign ? (int)(b * R) : -1);
+}
+
+int lrf_qmf_decompose_f32(lrf_ctx* c, const float* X, int64_t B, int64_t M, int64_t N, int R, int K, int lo, int hi,
+                          const int8_t* sign, int8_t* U, int8_t* V)
+{
+    if (!c || !X || !U || !V) return set_err(LRF_EINVAL, "NULL argument");
+    int rc = check_params(M, N, R, K, lo, hi);
+    if (rc) return rc;
+    if (B < 1) return set_err(LRF_EINVAL, "B must be >= 1");
+    HIP_TRY(hipSetDevice(c->device));
+    Tables t;
+    uniform_tables(t, B, M, R, sign != nullptr);
+    if ((rc = upload_tables(c, t))) return rc;
+    if ((rc = run_init(c, X, (int)t.planes.size(), sign))) return rc;
+    return run_bcd(c, X, t, K, lo, hi, 1, nullptr, U, V);
+}
+
+int lrf_qmf_bcd_f32(lrf_ctx* c, const float* X, int64_t B, int64_t M, int64_t N, int R, int K, int lo, int hi,
+                    const float* U0, const float* V0, int8_t* U, int8_t* V)
+{
+    if (!c || !X || !U || !V || !U0 || !V0) return set_err(LRF_EINVAL, "NULL argument");
+    int rc = check_params(M, N, R, K, lo, hi);
+    if (rc) return rc;
+    if (B < 1) return set_err(LRF_EINVAL, "B must be >= 1");
+    HIP_TRY(hipSetDevice(c->device));
+    Tables t;
+    uniform_tables(t, B, M, R, false);
+    if ((rc = upload_tables(c, t))) return rc;
+    hipLaunchKernelGGL(k_load_v0, dim3((unsigned)t.planes.size()), dim3(256), 0, c->stream, (const PlaneDesc*)c->planes.p, V0,
+                       (float*)c->vf.p);
+    LAUNCH_CHECK();
+    return run_bcd(c, X, t, K, lo, hi, 2, U0, U, V);
+}
+
+int lrf_qmf_svd_init_f32(lrf_ctx* c, const float* X, int64_t B, int64_t M, int64_t N, int R, const int8_t* sign,
+                         float* U0, float* V0)
+{
+    if (!c || !X || !U0 || !V0) return set_err(LRF_EINVAL, "NULL argument");
+    int rc = check_params(M, N, R, 1, -16, 15);
+    if (rc) return rc;
+    if (B < 1) return set_err(LRF_EINVAL, "B must be >= 1");
+    HIP_TRY(hipSetDevice(c->device));
+    Tables t;
+    uniform_tables(t, B, M, R, sign != nullptr);
+    if ((rc = upload_tables(c, t))) return rc;
+    if ((rc = run_init(c, X, (int)t.planes.size(), sign))) return rc;
+    hipLaunchKernelGGL(k_emit_init, dim3((unsigned)t.blocks.size()), dim3(256), 0, c->stream, X, (const PlaneDesc*)c->planes.p,
+                       (const BlockDesc*)c->blocks.p, (const float*)c->vf.p, (const float*)c->wf.p, U0, V0);
+    LAUNCH_CHECK();
+    return LRF_OK;
+}
+
+int lrf_qmf_encode_rgb_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_t H, int64_t W, const int R[3], int K, int lo,
+                          int hi, const int8_t* sign, int8_t* U, int8_t* V)
+{
+    if (!c || !rgb || !R || !U || !V) return set_err(LRF_EINVAL, "NULL argument");
+    if (B < 1 || B > 65535) return set_err(LRF_EINVAL, "B=%ld out of range [1,65535]", (long)B);
+    ImageGeom g;
+    int rc = make_geom(H, W, &g);
+    if (rc) return rc;
+    for (int ch = 0; ch < 3; ch++)
+        if ((rc = check_params(g.p[ch].M, 64, R[ch], K, lo, hi))) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    if ((rc = ensure(c, c->x, (size_t)B * g.img_floats * sizeof(float)))) return rc;
+    float* X = (float*)c->x.p;
+    if ((rc = lrf_qmf_planes_from_rgb_u8(c, rgb, B, H, W, X))) return rc;
+    // plane table: all Y planes first (four times the work of a chroma plane), then Cb, then Cr
+    long u_img = 0, v_img = 0, s_img = R[0] + R[1] + R[2];
+    long uoff[3], voff[3], soff[3] = {0, R[0], R[0] + R[1]};
+    for (int ch = 0; ch < 3; ch++) {
+        uoff[ch] = u_img; voff[ch] = v_img;
+        u_img += (long)g.p[ch].M * R[ch];
+        v_img += 64L * R[ch];
+    }
+    Tables t;
+    for (int ch = 0; ch < 3; ch++)
+        for (int64_t b = 0; b < B; b++)
+            add_plane(t, b * g.img_floats + g.p[ch].xoff, b * u_img + uoff[ch], b * v_img + voff[ch], 0, 0, g.p[ch].M, R[ch],
+                      sign ? (int)(b * s_img + soff[ch]) : -1);
+    if ((rc = upload_tables(c, t))) return rc;
+    if ((rc = run_init(c, X, (int)t.planes.size(), sign))) return rc;
+    return run_bcd(c, X, t, K, lo, hi, 1, nullptr, U, V);
+}
+
+int lrf_qmf_decode_rgb_u8(lrf_ctx* c, const int8_t* U, const int8_t* V, int64_t B, int64_t H, int64_t W, const int R[3],
+                          uint8_t* rgb)
+{
+    if (!c || !U || !V || !R || !rgb) return set_err(LRF_EINVAL, "NULL argument");
+    if (B < 1 || B > 65535) return set_err(LRF_EINVAL, "B=%ld out of range [1,65535]", (long)B);
+    ImageGeom g;
+    int rc = make_geom(H, W, &g);
+    if (rc) return rc;
+    for (int ch = 0; ch < 3; ch++)
+        if (R[ch] < 1 || R[ch] > 64) return set_err(LRF_EINVAL, "rank %d out of range", R[ch]);
+    HIP_TRY(hipSetDevice(c->device));
+    long u_img = 0, v_img = 0;
+    for (int ch = 0; ch < 3; ch++) {
+        u_img += (long)g.p[ch].M * R[ch];
+        v_img += 64L * R[ch];
+    }
+    long n4 = (long)H * ((W + 3) / 4);
+    Prof p(c, LRF_K_DECODE);
+    hipLaunchKernelGGL(k_decode, dim3((unsigned)((n4 + 255) / 256), (unsigned)B), dim3(256), 0, c->stream, U, V, (int)H, (int)W,
+                       g, R[0], R[1], R[2], u_img, v_img, rgb);
+    LAUNCH_CHECK();
+    return LRF_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,44 @@
+// lrf_internal.h — structures shared by the kernels and the host side of liblrf_hip.so.
+#ifndef LRF_INTERNAL_H
+#define LRF_INTERNAL_H
+#include <stdint.h>
+
+#define LRF_RP 16    // rank padded to one 16-wide MFMA tile (== LRF_MAX_RANK)
+#define LRF_KC 384   // rows per X^T U reduction block (the reference's MKL K-blocking)
+
+// geometry of one colour plane of an image (lrf/compression/qmf.py:230-242)
+struct PlaneGeom {
+    int h, w;          // plane size (chroma: floor(H/2), floor(W/2))
+    int hp, wp;        // after reflect padding to multiples of 8
+    int top, left;     // pad_top / pad_left == unpad start (utils.py:127-130, :148-150)
+    int top_crop, left_crop;
+    int nw;            // patches per row
+    int M;             // number of patches
+    long xoff;         // floats from the image's X base
+    long o4;           // first float4 output index of this plane inside the image
+};
+struct ImageGeom {
+    PlaneGeom p[3];
+    long tot4;         // float4 outputs per image
+    long img_floats;   // floats per image in X
+};
+
+// one matrix to factorise
+struct PlaneDesc {
+    long x_off;        // floats from the X base
+    long u_off;        // elements from the U (int8) base
+    long v_off;        // elements from the V (int8) base
+    long u0_off;       // elements from the fp32 U0 base (init in/out)
+    long v0_off;       // elements from the fp32 V0 base
+    int M, R;
+    int blk0, nblk;    // slots in the X^T U partial table
+    int native_t2_u;   // ATen native order for `uu @ bb` in update_u: (R-1)*M < 400
+    int sign_off;      // offset into the sign vector, or -1
+};
+struct BlockDesc {
+    int plane;         // index into the PlaneDesc table
+    int row0;          // first row of the block
+    int blk;           // block number inside the plane
+    int pad;
+};
+#endif

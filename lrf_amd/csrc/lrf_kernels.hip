@@ -1,0 +1,623 @@
+// lrf_kernels.hip — gfx950 (MI355X, CDNA4) kernels of the QMF hot path.
+//
+// Compiled with -ffp-contract=off: every fused multiply-add below is explicit, because the int8
+// factors must come out bit-identical to the reference's CPU arithmetic (see DESIGN.md "fp32 order").
+// The f32 MFMA (v_mfma_f32_16x16x4_f32) is a k-ordered fmaf chain, which is exactly the order MKL's
+// sgemm micro-kernel uses for the reference's `x @ v` and, in 384-row blocks, for `x.mT @ u`.
+//
+// Reference code restated here (paths relative to the reference root):
+//   k_planes   lrf/compression/utils.py:24-47,76-95,108-132 + lrf/compression/qmf.py:43-56
+//   k_init     lrf/factorization/qmf.py:42-71 (SVDInit; LAPACK replaced by fp64 Gram + Jacobi)
+//   k_bcd      lrf/factorization/qmf.py:93-126 (update_u) + the a = x.mT @ u half of :128-139
+//   k_vupdate  lrf/factorization/qmf.py:128-139 (update_v), :191-195 (_project)
+//   k_decode   lrf/compression/qmf.py:329-351, lrf/compression/utils.py:50-73,98-105,135-182
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lrf_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+#define LRF_EPS 1e-16f
+
+// ------------------------------------------------------------------------------------------------
+// K1: uint8 RGB -> patch matrices (YCbCr, area down-sampled chroma, reflect pad, patchify)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect_idx(int i, int n)
+{
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+    return i;
+}
+
+// offset + einsum("ij,j...->i...") for one pixel: k-ordered fma chain from 0 (sgemm, K = 3).
+__device__ __forceinline__ float ycc_at(const uint8_t* __restrict__ img, long hw, long pix, int c)
+{
+    const float T[3][3] = {{0.299f, 0.587f, 0.114f}, {-0.168736f, -0.331264f, 0.5f}, {0.5f, -0.418688f, -0.081312f}};
+    float acc = 0.f;
+    acc = fmaf(T[c][0], (float)img[pix], acc);
+    acc = fmaf(T[c][1], (float)img[hw + pix], acc);
+    acc = fmaf(T[c][2], (float)img[2 * hw + pix], acc);
+    return (c ? 128.f : 0.f) + acc;
+}
+
+__global__ __launch_bounds__(256) void k_planes(const uint8_t* __restrict__ rgb, int H, int W, ImageGeom g,
+                                                float* __restrict__ X)
+{
+    long o = (long)blockIdx.x * 256 + threadIdx.x; // one float4 of output per thread
+    if (o >= g.tot4) return;
+    const uint8_t* img = rgb + (long)blockIdx.y * 3 * H * W;
+    float* Xi = X + (long)blockIdx.y * g.img_floats;
+    int c = (o >= g.p[1].o4) ? ((o >= g.p[2].o4) ? 2 : 1) : 0;
+    const PlaneGeom pg = g.p[c];
+    long ol = o - pg.o4;
+    int patch = (int)(ol >> 4), a = (int)((ol >> 1) & 7), b4 = (int)(ol & 1) * 4;
+    int hh = patch / pg.nw, ww = patch - hh * pg.nw;
+    int y = reflect_idx(hh * 8 + a - pg.top, pg.h);
+    long hw = (long)H * W;
+    f32x4 out;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int x = reflect_idx(ww * 8 + b4 + i - pg.left, pg.w);
+        float v;
+        if (c == 0) {
+            v = ycc_at(img, hw, (long)y * W + x, 0);
+        } else { // adaptive average pool window, row-major fp32 sum, then / kh / kw
+            int h0 = (int)(((long)y * H) / pg.h), h1 = (int)((((long)y + 1) * H + pg.h - 1) / pg.h);
+            int w0 = (int)(((long)x * W) / pg.w), w1 = (int)((((long)x + 1) * W + pg.w - 1) / pg.w);
+            float sum = 0.f;
+            for (int yy = h0; yy < h1; yy++)
+                for (int xx = w0; xx < w1; xx++) sum = sum + ycc_at(img, hw, (long)yy * W + xx, c);
+            v = sum / (float)(h1 - h0) / (float)(w1 - w0);
+        }
+        out[i] = v;
+    }
+    *reinterpret_cast<f32x4*>(Xi + pg.xoff + (long)patch * 64 + a * 8 + b4) = out;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: SVD initialisation = fp64 Gram (MFMA f64) + cyclic Jacobi eigen-solve in LDS + top-R factors
+// one workgroup (4 waves) per matrix
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void rr_pair(int t, int i, int& p, int& q)
+{
+    int a, b;
+    if (i == 0) { a = 63; b = t % 63; }
+    else { a = (t + i) % 63; b = (t - i + 63) % 63; }
+    p = a < b ? a : b;
+    q = a < b ? b : a;
+}
+
+__global__ __launch_bounds__(256) void k_init(const float* __restrict__ X, const PlaneDesc* __restrict__ planes,
+                                              const int8_t* __restrict__ sign, float* __restrict__ Vf,
+                                              float* __restrict__ Wf, int max_sweeps)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* G = reinterpret_cast<double*>(smem);           // [64][64]
+    double* E = G + 64 * 64;                               // [64][64]
+    double* cs = E + 64 * 64;                              // [32][2]
+    int* pq = reinterpret_cast<int*>(cs + 64);             // [32][2]
+    int* order = pq + 64;                                  // [64]
+    int* flag = order + 64;                                // [2]
+
+    const PlaneDesc pd = planes[blockIdx.x];
+    const float* Xp = X + pd.x_off;
+    const int M = pd.M, R = pd.R;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+
+    // ---- Gram: wave w takes the 4-row steps s = w, w+4, ...; tile (t,t') holds G[4i+t][4j+t']
+    f64x4 acc[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) acc[i] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    const int nsteps = (M + 3) >> 2;
+    for (int s = wave; s < nsteps; s += 4) {
+        int row = 4 * s + lq;
+        f32x4 x = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (row < M) x = *reinterpret_cast<const f32x4*>(Xp + (long)row * 64 + 4 * li);
+        double xd[4] = {(double)x[0], (double)x[1], (double)x[2], (double)x[3]};
+        int n = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int u = t; u < 4; u++) {
+                acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(xd[t], xd[u], acc[n], 0, 0, 0);
+                n++;
+            }
+    }
+    // G = ((g0 + g1) + g2) + g3, in wave order.  f64 C/D layout: col = lane&15, row = (lane>>4) + 4*reg.
+    for (int w = 0; w < 4; w++) {
+        if (wave == w) {
+            int n = 0;
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int u = t; u < 4; u++) {
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) {
+                        int gi = 4 * (lq + 4 * reg) + t, gj = 4 * li + u;
+                        double v = acc[n][reg];
+                        if (w) v = G[gi * 64 + gj] + v;
+                        G[gi * 64 + gj] = v;
+                        if (t != u) G[gj * 64 + gi] = v;
+                    }
+                    n++;
+                }
+        }
+        __syncthreads();
+    }
+    // note: for t == u the tile covers both (gi,gj) and (gj,gi) already.
+
+    // ---- Jacobi
+    for (int i = tid; i < 64 * 64; i += 256) E[i] = ((i >> 6) == (i & 63)) ? 1.0 : 0.0;
+    if (tid == 0) flag[0] = 0;
+    __syncthreads();
+    for (int sweep = 0; sweep < max_sweeps; sweep++) {
+        for (int t = 0; t < 63; t++) {
+            if (tid < 32) {
+                int p, q;
+                rr_pair(t, tid, p, q);
+                pq[2 * tid] = p;
+                pq[2 * tid + 1] = q;
+                double apq = G[p * 64 + q], app = G[p * 64 + p], aqq = G[q * 64 + q];
+                double c = 1.0, s = 0.0;
+                if (apq * apq > 1.2325951644078309e-32 * fabs(app * aqq)) {
+                    double tau = (aqq - app) / (2.0 * apq);
+                    double tt = 1.0 / (fabs(tau) + sqrt(1.0 + tau * tau));
+                    if (tau < 0.0) tt = -tt;
+                    c = 1.0 / sqrt(1.0 + tt * tt);
+                    s = tt * c;
+                    flag[0] = 1;
+                }
+                cs[2 * tid] = c;
+                cs[2 * tid + 1] = s;
+            }
+            __syncthreads();
+            { // row phase: thread = (column k, group of 8 pairs)
+                int k = tid & 63, grp = tid >> 6;
+#pragma unroll
+                for (int ii = 0; ii < 8; ii++) {
+                    int i = grp * 8 + ii;
+                    double c = cs[2 * i], s = cs[2 * i + 1];
+                    if (s != 0.0) {
+                        int p = pq[2 * i], q = pq[2 * i + 1];
+                        double gp = G[p * 64 + k], gq = G[q * 64 + k];
+                        G[p * 64 + k] = c * gp - s * gq;
+                        G[q * 64 + k] = s * gp + c * gq;
+                    }
+                }
+            }
+            __syncthreads();
+            { // column phase on G and E: thread = (pair i, 8 rows)
+                int i = tid & 31;
+                double c = cs[2 * i], s = cs[2 * i + 1];
+                if (s != 0.0) {
+                    int p = pq[2 * i], q = pq[2 * i + 1];
+#pragma unroll
+                    for (int kk = 0; kk < 8; kk++) {
+                        int k = (tid >> 5) + 8 * kk;
+                        double gp = G[k * 64 + p], gq = G[k * 64 + q];
+                        double np_ = c * gp - s * gq, nq_ = s * gp + c * gq;
+                        if (k == p) nq_ = 0.0; // (p,q) annihilated
+                        if (k == q) np_ = 0.0; // (q,p)
+                        G[k * 64 + p] = np_;
+                        G[k * 64 + q] = nq_;
+                        double ep = E[k * 64 + p], eq = E[k * 64 + q];
+                        E[k * 64 + p] = c * ep - s * eq;
+                        E[k * 64 + q] = s * ep + c * eq;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        int rotated = flag[0];
+        __syncthreads();
+        if (tid == 0) flag[0] = 0;
+        __syncthreads();
+        if (!rotated) break;
+    }
+
+    // ---- order eigenvalues (descending, ties: lower index first), extract top-R columns
+    if (tid < 64) {
+        double lam = G[tid * 64 + tid];
+        int rank = 0;
+        for (int i = 0; i < 64; i++) {
+            double li_ = G[i * 64 + i];
+            rank += (li_ > lam || (li_ == lam && i < tid)) ? 1 : 0;
+        }
+        order[rank] = tid;
+    }
+    __syncthreads();
+    float* Vp = Vf + (long)blockIdx.x * 64 * LRF_RP;
+    float* Wp = Wf + (long)blockIdx.x * 64 * LRF_RP;
+    for (int i = tid; i < 64 * LRF_RP; i += 256) { // zero padding columns
+        if ((i & (LRF_RP - 1)) >= R) { Vp[i] = 0.f; Wp[i] = 0.f; }
+    }
+    if (tid < R) {
+        int r = tid;
+        int rmax = M < 64 ? M : 64;
+        if (r >= rmax) {
+            for (int j = 0; j < 64; j++) { Vp[j * LRF_RP + r] = 0.f; Wp[j * LRF_RP + r] = 0.f; }
+        } else {
+            int c = order[r];
+            double lam = G[c * 64 + c];
+            double sigma = sqrt(lam > 0.0 ? lam : 0.0);
+            double sr = sqrt(sigma);
+            double dot = 0.0;
+            for (int j = 0; j < 64; j++) dot = fma((double)(j + 1), E[j * 64 + c], dot);
+            int sg = (pd.sign_off >= 0 && sign) ? (int)sign[pd.sign_off + r] : 0;
+            double want = sg ? (double)sg : -1.0;
+            double flip = ((dot < 0.0 ? -1.0 : 1.0) == want) ? 1.0 : -1.0;
+            for (int j = 0; j < 64; j++) {
+                double e = flip * E[j * 64 + c];
+                Vp[j * LRF_RP + r] = (float)(e * sr);
+                Wp[j * LRF_RP + r] = (sr > 0.0) ? (float)(e / sr) : 0.f;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gauss-Seidel over the R columns of one row (qmf.py:108-119).  a[] = (x @ v) row, u[] = current
+// row of the factor being updated (in/out).  b_s: LDS [LRF_RP][LRF_RP] (b = v.mT @ v), den_s[r] =
+// (b[r][r] + 0) + eps.  `native` selects the ATen small-product order for the `uu @ bb` term.
+// ------------------------------------------------------------------------------------------------
+template <int R>
+__device__ __forceinline__ void gs_row(const float* a, float* u, const float* b_s, const float* den_s, bool native,
+                                       float lo, float hi)
+{
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        float uu[R > 1 ? R - 1 : 1], bb[R > 1 ? R - 1 : 1];
+        int n = 0;
+#pragma unroll
+        for (int j = 0; j < R; j++)
+            if (j != r) {
+                uu[n] = u[j];
+                bb[n] = b_s[j * LRF_RP + r];
+                n++;
+            }
+        constexpr int K = R - 1;
+        float term2 = 0.f;
+        if (K > 0) {
+            if (native) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    float p = uu[k] * bb[k];
+                    acc = acc + p;
+                }
+                term2 = acc;
+            } else if (K == 1) {
+                term2 = uu[0] * bb[0];
+            } else { // MKL single-column order (oracle/lrf_oracle.c dot_mkl_n1)
+                float odd = fmaf(uu[1], bb[1], uu[0] * bb[0]);
+                constexpr int last_odd = ((K - 1) & 1) ? K - 1 : K - 2;
+#pragma unroll
+                for (int k = last_odd; k >= 3; k -= 2) odd = odd + uu[k] * bb[k];
+                if (K < 3) term2 = odd;
+                else {
+                    float even = uu[2] * bb[2];
+#pragma unroll
+                    for (int k = 4; k < K; k += 2) even = even + uu[k] * bb[k];
+                    term2 = odd + even;
+                }
+            }
+        }
+        float num = a[r] - term2;
+        float val = (num + LRF_EPS) / den_s[r];
+        val = rintf(val);
+        val = fminf(fmaxf(val, lo), hi);
+        u[r] = val;
+    }
+}
+
+template <int R>
+__device__ __forceinline__ void gs_row_lds(const float* a_row, float* u_row, const float* b_s, const float* den_s,
+                                           bool native, float lo, float hi)
+{
+    float a[R], u[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) { a[r] = a_row[r]; u[r] = u_row[r]; }
+    gs_row<R>(a, u, b_s, den_s, native, lo, hi);
+#pragma unroll
+    for (int r = 0; r < R; r++) u_row[r] = u[r];
+}
+
+__device__ __forceinline__ void gs_dispatch(int R, const float* a_row, float* u_row, const float* b_s,
+                                            const float* den_s, bool native, float lo, float hi)
+{
+    switch (R) {
+#define LRF_CASE(r) case r: gs_row_lds<r>(a_row, u_row, b_s, den_s, native, lo, hi); break;
+        LRF_CASE(1) LRF_CASE(2) LRF_CASE(3) LRF_CASE(4) LRF_CASE(5) LRF_CASE(6) LRF_CASE(7) LRF_CASE(8)
+        LRF_CASE(9) LRF_CASE(10) LRF_CASE(11) LRF_CASE(12) LRF_CASE(13) LRF_CASE(14) LRF_CASE(15) LRF_CASE(16)
+#undef LRF_CASE
+    }
+}
+
+// b = v.mT @ v for the R x R block: thread (j, r).  ATen uses its native kernel when depth*R*R < 400.
+__device__ __forceinline__ void gram_small(const float* __restrict__ Vp /*[depth][LRF_RP]*/, int depth, int R,
+                                           float* b_s, float* den_s, int tid, int nthreads)
+{
+    bool native = (long)depth * R * R < 400;
+    for (int i = tid; i < R * R; i += nthreads) {
+        int j = i / R, r = i - j * R;
+        float acc = 0.f;
+        if (native) {
+            for (int k = 0; k < depth; k++) {
+                float p = Vp[k * LRF_RP + j] * Vp[k * LRF_RP + r];
+                acc = acc + p;
+            }
+        } else {
+            for (int k = 0; k < depth; k++) acc = fmaf(Vp[k * LRF_RP + j], Vp[k * LRF_RP + r], acc);
+        }
+        b_s[j * LRF_RP + r] = acc;
+        if (j == r) den_s[r] = (acc + 0.f) + LRF_EPS;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: one BCD half-iteration over X: U update (row local) fused with the partial a' = X^T U of the
+// following V update.  One workgroup (4 waves) per (matrix, 384-row block); sub-tiles of 64 rows
+// staged through LDS.  MODE 0: old U from int8 (iterations >= 2); MODE 1: first iteration, old U =
+// X @ W0 computed here; MODE 2: first iteration, old U = caller's fp32 U0.
+// ------------------------------------------------------------------------------------------------
+#define XS_LD 66 // LDS row stride (dwords) of the X sub-tile: conflict-free B-operand reads
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_bcd(const float* __restrict__ X, const PlaneDesc* __restrict__ planes,
+                                             const BlockDesc* __restrict__ blocks, const float* __restrict__ Vf,
+                                             const float* __restrict__ Wf, const float* __restrict__ U0,
+                                             int8_t* __restrict__ U, float* __restrict__ Ppart, float lo, float hi)
+{
+    __shared__ __attribute__((aligned(16))) float Xs[64 * XS_LD];
+    __shared__ __attribute__((aligned(16))) float a_s[64 * LRF_RP];
+    __shared__ __attribute__((aligned(16))) float u_s[64 * LRF_RP];
+    __shared__ __attribute__((aligned(16))) float b_s[LRF_RP * LRF_RP];
+    __shared__ float den_s[LRF_RP];
+
+    const BlockDesc bd = blocks[blockIdx.x];
+    const PlaneDesc pd = planes[bd.plane];
+    const int R = pd.R;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const float* Xp = X + pd.x_off + (long)bd.row0 * 64;
+    const float* Vp = Vf + (long)bd.plane * 64 * LRF_RP;
+    int nrows = pd.M - bd.row0;
+    if (nrows > LRF_KC) nrows = LRF_KC;
+    const int nsub = (nrows + 63) >> 6;
+
+    // A operand of a^T = V^T X^T : A[i = r][k]; lane holds V[4s + lq][li]
+    float aV[16], aW[16];
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+        aV[s] = Vp[(4 * s + lq) * LRF_RP + li];
+        if (MODE == 1) aW[s] = Wf[(long)bd.plane * 64 * LRF_RP + (4 * s + lq) * LRF_RP + li];
+    }
+    gram_small(Vp, 64, R, b_s, den_s, tid, 256);
+
+    f32x4 accP = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < nsub; t++) {
+        const int r0 = t * 64;
+        __syncthreads(); // previous sub-tile fully consumed (also orders b_s / den_s writes)
+        // ---- stage X[r0 .. r0+63][0..63] -> Xs (zero rows past the block)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int e = i * 256 + tid; // float4 index: row = e >> 4, c4 = e & 15
+            int row = e >> 4, c4 = e & 15;
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (r0 + row < nrows) v = *reinterpret_cast<const f32x4*>(Xp + (long)(r0 + row) * 64 + 4 * c4);
+            float2* d = reinterpret_cast<float2*>(&Xs[row * XS_LD + 4 * c4]);
+            d[0] = make_float2(v[0], v[1]);
+            d[1] = make_float2(v[2], v[3]);
+        }
+        __syncthreads();
+        // ---- a^T tile for rows 16*wave .. +15 : 16 chained MFMAs over k
+        {
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, accw = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const float* xr = &Xs[(16 * wave + li) * XS_LD + lq];
+#pragma unroll
+            for (int s = 0; s < 16; s++) {
+                float bx = xr[4 * s];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aV[s], bx, acc, 0, 0, 0);
+                if (MODE == 1) accw = __builtin_amdgcn_mfma_f32_16x16x4f32(aW[s], bx, accw, 0, 0, 0);
+            }
+            // D[i = 4*lq + reg (r)][j = li (row)]
+            *reinterpret_cast<f32x4*>(&a_s[(16 * wave + li) * LRF_RP + 4 * lq]) = acc;
+            if (MODE == 1) *reinterpret_cast<f32x4*>(&u_s[(16 * wave + li) * LRF_RP + 4 * lq]) = accw;
+        }
+        __syncthreads();
+        // ---- Gauss-Seidel: one wave, lane = row (rotating wave so the VALU work spreads over SIMDs)
+        if (wave == (t & 3)) {
+            int row = r0 + lane;
+            float* ur = &u_s[lane * LRF_RP];
+            if (row < nrows) {
+                long grow = (long)bd.row0 + row;
+                if (MODE == 0) {
+                    const int8_t* up = U + pd.u_off + grow * R;
+                    for (int r = 0; r < R; r++) ur[r] = (float)up[r];
+                } else if (MODE == 2) {
+                    const float* up = U0 + pd.u0_off + grow * R;
+                    for (int r = 0; r < R; r++) ur[r] = up[r];
+                }
+                gs_dispatch(R, &a_s[lane * LRF_RP], ur, b_s, den_s, pd.native_t2_u != 0, lo, hi);
+                int8_t* uo = U + pd.u_off + grow * R;
+                for (int r = 0; r < R; r++) uo[r] = (int8_t)ur[r];
+                for (int r = R; r < LRF_RP; r++) ur[r] = 0.f;
+            } else {
+                for (int r = 0; r < LRF_RP; r++) ur[r] = 0.f;
+            }
+        }
+        __syncthreads();
+        // ---- partial a' = X^T U for columns 16*wave .. +15: chain over the 64 rows of the sub-tile
+        {
+            const float* xc = &Xs[lq * XS_LD + 16 * wave + li];
+            const float* uc = &u_s[lq * LRF_RP + li];
+#pragma unroll
+            for (int s = 0; s < 16; s++)
+                accP = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[4 * s * XS_LD], uc[4 * s * LRF_RP], accP, 0, 0, 0);
+        }
+    }
+    // D[i = 4*lq + reg (column 16*wave + i)][j = li (r)]
+    float* Pp = Ppart + ((long)pd.blk0 + bd.blk) * 64 * LRF_RP;
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) Pp[(16 * wave + 4 * lq + reg) * LRF_RP + li] = accP[reg];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3b: V update for one matrix per workgroup: a' = sum of the block partials (in block order),
+// b' = U^T U (exact integers), Gauss-Seidel over the R columns for the 64 rows of V.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_vupdate(const PlaneDesc* __restrict__ planes, const int8_t* __restrict__ U,
+                                                 const float* __restrict__ Ppart, float* __restrict__ Vf,
+                                                 int8_t* __restrict__ V8, float lo, float hi, int write_i8)
+{
+    __shared__ int q_i[LRF_RP * LRF_RP];
+    __shared__ __attribute__((aligned(16))) float b_s[LRF_RP * LRF_RP];
+    __shared__ float den_s[LRF_RP];
+    __shared__ __attribute__((aligned(16))) float a_s[64 * LRF_RP];
+    __shared__ __attribute__((aligned(16))) float v_s[64 * LRF_RP];
+
+    const PlaneDesc pd = planes[blockIdx.x];
+    const int R = pd.R, M = pd.M, tid = threadIdx.x;
+    for (int i = tid; i < LRF_RP * LRF_RP; i += 256) q_i[i] = 0;
+    __syncthreads();
+    // b' = U^T U: exact in int32 (|u| <= 128, M < 2^17 checked on the host)
+    {
+        int qa[LRF_RP * (LRF_RP + 1) / 2];
+        const int npair = R * (R + 1) / 2;
+        for (int i = 0; i < npair; i++) qa[i] = 0;
+        const int8_t* Up = U + pd.u_off;
+        for (int m = tid; m < M; m += 256) {
+            int u[LRF_RP];
+            for (int r = 0; r < R; r++) u[r] = Up[(long)m * R + r];
+            int n = 0;
+            for (int j = 0; j < R; j++)
+                for (int r = j; r < R; r++) qa[n++] += u[j] * u[r];
+        }
+        int n = 0;
+        for (int j = 0; j < R; j++)
+            for (int r = j; r < R; r++) {
+                int v = qa[n++];
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+                if ((tid & 63) == 0) atomicAdd(&q_i[j * LRF_RP + r], v);
+            }
+    }
+    // a' = ((P0 + P1) + P2) + ...
+    for (int i = tid; i < 64 * LRF_RP; i += 256) {
+        const float* Pp = Ppart + (long)pd.blk0 * 64 * LRF_RP + i;
+        float acc = Pp[0];
+        for (int b = 1; b < pd.nblk; b++) acc = acc + Pp[(long)b * 64 * LRF_RP];
+        a_s[i] = acc;
+        v_s[i] = Vf[(long)blockIdx.x * 64 * LRF_RP + i];
+    }
+    __syncthreads();
+    for (int i = tid; i < R * R; i += 256) {
+        int j = i / R, r = i - j * R;
+        float q = (float)(j <= r ? q_i[j * LRF_RP + r] : q_i[r * LRF_RP + j]);
+        b_s[j * LRF_RP + r] = q;
+        if (j == r) den_s[r] = (q + 0.f) + LRF_EPS;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        bool native = (long)(R - 1) * 64 < 400;
+        gs_dispatch(R, &a_s[tid * LRF_RP], &v_s[tid * LRF_RP], b_s, den_s, native, lo, hi);
+        float* Vp = Vf + (long)blockIdx.x * 64 * LRF_RP + tid * LRF_RP;
+        for (int r = 0; r < R; r++) Vp[r] = v_s[tid * LRF_RP + r];
+        if (write_i8) {
+            int8_t* vo = V8 + pd.v_off + (long)tid * R;
+            for (int r = 0; r < R; r++) vo[r] = (int8_t)v_s[tid * LRF_RP + r];
+        }
+    }
+}
+
+// loads caller-supplied fp32 V0 [B][64][R] into the padded Vf table (lrf_qmf_bcd_f32)
+__global__ void k_load_v0(const PlaneDesc* __restrict__ planes, const float* __restrict__ V0, float* __restrict__ Vf)
+{
+    const PlaneDesc pd = planes[blockIdx.x];
+    for (int i = threadIdx.x; i < 64 * LRF_RP; i += blockDim.x) {
+        int j = i / LRF_RP, r = i - j * LRF_RP;
+        Vf[(long)blockIdx.x * 64 * LRF_RP + i] = (r < pd.R) ? V0[pd.v0_off + (long)j * pd.R + r] : 0.f;
+    }
+}
+
+// u0 = X @ W0 (fp32 out), v0 from Vf: lrf_qmf_svd_init_f32
+__global__ __launch_bounds__(256) void k_emit_init(const float* __restrict__ X, const PlaneDesc* __restrict__ planes,
+                                                   const BlockDesc* __restrict__ blocks, const float* __restrict__ Vf,
+                                                   const float* __restrict__ Wf, float* __restrict__ U0,
+                                                   float* __restrict__ V0)
+{
+    const BlockDesc bd = blocks[blockIdx.x];
+    const PlaneDesc pd = planes[bd.plane];
+    const int R = pd.R;
+    int nrows = pd.M - bd.row0;
+    if (nrows > LRF_KC) nrows = LRF_KC;
+    const float* Wp = Wf + (long)bd.plane * 64 * LRF_RP;
+    for (int i = threadIdx.x; i < nrows * R; i += 256) {
+        int m = i / R, r = i - m * R;
+        const float* x = X + pd.x_off + (long)(bd.row0 + m) * 64;
+        float acc = 0.f;
+        for (int k = 0; k < 64; k++) acc = fmaf(x[k], Wp[k * LRF_RP + r], acc);
+        U0[pd.u0_off + (long)(bd.row0 + m) * R + r] = acc;
+    }
+    if (bd.blk == 0)
+        for (int i = threadIdx.x; i < 64 * R; i += 256) {
+            int j = i / R, r = i - j * R;
+            V0[pd.v0_off + i] = Vf[(long)bd.plane * 64 * LRF_RP + j * LRF_RP + r];
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: int8 factors -> uint8 RGB.  One thread per 4 horizontally adjacent pixels.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float recon_at(const int8_t* __restrict__ Uc, const int8_t* __restrict__ Vc, int R,
+                                          const PlaneGeom& pg, int y, int x)
+{
+    // depatchify(unpad): padded coordinates, patch index, element index
+    int yy = y + pg.top_crop, xx = x + pg.left_crop;
+    int m = (yy >> 3) * pg.nw + (xx >> 3), n = (yy & 7) * 8 + (xx & 7);
+    float acc = 0.f; // u @ v.mT : k-ordered fma chain (exact: small integers)
+    for (int r = 0; r < R; r++) acc = fmaf((float)Uc[(long)m * R + r], (float)Vc[n * R + r], acc);
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void k_decode(const int8_t* __restrict__ U, const int8_t* __restrict__ V, int H, int W,
+                                                ImageGeom g, int R0, int R1, int R2, long u_img, long v_img,
+                                                uint8_t* __restrict__ rgb)
+{
+    int w4 = (W + 3) >> 2;
+    long o = (long)blockIdx.x * 256 + threadIdx.x;
+    if (o >= (long)H * w4) return;
+    int y = (int)(o / w4), x0 = (int)(o - (long)y * w4) * 4;
+    const int8_t* Ui = U + (long)blockIdx.y * u_img;
+    const int8_t* Vi = V + (long)blockIdx.y * v_img;
+    const int8_t* Uc[3] = {Ui, Ui + (long)g.p[0].M * R0, Ui + (long)g.p[0].M * R0 + (long)g.p[1].M * R1};
+    const int8_t* Vc[3] = {Vi, Vi + 64 * R0, Vi + 64 * R0 + 64 * R1};
+    const int Rc[3] = {R0, R1, R2};
+    uint8_t* out = rgb + (long)blockIdx.y * 3 * H * W;
+    const float T[3][3] = {{1.0f, 0.0f, 1.402f}, {1.0f, -0.344136f, -0.714136f}, {1.0f, 1.772f, 0.0f}};
+    // nearest up-sampling source rows/cols (ATen: floor(dst * (in/out)) in fp32, clamped)
+    float sh = (float)g.p[1].h / (float)H, sw = (float)g.p[1].w / (float)W;
+    int sy = (int)floorf((float)y * sh);
+    if (sy > g.p[1].h - 1) sy = g.p[1].h - 1;
+    for (int i = 0; i < 4; i++) {
+        int x = x0 + i;
+        if (x >= W) break;
+        int sx = (int)floorf((float)x * sw);
+        if (sx > g.p[1].w - 1) sx = g.p[1].w - 1;
+        float c[3];
+        c[0] = recon_at(Uc[0], Vc[0], Rc[0], g.p[0], y, x) + 0.f;
+        c[1] = recon_at(Uc[1], Vc[1], Rc[1], g.p[1], sy, sx) + -128.f;
+        c[2] = recon_at(Uc[2], Vc[2], Rc[2], g.p[2], sy, sx) + -128.f;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            float acc = 0.f;
+            acc = fmaf(T[ch][0], c[0], acc);
+            acc = fmaf(T[ch][1], c[1], acc);
+            acc = fmaf(T[ch][2], c[2], acc);
+            acc = fminf(fmaxf(acc, 0.f), 255.f);
+            out[(long)ch * H * W + (long)y * W + x] = (uint8_t)acc; // truncation (to_dtype)
+        }
+    }
+}
