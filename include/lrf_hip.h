@@ -50,8 +50,11 @@ int lrf_version(void);
 
 int lrf_ctx_create(int device, lrf_ctx** out);
 void lrf_ctx_destroy(lrf_ctx* ctx);
-/* hip_stream: a hipStream_t (NULL = the context's own stream, created at lrf_ctx_create). */
+/* A new context enqueues on a non-blocking stream of its own.  lrf_ctx_set_stream switches to the
+ * caller's hipStream_t, taken as is (NULL = HIP's default stream, which is what a torch process uses
+ * unless it changed streams); lrf_ctx_use_own_stream switches back.  Both first wait for the stream in use. */
 int lrf_ctx_set_stream(lrf_ctx* ctx, void* hip_stream);
+int lrf_ctx_use_own_stream(lrf_ctx* ctx);
 int lrf_ctx_synchronize(lrf_ctx* ctx);
 /* bytes of scratch the context currently holds */
 size_t lrf_ctx_workspace_bytes(const lrf_ctx* ctx);

@@ -41,6 +41,7 @@ def load():
         lib.lrf_ctx_destroy.argtypes = [c_void_p]
         lib.lrf_ctx_destroy.restype = None
         lib.lrf_ctx_set_stream.argtypes = [c_void_p, c_void_p]
+        lib.lrf_ctx_use_own_stream.argtypes = [c_void_p]
         lib.lrf_ctx_synchronize.argtypes = [c_void_p]
         lib.lrf_ctx_profile.argtypes = [c_void_p, c_int]
         lib.lrf_ctx_profile_reset.argtypes = [c_void_p]
@@ -64,7 +65,7 @@ def load():
         return lib
 
 
-EXPORTS = ["lrf_last_error", "lrf_device_count", "lrf_version", "lrf_ctx_create", "lrf_ctx_destroy", "lrf_ctx_set_stream",
+EXPORTS = ["lrf_last_error", "lrf_device_count", "lrf_version", "lrf_ctx_create", "lrf_ctx_destroy", "lrf_ctx_set_stream", "lrf_ctx_use_own_stream",
            "lrf_ctx_synchronize", "lrf_ctx_workspace_bytes", "lrf_ctx_profile", "lrf_ctx_kernel_time",
            "lrf_ctx_profile_reset", "lrf_malloc", "lrf_free", "lrf_memcpy_h2d", "lrf_memcpy_d2h", "lrf_plane_dims",
            "lrf_qmf_planes_from_rgb_u8", "lrf_qmf_decompose_f32", "lrf_qmf_bcd_f32", "lrf_qmf_svd_init_f32",
@@ -156,6 +157,7 @@ class Context:
 
     def decompose(self, X, R, K, lo, hi, sign=None):
         import torch
+        X = X.contiguous()
         B, M, N = X.shape
         U = torch.empty((B, M, R), dtype=torch.int8, device=X.device)
         V = torch.empty((B, N, R), dtype=torch.int8, device=X.device)
@@ -165,6 +167,7 @@ class Context:
 
     def bcd(self, X, U0, V0, K, lo, hi):
         import torch
+        X, U0, V0 = X.contiguous(), U0.float().contiguous(), V0.float().contiguous()
         B, M, N = X.shape
         R = U0.shape[-1]
         U = torch.empty((B, M, R), dtype=torch.int8, device=X.device)
@@ -175,6 +178,7 @@ class Context:
 
     def svd_init(self, X, R, sign=None):
         import torch
+        X = X.contiguous()
         B, M, N = X.shape
         U0 = torch.empty((B, M, R), dtype=torch.float32, device=X.device)
         V0 = torch.empty((B, N, R), dtype=torch.float32, device=X.device)
@@ -202,6 +206,7 @@ class Context:
 
     def decode_rgb(self, U, V, H, W, ranks):
         import torch
+        U, V = U.contiguous(), V.contiguous()
         B = U.shape[0]
         rgb = torch.empty((B, 3, H, W), dtype=torch.uint8, device=U.device)
         R = (c_int * 3)(*[int(r) for r in ranks])

@@ -315,10 +315,19 @@ void lrf_ctx_destroy(lrf_ctx* c)
 int lrf_ctx_set_stream(lrf_ctx* c, void* hip_stream)
 {
     if (!c) return set_err(LRF_EINVAL, "ctx is NULL");
-    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    hipStream_t s = (hipStream_t)hip_stream; // NULL is HIP's default stream, a valid handle
     if (s == c->stream) return LRF_OK;
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->stream = s;
+    return LRF_OK;
+}
+
+int lrf_ctx_use_own_stream(lrf_ctx* c)
+{
+    if (!c) return set_err(LRF_EINVAL, "ctx is NULL");
+    if (c->stream == c->own_stream) return LRF_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->stream = c->own_stream;
     return LRF_OK;
 }
 

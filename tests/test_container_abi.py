@@ -1,0 +1,88 @@
+"""CPU suite: byte container against the reference's streams; the C-ABI library loads and exports its header."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import QMF_CASES, ROOT, Case
+
+
+@pytest.mark.parametrize("name", QMF_CASES + ["tiny_it0"])
+def test_repack_is_byte_identical(name):
+    from lrf_amd.codec import pack_image, parse_stream
+    case = Case(name)
+    meta, fac = parse_stream(case.encoded)
+    H, W = case.image.shape[-2:]
+    again = pack_image(fac, (H, W), meta["rank"], meta["bounds"], meta["patch size"], meta["dtype"])
+    assert again == case.encoded
+
+
+def test_combine_separate_errors():
+    from lrf_amd import combine_bytes, separate_bytes
+    parts = [b"a", b"", b"xyz" * 5, b"\x00\x01"]
+    assert list(separate_bytes(combine_bytes(parts), 4)) == parts
+    with pytest.raises(TypeError):
+        combine_bytes([b"a", "b"])
+    with pytest.raises(ValueError):
+        separate_bytes(b"\x00", 2)
+
+
+def test_rank_rule():
+    import lrf_amd
+    assert lrf_amd.qmf_ranks((512, 768), quality=7) == [4, 2, 2]
+    assert lrf_amd.qmf_ranks((512, 768), rank=7) == [7, 3, 3]
+    assert lrf_amd.qmf_ranks((64, 96), quality=7) == [4, 1, 1]
+    assert lrf_amd.qmf_ranks((64, 96), rank=1) == [1, 1, 1]
+    with pytest.raises(AssertionError):
+        lrf_amd.qmf_ranks((64, 96), quality=101)
+
+
+def test_library_exports_every_declared_symbol():
+    import ctypes
+
+    from lrf_amd import _lib
+    header = open(os.path.join(ROOT, "include", "lrf_hip.h")).read()
+    declared = set(re.findall(r"\b(lrf_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    lib = ctypes.CDLL(_lib.LIB_PATH)  # loads without a GPU
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.lrf_version() == 1
+
+
+def test_plane_dims_match_reference_metadata():
+    from lrf_amd import _lib
+    from lrf_amd.codec import parse_stream
+    for name in ("odd_q7", "nat_q7", "s2odd_q7", "s1_q7"):
+        case = Case(name)
+        meta, _ = parse_stream(case.encoded)
+        H, W = case.image.shape[-2:]
+        dims = _lib.plane_dims(H, W)
+        assert [list(d[:2]) for d in dims] == meta["original size"]
+        assert [list(d[2:4]) for d in dims] == meta["padded size"]
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+
+    import lrf_amd
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError):
+        lrf_amd.qmf_encode(torch.zeros(3, 16, 16, dtype=torch.uint8), quality=7)
+
+
+def test_unsupported_branches_raise():
+    import torch
+
+    import lrf_amd
+    img = torch.zeros(3, 16, 16, dtype=torch.uint8)
+    with pytest.raises(AssertionError):
+        lrf_amd.qmf_encode(img)
+    with pytest.raises(AssertionError):
+        lrf_amd.qmf_encode(img, quality=7, color_space="HSV")
+    with pytest.raises(NotImplementedError):
+        lrf_amd.qmf_encode(img, quality=7, color_space="RGB")
+    with pytest.raises(NotImplementedError):
+        lrf_amd.qmf_encode(img, quality=7, patch=False)

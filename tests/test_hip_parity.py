@@ -1,0 +1,208 @@
+"""GPU suite (-m gpu): the HIP path, through the C ABI, against the oracle and the reference's golden vectors.
+Everything integer (factors, bytes, decoded pixels) is compared bit for bit."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import QMF_CASES, Case
+from test_oracle_golden import EXACT_CASES
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from lrf_amd import _lib
+    return _lib.context(0)
+
+
+def _planes(ctx, img):
+    from lrf_amd import _lib
+    H, W = img.shape[-2:]
+    X = ctx.planes_from_rgb(img.cuda().unsqueeze(0))[0].cpu().numpy()
+    out, off = [], 0
+    for d in _lib.plane_dims(H, W):
+        out.append(X[off:off + d[4] * 64].reshape(d[4], 64))
+        off += d[4] * 64
+    return out
+
+
+@pytest.mark.parametrize("name", ["tiny_q7", "odd_q7", "s2odd_q7", "nat_q7", "s1_q7", "const_q7"])
+def test_planes_bit_exact(name, ctx, oracle):
+    case = Case(name)
+    got = _planes(ctx, case.image)
+    want = oracle.rgb_to_planes(case.image.numpy())
+    for c in range(3):
+        assert np.array_equal(got[c].view(np.int32), want[c].view(np.int32)), f"plane {c}"
+
+
+@pytest.mark.parametrize("name", EXACT_CASES)
+def test_encode_reproduces_reference_bytes(name):
+    """With the reference's LAPACK column signs the whole encoder emits the reference's byte stream."""
+    import lrf_amd
+    case = Case(name)
+    sign = np.concatenate(case.signs())
+    enc = lrf_amd.qmf_encode(case.image, init_sign=sign, **case.kwargs)
+    assert enc == case.encoded
+    dec = lrf_amd.qmf_decode(enc)
+    assert hashlib.sha256(dec.numpy().tobytes()).hexdigest() == case.decoded_sha256
+    assert abs(lrf_amd.psnr(case.image, dec).item() - case.psnr) < 1e-3
+    assert abs(lrf_amd.bits_per_pixel(case.image.shape[-2:], enc) - case.bpp) < 1e-12
+
+
+@pytest.mark.parametrize("name", QMF_CASES)
+def test_encode_equals_oracle_default_sign(name, oracle):
+    """Default sign rule, every case (also the ones outside the pinned region): HIP == oracle, bit for bit."""
+    import lrf_amd
+    from lrf_amd.codec import split_factors
+    case = Case(name)
+    H, W = case.image.shape[-2:]
+    K = case.kwargs.get("num_iters", 10)
+    U, V = lrf_amd.qmf_factorize_batch(case.image.cuda().unsqueeze(0), case.ranks, num_iters=K)
+    got = split_factors(U[0].cpu().numpy(), V[0].cpu().numpy(), (H, W), case.ranks)
+    X = oracle.rgb_to_planes(case.image.numpy())
+    for c in range(3):
+        u, v = oracle.qmf_decompose(X[c], case.ranks[c], K, (-16, 15))
+        assert np.array_equal(got[2 * c], u.astype(np.int8)), f"U plane {c}"
+        assert np.array_equal(got[2 * c + 1], v.astype(np.int8)), f"V plane {c}"
+
+
+@pytest.mark.parametrize("name", QMF_CASES + ["tiny_it0"])
+def test_decode_reference_stream(name):
+    """L0: the reference's bytes decode to the reference's pixels."""
+    import lrf_amd
+    case = Case(name)
+    dec = lrf_amd.qmf_decode(case.encoded)
+    assert dec.dtype == torch.uint8 and tuple(dec.shape) == tuple(case.image.shape)
+    assert hashlib.sha256(dec.numpy().tobytes()).hexdigest() == case.decoded_sha256
+
+
+@pytest.mark.parametrize("name", ["tiny_q7", "tiny_r7", "tiny_rank2", "tiny_it1", "tiny_it2", "odd_q7", "odd_r7"])
+def test_bcd_from_reference_init(name, ctx, oracle):
+    """L1: lrf_qmf_bcd_f32 from the reference's (u0, v0) gives the reference's factors."""
+    case = Case(name)
+    X = oracle.rgb_to_planes(case.image.numpy())
+    f = case.ref_factors()
+    K = case.kwargs.get("num_iters", 10)
+    for c in range(3):
+        xd = torch.from_numpy(X[c]).cuda().unsqueeze(0)
+        U, V = ctx.bcd(xd, torch.from_numpy(case.z[f"u0_{c}"]).cuda().unsqueeze(0),
+                       torch.from_numpy(case.z[f"v0_{c}"]).cuda().unsqueeze(0), K, -16, 15)
+        assert np.array_equal(U[0].cpu().numpy(), f[2 * c])
+        assert np.array_equal(V[0].cpu().numpy(), f[2 * c + 1])
+
+
+def test_svd_init_matches_oracle(ctx, oracle):
+    case = Case("odd_r7")
+    X = oracle.rgb_to_planes(case.image.numpy())
+    for c in range(3):
+        u0, v0 = ctx.svd_init(torch.from_numpy(X[c]).cuda().unsqueeze(0), case.ranks[c])
+        ou, ov = oracle.svd_init(X[c], case.ranks[c])
+        assert np.array_equal(v0[0].cpu().numpy().view(np.int32), ov.view(np.int32))
+        assert np.array_equal(u0[0].cpu().numpy().view(np.int32), ou.view(np.int32))
+        # against LAPACK (fixture): equal up to column sign within fp32 tolerance
+        rv = case.z[f"v0_{c}"]
+        s = np.sign((rv * ov).sum(0))
+        assert np.abs(ov * s - rv).max() <= 2e-4 * np.abs(rv).max()
+
+
+def test_qmf_class_api(oracle):
+    """QMF(...).decompose keeps the reference's interface: (u, v, w) fp32 on the input's device."""
+    import lrf_amd
+    case = Case("tiny_r7")
+    X = oracle.rgb_to_planes(case.image.numpy())
+    x = torch.from_numpy(X[0]).unsqueeze(0)
+    qmf = lrf_amd.QMF(rank=7, bounds=(-16, 15), factor=(0, 1), num_iters=10)
+    u, v, w = qmf.decompose(x)
+    assert u.dtype == torch.float32 and tuple(u.shape) == (1, 96, 7) and tuple(v.shape) == (1, 64, 7)
+    assert tuple(w.shape) == (1, 2, 1) and w.flatten().tolist() == [0.0, 1.0] and not u.is_cuda
+    uo, vo = oracle.qmf_decompose(X[0], 7, 10, (-16, 15))
+    assert np.array_equal(u[0].numpy(), uo) and np.array_equal(v[0].numpy(), vo)
+    rec = lrf_amd.QMF.reconstruct(u, v)
+    assert torch.allclose(qmf.forward(x), rec)
+    with pytest.raises(NotImplementedError):
+        lrf_amd.QMF(rank=3)  # unbounded
+    with pytest.raises(NotImplementedError):
+        lrf_amd.QMF(rank=3, bounds=(-16, 15), factor=(0, 1, 2))
+
+
+def test_c_abi_argument_errors(ctx):
+    x = torch.zeros(1, 10, 64, device="cuda")
+    with pytest.raises(NotImplementedError):
+        ctx.decompose(torch.zeros(1, 10, 32, device="cuda"), 2, 10, -16, 15)  # N != 64
+    with pytest.raises(NotImplementedError):
+        ctx.decompose(x, 17, 10, -16, 15)
+    with pytest.raises(ValueError):
+        ctx.decompose(x, 0, 10, -16, 15)
+    with pytest.raises(ValueError):
+        ctx.decompose(x, 2, 10, -200, 15)
+    with pytest.raises(ValueError):
+        ctx.encode_rgb(torch.zeros(1, 3, 1, 1, dtype=torch.uint8, device="cuda"), [1, 1, 1], 10, -16, 15)
+
+
+@pytest.mark.parametrize("hw", [(8, 8), (16, 24), (17, 31), (40, 100), (9, 200)])
+def test_small_and_ragged_sizes(hw, oracle):
+    import lrf_amd
+    from lrf_amd.codec import split_factors
+    H, W = hw
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    img = torch.randint(0, 256, (3, H, W), dtype=torch.uint8, generator=g)
+    ranks = lrf_amd.qmf_ranks((H, W), rank=3)
+    U, V = lrf_amd.qmf_factorize_batch(img.cuda().unsqueeze(0), ranks)
+    got = split_factors(U[0].cpu().numpy(), V[0].cpu().numpy(), (H, W), ranks)
+    X = oracle.rgb_to_planes(img.numpy())
+    for c in range(3):
+        u, v = oracle.qmf_decompose(X[c], ranks[c], 10, (-16, 15))
+        assert np.array_equal(got[2 * c], u.astype(np.int8)) and np.array_equal(got[2 * c + 1], v.astype(np.int8))
+    dec = lrf_amd.qmf_decode(lrf_amd.qmf_encode(img, rank=3))
+    assert np.array_equal(dec.numpy(), oracle.planes_to_rgb(got[0::2], got[1::2], H, W))
+
+
+def test_full_size_batch_properties(oracle):
+    """BASELINE config 2 at full size (256 x 512x768x3, ranks (7,3,3), K=10): size-independent properties plus
+    a spot check of single images against the oracle."""
+    import lrf_amd
+    from lrf_amd.codec import split_factors
+    B, H, W = 256, 512, 768
+    g = torch.Generator(device="cuda").manual_seed(0)
+    imgs = torch.randint(0, 256, (B, 3, H, W), dtype=torch.uint8, device="cuda", generator=g)
+    imgs[7] = imgs[3]                      # duplicate inputs must give duplicate outputs
+    ranks = [7, 3, 3]
+    U, V = lrf_amd.qmf_factorize_batch(imgs, ranks)
+    U2, V2 = lrf_amd.qmf_factorize_batch(imgs, ranks)
+    assert torch.equal(U, U2) and torch.equal(V, V2), "not deterministic"
+    assert torch.equal(U[7], U[3]) and torch.equal(V[7], V[3])
+    assert int(U.min()) >= -16 and int(U.max()) <= 15 and int(V.min()) >= -16 and int(V.max()) <= 15
+    # batch independence: image b alone == image b inside the batch
+    for b in (0, 200):
+        Ub, Vb = lrf_amd.qmf_factorize_batch(imgs[b:b + 1].clone(), ranks)
+        assert torch.equal(Ub[0], U[b]) and torch.equal(Vb[0], V[b])
+    # oracle spot check
+    b = 255
+    got = split_factors(U[b].cpu().numpy(), V[b].cpu().numpy(), (H, W), ranks)
+    X = oracle.rgb_to_planes(imgs[b].cpu().numpy())
+    for c in range(3):
+        u, v = oracle.qmf_decompose(X[c], ranks[c], 10, (-16, 15))
+        assert np.array_equal(got[2 * c], u.astype(np.int8)) and np.array_equal(got[2 * c + 1], v.astype(np.int8))
+    # encode -> decode round trip on the whole batch: PSNR of every image close to the reference's figure for
+    # i.i.d. uniform noise at these ranks (10.88 dB for the seed-0 image, fixture s1_r7)
+    ctx = lrf_amd._lib.context(0)
+    dec = ctx.decode_rgb(U, V, H, W, ranks)
+    mse = ((imgs.float() - dec.float()) ** 2).mean(dim=(1, 2, 3))
+    psnr = 20 * torch.log10(255 / torch.sqrt(mse))
+    assert float(psnr.min()) > 10.7 and float(psnr.max()) < 11.1
+
+
+def test_batched_streams_roundtrip():
+    import lrf_amd
+    g = torch.Generator().manual_seed(5)
+    imgs = torch.randint(0, 256, (3, 3, 48, 80), dtype=torch.uint8, generator=g)
+    streams = lrf_amd.qmf_encode_batch(imgs, quality=7)
+    assert len(streams) == 3
+    for b in range(3):
+        assert streams[b] == lrf_amd.qmf_encode(imgs[b], quality=7)
+    dec = lrf_amd.qmf_decode_batch(streams).cpu()
+    for b in range(3):
+        assert torch.equal(dec[b], lrf_amd.qmf_decode(streams[b]))

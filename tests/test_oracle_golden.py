@@ -1,0 +1,105 @@
+"""CPU suite: the oracle (oracle/lrf_oracle.c) against the golden vectors captured from the reference."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import QMF_CASES, Case
+
+# cases whose every product lies in the pinned region (R <= 7, see lrf_oracle.c header) and whose planes have
+# full column rank, so that even the *initialisation* is determined up to sign
+EXACT_CASES = ["tiny_q7", "tiny_r7", "tiny_it1", "tiny_it2", "odd_q7", "odd_r7", "smooth_q7", "smooth_r7", "s1_q7",
+               "s1_r7", "nat_q7", "nat_r7", "s2odd_q7", "tiny_rank2"]
+
+
+@pytest.mark.parametrize("name", QMF_CASES)
+def test_planes_and_decode_match_reference(name, oracle):
+    """L0: decoding the reference's factors reproduces the reference's decoded image bit for bit."""
+    case = Case(name)
+    H, W = case.image.shape[-2:]
+    f = case.ref_factors()
+    dec = oracle.planes_to_rgb(f[0::2], f[1::2], H, W)
+    assert hashlib.sha256(dec.tobytes()).hexdigest() == case.decoded_sha256
+    mse = np.mean((case.image.numpy().astype(np.float32) - dec.astype(np.float32)) ** 2)
+    assert abs(20 * np.log10(255 / np.sqrt(mse)) - case.psnr) < 1e-3
+
+
+@pytest.mark.parametrize("name", ["tiny_q7", "tiny_r7", "tiny_rank2", "tiny_it1", "tiny_it2", "odd_q7", "odd_r7"])
+def test_bcd_from_reference_init_is_bit_exact(name, oracle):
+    """L1: from the reference's own (u0, v0) the BCD iterations give the reference's int8 factors exactly."""
+    case = Case(name)
+    X = oracle.rgb_to_planes(case.image.numpy())
+    f = case.ref_factors()
+    K = case.kwargs.get("num_iters", 10)
+    for c in range(3):
+        u, v = oracle.bcd(X[c], case.z[f"u0_{c}"], case.z[f"v0_{c}"], K)
+        assert np.array_equal(u.astype(np.int8), f[2 * c]), f"U plane {c}"
+        assert np.array_equal(v.astype(np.int8), f[2 * c + 1]), f"V plane {c}"
+
+
+@pytest.mark.parametrize("name", EXACT_CASES)
+def test_full_encode_with_reference_signs_is_bit_exact(name, oracle):
+    """L3: own initialisation (fp64 Gram + Jacobi) with the reference's LAPACK column signs -> identical factors."""
+    case = Case(name)
+    X = oracle.rgb_to_planes(case.image.numpy())
+    f = case.ref_factors()
+    K = case.kwargs.get("num_iters", 10)
+    bad = 0
+    for c in range(3):
+        u, v = oracle.qmf_decompose(X[c], case.ranks[c], K, (-16, 15), sign=case.z[f"sign{c}"])
+        bad += int((u.astype(np.int8) != f[2 * c]).sum()) + int((v.astype(np.int8) != f[2 * c + 1]).sum())
+    assert bad == 0, f"{bad} factor entries differ from the reference"
+
+
+@pytest.mark.parametrize("name", ["tiny_q20", "tiny_rank1", "zero_q7", "const_q7"])
+def test_unpinned_cases_psnr(name, oracle):
+    """R > 7 (MKL order not pinned), R == 1 (gemv order not pinned) and rank-deficient planes (LAPACK's null-space
+    vectors are arbitrary): factors may differ from the reference; the decoded quality must not."""
+    case = Case(name)
+    H, W = case.image.shape[-2:]
+    X = oracle.rgb_to_planes(case.image.numpy())
+    U, V = [], []
+    for c in range(3):
+        u, v = oracle.qmf_decompose(X[c], case.ranks[c], case.kwargs.get("num_iters", 10), (-16, 15), sign=case.z[f"sign{c}"])
+        U.append(u.astype(np.int8))
+        V.append(v.astype(np.int8))
+    dec = oracle.planes_to_rgb(U, V, H, W)
+    mse = np.mean((case.image.numpy().astype(np.float32) - dec.astype(np.float32)) ** 2)
+    psnr = 20 * np.log10(255 / np.sqrt(mse)) if mse > 0 else 99.0
+    tol = 0.25 if name in ("zero_q7", "const_q7") else 0.05
+    assert psnr > case.psnr - tol, f"PSNR {psnr:.3f} vs reference {case.psnr:.3f}"
+
+
+def test_default_sign_changes_nothing_but_sign_for_quality(oracle):
+    """L2: without the reference's signs the factors differ only through the joint column sign; PSNR stays put."""
+    case = Case("smooth_r7")
+    H, W = case.image.shape[-2:]
+    X = oracle.rgb_to_planes(case.image.numpy())
+    U, V = [], []
+    for c in range(3):
+        u, v = oracle.qmf_decompose(X[c], case.ranks[c], 10, (-16, 15))
+        U.append(u.astype(np.int8))
+        V.append(v.astype(np.int8))
+    dec = oracle.planes_to_rgb(U, V, H, W)
+    mse = np.mean((case.image.numpy().astype(np.float32) - dec.astype(np.float32)) ** 2)
+    assert abs(20 * np.log10(255 / np.sqrt(mse)) - case.psnr) < 0.05
+
+
+def test_jacobi_eigen(oracle):
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((500, 64))
+    G = A.T @ A
+    lam, E, sweeps = oracle.jacobi_f64(G)
+    assert sweeps < 15
+    assert np.allclose(E @ np.diag(lam) @ E.T, G, rtol=0, atol=1e-9 * np.abs(G).max())
+    assert np.allclose(E.T @ E, np.eye(64), atol=1e-13)
+    assert np.allclose(np.sort(lam), np.linalg.eigvalsh(G), rtol=1e-12, atol=1e-9)
+
+
+def test_quantize_roundtrip(oracle):
+    rng = np.random.default_rng(1)
+    t = rng.standard_normal((100, 5)).astype(np.float32) * 10
+    q, sc, mn = oracle.quantize_u8(t)
+    back = oracle.dequantize_u8(q, sc, mn)
+    assert q.min() == 0 and q.max() == 255
+    assert np.abs(back - t).max() <= sc * 1.001
