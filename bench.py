@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""bench.py — Mpixels/s of the QMF encoder hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch already resident in HBM: 256 synthetic 512x768x3
+uint8 images -> patch matrices -> SVD initialisation -> 10 BCD iterations -> int8 factors (U, V) in HBM
+(BASELINE.json configs[1]; ranks (7,3,3) = `rank=7`).  The zlib/JSON container is host work and is not
+in the timed region.  With N > 1 every rank encodes its own 256 images (weak scaling, no data-path
+collective); RCCL carries only the barrier, the max-reduction of the time and the final stats gather.
+
+  python bench.py --gpus 1 --steps 5 --warmup 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+H, W, RANKS, NUM_ITERS, BOUNDS = 512, 768, (7, 3, 3), 10, (-16, 15)
+
+
+def cpu_baseline(images_u8, budget_s=12.0):
+    """The oracle (CPU port of the reference arithmetic, one thread) on a bounded sample of the same batch."""
+    import numpy as np
+
+    from oracle import oracle
+    oracle.build()
+    n, t_used, t0 = 0, 0.0, time.perf_counter()
+    for b in range(images_u8.shape[0]):
+        img = images_u8[b]
+        X = oracle.rgb_to_planes(img)
+        for c in range(3):
+            oracle.qmf_decompose(X[c], RANKS[c], NUM_ITERS, BOUNDS)
+        n += 1
+        t_used = time.perf_counter() - t0
+        if t_used > budget_s and n >= 8:
+            break
+    return {"value": round(n * H * W / t_used / 1e6, 4), "unit": "Mpix/s", "cores": 1, "kind": "port",
+            "sample": f"first {n} images of the batch (512x768x3, ranks {list(RANKS)}, {NUM_ITERS} iters), "
+                      f"oracle/lrf_oracle.c single thread, {t_used:.1f} s",
+            "cpu": _cpu_model(), "host_cores": os.cpu_count()}
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU per step (BASELINE config: 256)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import lrf_amd
+    from lrf_amd import _lib
+
+    B = args.batch
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    images = torch.randint(0, 256, (B, 3, H, W), dtype=torch.uint8, device=dev, generator=g)
+    dims = _lib.plane_dims(H, W)
+    U = torch.empty((B, sum(d[4] * r for d, r in zip(dims, RANKS))), dtype=torch.int8, device=dev)
+    V = torch.empty((B, 64 * sum(RANKS)), dtype=torch.int8, device=dev)
+    ctx = _lib.context(local_rank)
+
+    def step():
+        lrf_amd.qmf_factorize_batch(images, RANKS, NUM_ITERS, BOUNDS, out=(U, V))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.profile(True)
+    ctx.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    ctx.profile(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        stats = torch.tensor([float(B * H * W * args.steps), dt], dtype=torch.float64, device=dev)
+        gathered = [torch.zeros_like(stats) for _ in range(world)]
+        dist.all_gather(gathered, stats)  # final metrics gather (the only payload collective)
+        total_px = sum(float(s[0]) for s in gathered)
+    else:
+        total_px = float(B * H * W * args.steps)
+
+    if rank == 0:
+        value = total_px / dt / 1e6
+        kern = {}
+        for kid, name in _lib.KERNEL_NAMES.items():
+            ms, n = ctx.kernel_time(kid)
+            if n:
+                kern[name] = {"launches_per_step": n / args.steps, "avg_ms": ms / n, "ms_per_step": ms / args.steps}
+        # dominant kernel: one BCD pass (k_bcd).  Algorithmic bytes per launch (DESIGN.md "Roofline"):
+        # X read once (4 B per patch element) + int8 U written once.
+        alg_bytes = B * (sum(d[4] for d in dims) * 64 * 4 + sum(d[4] * r for d, r in zip(dims, RANKS)))
+        bcd_ms = kern["k_bcd"]["avg_ms"]
+        achieved = alg_bytes / (bcd_ms * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get("k_bcd", {}).get("hbm_bytes_per_launch")
+            except (ValueError, OSError):
+                traffic = None
+        out = {
+            "metric": "Mpixels/sec qmf_encode (8x8 patch, r=7, 10 iters)",
+            "value": round(value, 2),
+            "unit": "Mpix/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{B} x 512x768x3 uint8 per GPU, YCbCr 4:2:0, 8x8 patches, ranks (7,3,3), "
+                                   f"bounds (-16,15), num_iters 10, int8 factors out (BASELINE configs[1])",
+                       "global_batch": B * world, "parallelism": f"images sharded over {world} GPU(s), no data-path collective"},
+            "roofline": {"bound": "hbm", "kernel": "k_bcd", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(bcd_ms, 5)},
+            "kernels": {k: {a: round(b, 5) for a, b in v.items()} for k, v in kern.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(images[:64].cpu().numpy())
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -42,10 +42,50 @@
  * products
  * ---------------------------------------------------------------------------------------------- */
 
-/* MKL-ordered product: C[m*ldc+n] = sum_k A[m*sam+k*sak] * B[k*sbk+n*sbn]. */
+/* MKL-ordered product: C[m*ldc+n] = sum_k A[m*sam+k*sak] * B[k*sbk+n*sbn].
+ * Every output element is its own k-ordered fma chain (blocks of LRF_KC, block sums added in order);
+ * the two fast paths below only reorder the loops ACROSS independent elements, never inside a chain. */
 static void mm_mkl(const float* A, long sam, long sak, const float* B, long sbk, long sbn,
                    float* C, long ldc, long M, long K, long N)
 {
+    if (N <= 64 && sak == 1 && sbn == 1 && K <= LRF_KC) {
+        /* rows of A contiguous (x @ v): N accumulators per row */
+        for (long m = 0; m < M; m++) {
+            float acc[64];
+            for (long n = 0; n < N; n++) acc[n] = 0.f;
+            const float* a = A + m * sam;
+            for (long k = 0; k < K; k++) {
+                const float ak = a[k];
+                const float* b = B + k * sbk;
+                for (long n = 0; n < N; n++) acc[n] = fmaf(ak, b[n], acc[n]);
+            }
+            for (long n = 0; n < N; n++) C[m * ldc + n] = acc[n];
+        }
+        return;
+    }
+    if (M <= 64 && N <= 64 && sam == 1 && sbn == 1) {
+        /* A is a transposed view (x.mT @ u): stream over k, M x N accumulators stored [n][m] */
+        float s[64][64], tot[64][64];
+        for (long k0 = 0; k0 < K; k0 += LRF_KC) {
+            long k1 = k0 + LRF_KC < K ? k0 + LRF_KC : K;
+            for (long n = 0; n < N; n++)
+                for (long m = 0; m < M; m++) s[n][m] = 0.f;
+            for (long k = k0; k < k1; k++) {
+                const float* a = A + k * sak;
+                const float* b = B + k * sbk;
+                for (long n = 0; n < N; n++) {
+                    const float bn = b[n];
+                    float* sn = s[n];
+                    for (long m = 0; m < M; m++) sn[m] = fmaf(a[m], bn, sn[m]);
+                }
+            }
+            for (long n = 0; n < N; n++)
+                for (long m = 0; m < M; m++) tot[n][m] = (k0 == 0) ? s[n][m] : tot[n][m] + s[n][m];
+        }
+        for (long m = 0; m < M; m++)
+            for (long n = 0; n < N; n++) C[m * ldc + n] = tot[n][m];
+        return;
+    }
     for (long m = 0; m < M; m++)
         for (long n = 0; n < N; n++) {
             float acc = 0.f;
@@ -194,18 +234,28 @@ int lrf_oracle_bcd(const float* X, long M, long N, int R, int num_iters,
 void lrf_oracle_gram_f64(const float* X, long M, long N, double* G)
 {
     double* acc = (double*)calloc((size_t)4 * N * N, sizeof(double));
+    double* xd = (double*)malloc(sizeof(double) * N);
     long nsteps = (M + 3) / 4;
     for (long s = 0; s < nsteps; s++) {
         double* g = acc + (size_t)(s & 3) * N * N;
         for (long m = 4 * s; m < 4 * s + 4 && m < M; m++) {
             const float* x = X + m * N;
-            for (long i = 0; i < N; i++) {
-                double xi = (double)x[i];
-                for (long j = 0; j < N; j++) g[i * N + j] = fma(xi, (double)x[j], g[i * N + j]);
+            for (long i = 0; i < N; i++) xd[i] = (double)x[i];
+            for (long i = 0; i < N; i++) { /* upper triangle; (j,i) is the same fma sequence */
+                double xi = xd[i];
+                double* gi = g + i * N;
+                for (long j = i; j < N; j++) gi[j] = fma(xi, xd[j], gi[j]);
             }
         }
     }
-    for (long i = 0; i < N * N; i++) G[i] = ((acc[i] + acc[N * N + i]) + acc[2 * N * N + i]) + acc[3 * N * N + i];
+    for (long i = 0; i < N; i++)
+        for (long j = i; j < N; j++) {
+            long e = i * N + j;
+            double v = ((acc[e] + acc[N * N + e]) + acc[2 * N * N + e]) + acc[3 * N * N + e];
+            G[i * N + j] = v;
+            G[j * N + i] = v;
+        }
+    free(xd);
     free(acc);
 }
 
@@ -259,18 +309,24 @@ int lrf_oracle_jacobi_f64(double* A, int n, double* E, int max_sweeps)
                     A[q * n + k] = s * gp + c * gq;
                 }
             }
-            for (int i = 0; i < np; i++) { /* column phase: A <- A J ; E <- E J */
-                int p = pq[2 * i], q = pq[2 * i + 1];
-                double c = cs[2 * i], s = cs[2 * i + 1];
-                if (s == 0.0) continue;
-                for (int k = 0; k < n; k++) {
-                    double gp = A[k * n + p], gq = A[k * n + q];
-                    A[k * n + p] = c * gp - s * gq;
-                    A[k * n + q] = s * gp + c * gq;
-                    double ep = E[k * n + p], eq = E[k * n + q];
-                    E[k * n + p] = c * ep - s * eq;
-                    E[k * n + q] = s * ep + c * eq;
+            for (int k = 0; k < n; k++) { /* column phase: A <- A J ; E <- E J (pairs are disjoint) */
+                double* ak = A + k * n;
+                double* ek = E + k * n;
+                for (int i = 0; i < np; i++) {
+                    double c = cs[2 * i], s = cs[2 * i + 1];
+                    if (s == 0.0) continue;
+                    int p = pq[2 * i], q = pq[2 * i + 1];
+                    double gp = ak[p], gq = ak[q];
+                    ak[p] = c * gp - s * gq;
+                    ak[q] = s * gp + c * gq;
+                    double ep = ek[p], eq = ek[q];
+                    ek[p] = c * ep - s * eq;
+                    ek[q] = s * ep + c * eq;
                 }
+            }
+            for (int i = 0; i < np; i++) {
+                if (cs[2 * i + 1] == 0.0) continue;
+                int p = pq[2 * i], q = pq[2 * i + 1];
                 A[p * n + q] = 0.0;
                 A[q * n + p] = 0.0;
             }
