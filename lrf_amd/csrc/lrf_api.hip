@@ -39,7 +39,7 @@ struct lrf_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
-    DevBuf planes, blocks, vf, wf, ppart, x, sign;
+    DevBuf planes, blocks, vf, wf, bf, ppart, qpart, x, sign;
     // host staging for descriptor tables (pinned)
     void* h_stage = nullptr;
     size_t h_stage_cap = 0;
@@ -156,6 +156,8 @@ static int make_geom(int64_t H, int64_t W, ImageGeom* g)
         p.top = (int)((hp - h) / 2); p.left = (int)((wp - w) / 2);
         p.top_crop = p.top; p.left_crop = p.left;
         p.nw = (int)(wp / 8);
+        p.nh = (int)(hp / 8);
+        p.pr0 = c ? g->p[c - 1].pr0 + g->p[c - 1].nh : 0;
         p.M = (int)M;
         p.xoff = xoff;
         p.o4 = xoff / 4;
@@ -210,7 +212,9 @@ static int upload_tables(lrf_ctx* c, const Tables& t)
     size_t np = t.planes.size(), nb = t.blocks.size();
     if ((rc = ensure(c, c->vf, np * 64 * LRF_RP * sizeof(float)))) return rc;
     if ((rc = ensure(c, c->wf, np * 64 * LRF_RP * sizeof(float)))) return rc;
+    if ((rc = ensure(c, c->bf, np * LRF_BT_STRIDE * sizeof(float)))) return rc;
     if ((rc = ensure(c, c->ppart, nb * 64 * LRF_RP * sizeof(float)))) return rc;
+    if ((rc = ensure(c, c->qpart, nb * LRF_RP * LRF_RP * sizeof(float)))) return rc;
     return LRF_OK;
 }
 
@@ -232,6 +236,25 @@ static int run_init(lrf_ctx* c, const float* X, int nplanes, const int8_t* sign_
     return LRF_OK;
 }
 
+static GsParams make_gs(int lo, int hi)
+{
+    GsParams gp;
+    gp.lo = (float)lo;
+    gp.hi = (float)hi;
+    int mx = abs(lo) > abs(hi) ? abs(lo) : abs(hi);
+    gp.flimit = (float)(mx + 2);
+    gp.fthr = 0.5f - 8e-7f * (float)(mx + 2); // see gs_row: q~ is within 3 ulp (< 2e-7 |q|) of fl(num/den)
+    return gp;
+}
+
+static int run_bprep(lrf_ctx* c, int nplanes)
+{
+    hipLaunchKernelGGL(k_bprep, dim3(nplanes), dim3(256), 0, c->stream, (const PlaneDesc*)c->planes.p, (const float*)c->vf.p,
+                       (float*)c->bf.p);
+    LAUNCH_CHECK();
+    return LRF_OK;
+}
+
 // mode: 1 = old U from X @ W0 (after run_init), 2 = old U from caller's fp32 U0
 static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, int hi, int first_mode, const float* U0,
                    int8_t* U, int8_t* V)
@@ -240,24 +263,28 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
     const BlockDesc* bl = (const BlockDesc*)c->blocks.p;
     float* vf = (float*)c->vf.p;
     float* wf = (float*)c->wf.p;
+    float* bf = (float*)c->bf.p;
     float* pp = (float*)c->ppart.p;
+    float* qp = (float*)c->qpart.p;
     int nb = (int)t.blocks.size(), np = (int)t.planes.size();
-    float flo = (float)lo, fhi = (float)hi;
+    GsParams gp = make_gs(lo, hi);
+    int rc = run_bprep(c, np);
+    if (rc) return rc;
     for (int it = 0; it < K; it++) {
         {
             Prof p(c, LRF_K_BCD);
             if (it == 0 && first_mode == 1)
-                hipLaunchKernelGGL(k_bcd<1>, dim3(nb), dim3(256), 0, c->stream, X, pl, bl, vf, wf, U0, U, pp, flo, fhi);
+                hipLaunchKernelGGL(k_bcd<1>, dim3(nb), dim3(256), 0, c->stream, X, pl, bl, vf, wf, bf, U0, U, pp, qp, gp);
             else if (it == 0 && first_mode == 2)
-                hipLaunchKernelGGL(k_bcd<2>, dim3(nb), dim3(256), 0, c->stream, X, pl, bl, vf, wf, U0, U, pp, flo, fhi);
+                hipLaunchKernelGGL(k_bcd<2>, dim3(nb), dim3(256), 0, c->stream, X, pl, bl, vf, wf, bf, U0, U, pp, qp, gp);
             else
-                hipLaunchKernelGGL(k_bcd<0>, dim3(nb), dim3(256), 0, c->stream, X, pl, bl, vf, wf, U0, U, pp, flo, fhi);
+                hipLaunchKernelGGL(k_bcd<0>, dim3(nb), dim3(256), 0, c->stream, X, pl, bl, vf, wf, bf, U0, U, pp, qp, gp);
             LAUNCH_CHECK();
         }
         {
             Prof p(c, LRF_K_VUPDATE);
-            hipLaunchKernelGGL(k_vupdate, dim3(np), dim3(256), 0, c->stream, pl, (const int8_t*)U, (const float*)pp, vf, V,
-                               flo, fhi, it == K - 1 ? 1 : 0);
+            hipLaunchKernelGGL(k_vupdate, dim3(np), dim3(256), 0, c->stream, pl, (const float*)pp, (const float*)qp, vf, bf, V, gp,
+                               it == K - 1 ? 1 : 0);
             LAUNCH_CHECK();
         }
     }
@@ -304,7 +331,7 @@ void lrf_ctx_destroy(lrf_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     fold_events(c);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-    DevBuf* bufs[] = {&c->planes, &c->blocks, &c->vf, &c->wf, &c->ppart, &c->x, &c->sign};
+    DevBuf* bufs[] = {&c->planes, &c->blocks, &c->vf, &c->wf, &c->bf, &c->ppart, &c->qpart, &c->x, &c->sign};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -342,7 +369,7 @@ int lrf_ctx_synchronize(lrf_ctx* c)
 size_t lrf_ctx_workspace_bytes(const lrf_ctx* c)
 {
     if (!c) return 0;
-    return c->planes.cap + c->blocks.cap + c->vf.cap + c->wf.cap + c->ppart.cap + c->x.cap + c->sign.cap;
+    return c->planes.cap + c->blocks.cap + c->vf.cap + c->wf.cap + c->bf.cap + c->ppart.cap + c->qpart.cap + c->x.cap + c->sign.cap;
 }
 
 int lrf_ctx_profile(lrf_ctx* c, int enable)
@@ -422,7 +449,8 @@ int lrf_qmf_planes_from_rgb_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
     Prof p(c, LRF_K_PLANES);
-    hipLaunchKernelGGL(k_planes, dim3((unsigned)((g.tot4 + 255) / 256), (unsigned)B), dim3(256), 0, c->stream, rgb, (int)H,
+    if ((long)H * W * 3 >= (1L << 31)) return set_err(LRF_ENOTSUP, "image too large for 32-bit pixel indexing");
+    hipLaunchKernelGGL(k_planes, dim3((unsigned)(g.p[2].pr0 + g.p[2].nh), (unsigned)B), dim3(256), 0, c->stream, rgb, (int)H,
                        (int)W, g, X);
     LAUNCH_CHECK();
     return LRF_OK;

@@ -13,6 +13,8 @@ struct PlaneGeom {
     int top, left;     // pad_top / pad_left == unpad start (utils.py:127-130, :148-150)
     int top_crop, left_crop;
     int nw;            // patches per row
+    int nh;            // patch rows
+    int pr0;           // first patch-row index of this plane inside the image (k_planes grid)
     int M;             // number of patches
     long xoff;         // floats from the image's X base
     long o4;           // first float4 output index of this plane inside the image

@@ -31,49 +31,94 @@ __device__ __forceinline__ int reflect_idx(int i, int n)
     return i;
 }
 
-// offset + einsum("ij,j...->i...") for one pixel: k-ordered fma chain from 0 (sgemm, K = 3).
-__device__ __forceinline__ float ycc_at(const uint8_t* __restrict__ img, long hw, long pix, int c)
+// offset + einsum("ij,j...->i...") for one pixel: k-ordered fma chain from 0 (sgemm, K = 3), then offset + acc.
+// ycc from three already-loaded channel bytes
+__device__ __forceinline__ float ycc_of(float r, float g, float b, int c)
 {
     const float T[3][3] = {{0.299f, 0.587f, 0.114f}, {-0.168736f, -0.331264f, 0.5f}, {0.5f, -0.418688f, -0.081312f}};
     float acc = 0.f;
-    acc = fmaf(T[c][0], (float)img[pix], acc);
-    acc = fmaf(T[c][1], (float)img[hw + pix], acc);
-    acc = fmaf(T[c][2], (float)img[2 * hw + pix], acc);
+    acc = fmaf(T[c][0], r, acc);
+    acc = fmaf(T[c][1], g, acc);
+    acc = fmaf(T[c][2], b, acc);
     return (c ? 128.f : 0.f) + acc;
 }
 
+// One workgroup per (patch row of one plane, image): it consumes 8 (luma) or 16 (chroma) full image rows and
+// writes nw complete 256-byte patches.  Thread item = one float4 of a patch (16 consecutive items = one patch,
+// so stores are fully coalesced); int32 arithmetic only, word loads on the aligned interior fast paths.
 __global__ __launch_bounds__(256) void k_planes(const uint8_t* __restrict__ rgb, int H, int W, ImageGeom g,
                                                 float* __restrict__ X)
 {
-    long o = (long)blockIdx.x * 256 + threadIdx.x; // one float4 of output per thread
-    if (o >= g.tot4) return;
-    const uint8_t* img = rgb + (long)blockIdx.y * 3 * H * W;
-    float* Xi = X + (long)blockIdx.y * g.img_floats;
-    int c = (o >= g.p[1].o4) ? ((o >= g.p[2].o4) ? 2 : 1) : 0;
+    const int pr = blockIdx.x;
+    const int c = (pr >= g.p[2].pr0) ? 2 : ((pr >= g.p[1].pr0) ? 1 : 0);
     const PlaneGeom pg = g.p[c];
-    long ol = o - pg.o4;
-    int patch = (int)(ol >> 4), a = (int)((ol >> 1) & 7), b4 = (int)(ol & 1) * 4;
-    int hh = patch / pg.nw, ww = patch - hh * pg.nw;
-    int y = reflect_idx(hh * 8 + a - pg.top, pg.h);
-    long hw = (long)H * W;
-    f32x4 out;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        int x = reflect_idx(ww * 8 + b4 + i - pg.left, pg.w);
-        float v;
+    const int hh = pr - pg.pr0;
+    const uint8_t* img = rgb + (long)blockIdx.y * 3 * H * W;
+    float* Xp = X + (long)blockIdx.y * g.img_floats + pg.xoff + (long)hh * pg.nw * 64;
+    const int hw = H * W;
+    const bool even2x = (c != 0) && (H == 2 * pg.h) && (W == 2 * pg.w);
+    const bool wordy = (pg.left == 0) && ((W & 7) == 0) && ((reinterpret_cast<uintptr_t>(rgb) & 7) == 0);
+    for (int it = threadIdx.x; it < pg.nw * 16; it += 256) {
+        const int ww = it >> 4, a = (it >> 1) & 7, b4 = (it & 1) * 4;
+        const int y = reflect_idx(hh * 8 + a - pg.top, pg.h);
+        const int x0 = ww * 8 + b4 - pg.left;
+        f32x4 out;
         if (c == 0) {
-            v = ycc_at(img, hw, (long)y * W + x, 0);
-        } else { // adaptive average pool window, row-major fp32 sum, then / kh / kw
-            int h0 = (int)(((long)y * H) / pg.h), h1 = (int)((((long)y + 1) * H + pg.h - 1) / pg.h);
-            int w0 = (int)(((long)x * W) / pg.w), w1 = (int)((((long)x + 1) * W + pg.w - 1) / pg.w);
-            float sum = 0.f;
-            for (int yy = h0; yy < h1; yy++)
-                for (int xx = w0; xx < w1; xx++) sum = sum + ycc_at(img, hw, (long)yy * W + xx, c);
-            v = sum / (float)(h1 - h0) / (float)(w1 - w0);
+            if (wordy && x0 + 3 < pg.w) {
+                const uint8_t* p0 = img + y * W + x0;
+                uint32_t r4 = *reinterpret_cast<const uint32_t*>(p0);
+                uint32_t g4 = *reinterpret_cast<const uint32_t*>(p0 + hw);
+                uint32_t b4w = *reinterpret_cast<const uint32_t*>(p0 + 2 * hw);
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    out[i] = ycc_of((float)((r4 >> (8 * i)) & 255u), (float)((g4 >> (8 * i)) & 255u),
+                                    (float)((b4w >> (8 * i)) & 255u), 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    int x = reflect_idx(x0 + i, pg.w);
+                    const uint8_t* p0 = img + y * W + x;
+                    out[i] = ycc_of((float)p0[0], (float)p0[hw], (float)p0[2 * hw], 0);
+                }
+            }
+        } else if (even2x && wordy && x0 + 3 < pg.w) {
+            // exact 2x2 windows: rows 2y, 2y+1; columns 2x0 .. 2x0+7 (8-byte aligned)
+            uint64_t ch[3][2];
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+#pragma unroll
+                for (int rr = 0; rr < 2; rr++)
+                    ch[k][rr] = *reinterpret_cast<const uint64_t*>(img + k * hw + (2 * y + rr) * W + 2 * x0);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                float sum = 0.f;
+#pragma unroll
+                for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+                    for (int cc = 0; cc < 2; cc++) {
+                        int sh = 8 * (2 * i + cc);
+                        sum = sum + ycc_of((float)((ch[0][rr] >> sh) & 255u), (float)((ch[1][rr] >> sh) & 255u),
+                                           (float)((ch[2][rr] >> sh) & 255u), c);
+                    }
+                out[i] = sum / 2.f / 2.f;
+            }
+        } else { // general adaptive-average-pool window (odd sizes), row-major fp32 sum, then / kh / kw
+            const int h0 = (y * H) / pg.h, h1 = ((y + 1) * H + pg.h - 1) / pg.h;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                int x = reflect_idx(x0 + i, pg.w);
+                int w0 = (x * W) / pg.w, w1 = ((x + 1) * W + pg.w - 1) / pg.w;
+                float sum = 0.f;
+                for (int yy = h0; yy < h1; yy++)
+                    for (int xx = w0; xx < w1; xx++) {
+                        const uint8_t* p0 = img + yy * W + xx;
+                        sum = sum + ycc_of((float)p0[0], (float)p0[hw], (float)p0[2 * hw], c);
+                    }
+                out[i] = sum / (float)(h1 - h0) / (float)(w1 - w0);
+            }
         }
-        out[i] = v;
+        *reinterpret_cast<f32x4*>(Xp + ww * 64 + a * 8 + b4) = out;
     }
-    *reinterpret_cast<f32x4*>(Xi + pg.xoff + (long)patch * 64 + a * 8 + b4) = out;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -260,12 +305,27 @@ __global__ __launch_bounds__(256) void k_init(const float* __restrict__ X, const
 
 // ------------------------------------------------------------------------------------------------
 // Gauss-Seidel over the R columns of one row (qmf.py:108-119).  a[] = (x @ v) row, u[] = current
-// row of the factor being updated (in/out).  b_s: LDS [LRF_RP][LRF_RP] (b = v.mT @ v), den_s[r] =
-// (b[r][r] + 0) + eps.  `native` selects the ATen small-product order for the `uu @ bb` term.
+// row of the factor being updated (in/out).  bt: the per-matrix table {b[RP][RP], den[RP], rden[RP]}
+// with b = v.mT @ v, den[r] = (b[r][r] + 0) + eps, rden = 1/den (uniform across lanes: scalar loads
+// when it lives in global memory).  `native` selects the ATen small-product order for `uu @ bb`.
+//
+// Division: the reference computes round(fl(num / den)).  q~ = num * rden is within 3 ulp of that
+// quotient, so unless q~ sits within `1/2 - fthr` of a rounding tie its nearest integer is the same;
+// only then (or never, beyond the clamp range) is the IEEE division evaluated.  Results are identical.
 // ------------------------------------------------------------------------------------------------
+#define LRF_BT_DEN (LRF_RP * LRF_RP)
+#define LRF_BT_RDEN (LRF_RP * LRF_RP + LRF_RP)
+#define LRF_BT_STRIDE (LRF_RP * LRF_RP + 2 * LRF_RP)
+
+struct GsParams {
+    float lo, hi;      // clamp
+    float flimit;      // |q~| >= flimit: certainly outside [lo,hi] after rounding
+    float fthr;        // |q~ - rint(q~)| <= fthr: rint(q~) == rint(fl(num/den))
+};
+
 template <int R>
-__device__ __forceinline__ void gs_row(const float* a, float* u, const float* b_s, const float* den_s, bool native,
-                                       float lo, float hi)
+__device__ __forceinline__ void gs_row(const float* a, float* u, const float* __restrict__ bt, bool native,
+                                       const GsParams gp)
 {
 #pragma unroll
     for (int r = 0; r < R; r++) {
@@ -275,7 +335,7 @@ __device__ __forceinline__ void gs_row(const float* a, float* u, const float* b_
         for (int j = 0; j < R; j++)
             if (j != r) {
                 uu[n] = u[j];
-                bb[n] = b_s[j * LRF_RP + r];
+                bb[n] = bt[j * LRF_RP + r];
                 n++;
             }
         constexpr int K = R - 1;
@@ -305,40 +365,42 @@ __device__ __forceinline__ void gs_row(const float* a, float* u, const float* b_
                 }
             }
         }
-        float num = a[r] - term2;
-        float val = (num + LRF_EPS) / den_s[r];
-        val = rintf(val);
-        val = fminf(fmaxf(val, lo), hi);
-        u[r] = val;
+        float num = (a[r] - term2) + LRF_EPS;
+        float q = num * bt[LRF_BT_RDEN + r];
+        float nq = rintf(q);
+        float val = nq;
+        if (fabsf(q) >= gp.flimit) val = q;
+        else if (fabsf(q - nq) > gp.fthr) val = rintf(num / bt[LRF_BT_DEN + r]);
+        u[r] = fminf(fmaxf(val, gp.lo), gp.hi);
     }
 }
 
 template <int R>
-__device__ __forceinline__ void gs_row_lds(const float* a_row, float* u_row, const float* b_s, const float* den_s,
-                                           bool native, float lo, float hi)
+__device__ __forceinline__ void gs_row_lds(const float* a_row, float* u_row, const float* __restrict__ bt, bool native,
+                                           const GsParams gp)
 {
     float a[R], u[R];
 #pragma unroll
     for (int r = 0; r < R; r++) { a[r] = a_row[r]; u[r] = u_row[r]; }
-    gs_row<R>(a, u, b_s, den_s, native, lo, hi);
+    gs_row<R>(a, u, bt, native, gp);
 #pragma unroll
     for (int r = 0; r < R; r++) u_row[r] = u[r];
 }
 
-__device__ __forceinline__ void gs_dispatch(int R, const float* a_row, float* u_row, const float* b_s,
-                                            const float* den_s, bool native, float lo, float hi)
+__device__ __forceinline__ void gs_dispatch(int R, const float* a_row, float* u_row, const float* __restrict__ bt,
+                                            bool native, const GsParams gp)
 {
     switch (R) {
-#define LRF_CASE(r) case r: gs_row_lds<r>(a_row, u_row, b_s, den_s, native, lo, hi); break;
+#define LRF_CASE(r) case r: gs_row_lds<r>(a_row, u_row, bt, native, gp); break;
         LRF_CASE(1) LRF_CASE(2) LRF_CASE(3) LRF_CASE(4) LRF_CASE(5) LRF_CASE(6) LRF_CASE(7) LRF_CASE(8)
         LRF_CASE(9) LRF_CASE(10) LRF_CASE(11) LRF_CASE(12) LRF_CASE(13) LRF_CASE(14) LRF_CASE(15) LRF_CASE(16)
 #undef LRF_CASE
     }
 }
 
-// b = v.mT @ v for the R x R block: thread (j, r).  ATen uses its native kernel when depth*R*R < 400.
-__device__ __forceinline__ void gram_small(const float* __restrict__ Vp /*[depth][LRF_RP]*/, int depth, int R,
-                                           float* b_s, float* den_s, int tid, int nthreads)
+// b = v.mT @ v (R x R) with den / rden, from a [depth][LRF_RP] factor: thread (j, r).
+// ATen uses its native kernel when depth*R*R < 400, MKL (k-ordered fma chain) otherwise.
+__device__ __forceinline__ void make_btable(const float* Vp, int depth, int R, float* bt, int tid, int nthreads)
 {
     bool native = (long)depth * R * R < 400;
     for (int i = tid; i < R * R; i += nthreads) {
@@ -352,30 +414,46 @@ __device__ __forceinline__ void gram_small(const float* __restrict__ Vp /*[depth
         } else {
             for (int k = 0; k < depth; k++) acc = fmaf(Vp[k * LRF_RP + j], Vp[k * LRF_RP + r], acc);
         }
-        b_s[j * LRF_RP + r] = acc;
-        if (j == r) den_s[r] = (acc + 0.f) + LRF_EPS;
+        bt[j * LRF_RP + r] = acc;
+        if (j == r) {
+            float den = (acc + 0.f) + LRF_EPS;
+            bt[LRF_BT_DEN + r] = den;
+            bt[LRF_BT_RDEN + r] = 1.0f / den;
+        }
     }
 }
 
+// b table of the initial V (after k_init or k_load_v0): one workgroup per matrix
+__global__ __launch_bounds__(256) void k_bprep(const PlaneDesc* __restrict__ planes, const float* __restrict__ Vf,
+                                               float* __restrict__ Bf)
+{
+    __shared__ float v_s[64 * LRF_RP];
+    for (int i = threadIdx.x; i < 64 * LRF_RP; i += 256) v_s[i] = Vf[(long)blockIdx.x * 64 * LRF_RP + i];
+    __syncthreads();
+    make_btable(v_s, 64, planes[blockIdx.x].R, Bf + (long)blockIdx.x * LRF_BT_STRIDE, threadIdx.x, 256);
+}
+
 // ------------------------------------------------------------------------------------------------
-// K3: one BCD half-iteration over X: U update (row local) fused with the partial a' = X^T U of the
-// following V update.  One workgroup (4 waves) per (matrix, 384-row block); sub-tiles of 64 rows
-// staged through LDS.  MODE 0: old U from int8 (iterations >= 2); MODE 1: first iteration, old U =
-// X @ W0 computed here; MODE 2: first iteration, old U = caller's fp32 U0.
+// K3: one BCD half-iteration over X: U update (row local) fused with the partials of the following V
+// update, a' = X^T U (fp32 chain over the block's rows) and b' = U^T U (exact).  One workgroup (4 waves)
+// per (matrix, 384-row block); 64-row sub-tiles staged through LDS, the next sub-tile prefetched into
+// registers while the current one is processed.
+// MODE 0: old U from int8 (iterations >= 2); MODE 1: first iteration, old U = X @ W0 computed here;
+// MODE 2: first iteration, old U = caller's fp32 U0.
 // ------------------------------------------------------------------------------------------------
 #define XS_LD 66 // LDS row stride (dwords) of the X sub-tile: conflict-free B-operand reads
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_bcd(const float* __restrict__ X, const PlaneDesc* __restrict__ planes,
                                              const BlockDesc* __restrict__ blocks, const float* __restrict__ Vf,
-                                             const float* __restrict__ Wf, const float* __restrict__ U0,
-                                             int8_t* __restrict__ U, float* __restrict__ Ppart, float lo, float hi)
+                                             const float* __restrict__ Wf, const float* __restrict__ Bf,
+                                             const float* __restrict__ U0, int8_t* __restrict__ U,
+                                             float* __restrict__ Ppart, float* __restrict__ Qpart, GsParams gp)
 {
     __shared__ __attribute__((aligned(16))) float Xs[64 * XS_LD];
     __shared__ __attribute__((aligned(16))) float a_s[64 * LRF_RP];
     __shared__ __attribute__((aligned(16))) float u_s[64 * LRF_RP];
-    __shared__ __attribute__((aligned(16))) float b_s[LRF_RP * LRF_RP];
-    __shared__ float den_s[LRF_RP];
+    __shared__ __attribute__((aligned(16))) int8_t uold_s[64 * LRF_RP];
 
     const BlockDesc bd = blocks[blockIdx.x];
     const PlaneDesc pd = planes[bd.plane];
@@ -384,9 +462,12 @@ __global__ __launch_bounds__(256) void k_bcd(const float* __restrict__ X, const 
     const int li = lane & 15, lq = lane >> 4;
     const float* Xp = X + pd.x_off + (long)bd.row0 * 64;
     const float* Vp = Vf + (long)bd.plane * 64 * LRF_RP;
+    const float* bt = Bf + (long)bd.plane * LRF_BT_STRIDE;
+    int8_t* Ub = U + pd.u_off + (long)bd.row0 * R;
     int nrows = pd.M - bd.row0;
     if (nrows > LRF_KC) nrows = LRF_KC;
     const int nsub = (nrows + 63) >> 6;
+    const int invR = (65536 + R - 1) / R; // (i * invR) >> 16 == i / R for i < 64 * R
 
     // A operand of a^T = V^T X^T : A[i = r][k]; lane holds V[4s + lq][li]
     float aV[16], aW[16];
@@ -395,23 +476,51 @@ __global__ __launch_bounds__(256) void k_bcd(const float* __restrict__ X, const 
         aV[s] = Vp[(4 * s + lq) * LRF_RP + li];
         if (MODE == 1) aW[s] = Wf[(long)bd.plane * 64 * LRF_RP + (4 * s + lq) * LRF_RP + li];
     }
-    gram_small(Vp, 64, R, b_s, den_s, tid, 256);
 
-    f32x4 accP = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int t = 0; t < nsub; t++) {
+    // prefetch registers: the X sub-tile (4 x float4 per thread) and the old int8 U rows (<= 4 bytes per thread)
+    f32x4 xpre[4];
+    int8_t upre[4];
+    auto issue = [&](int t) {
         const int r0 = t * 64;
-        __syncthreads(); // previous sub-tile fully consumed (also orders b_s / den_s writes)
-        // ---- stage X[r0 .. r0+63][0..63] -> Xs (zero rows past the block)
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            int e = i * 256 + tid; // float4 index: row = e >> 4, c4 = e & 15
-            int row = e >> 4, c4 = e & 15;
-            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (r0 + row < nrows) v = *reinterpret_cast<const f32x4*>(Xp + (long)(r0 + row) * 64 + 4 * c4);
-            float2* d = reinterpret_cast<float2*>(&Xs[row * XS_LD + 4 * c4]);
-            d[0] = make_float2(v[0], v[1]);
-            d[1] = make_float2(v[2], v[3]);
+            int e = i * 256 + tid, row = e >> 4, c4 = e & 15;
+            xpre[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (r0 + row < nrows) xpre[i] = *reinterpret_cast<const f32x4*>(Xp + (long)(r0 + row) * 64 + 4 * c4);
         }
+        if (MODE == 0) {
+            int lim = (nrows - r0 < 64 ? nrows - r0 : 64) * R;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                int e = i * 256 + tid;
+                upre[i] = (e < lim) ? Ub[(long)r0 * R + e] : (int8_t)0;
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int e = i * 256 + tid, row = e >> 4, c4 = e & 15;
+            float2* d = reinterpret_cast<float2*>(&Xs[row * XS_LD + 4 * c4]);
+            d[0] = make_float2(xpre[i][0], xpre[i][1]);
+            d[1] = make_float2(xpre[i][2], xpre[i][3]);
+        }
+        if (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                int e = i * 256 + tid;
+                if (e < 64 * R) uold_s[e] = upre[i];
+            }
+        }
+    };
+
+    f32x4 accP = (f32x4){0.f, 0.f, 0.f, 0.f}, accQ = (f32x4){0.f, 0.f, 0.f, 0.f};
+    issue(0);
+    for (int t = 0; t < nsub; t++) {
+        const int r0 = t * 64;
+        __syncthreads(); // previous sub-tile fully consumed
+        commit();
+        if (t + 1 < nsub) issue(t + 1);
         __syncthreads();
         // ---- a^T tile for rows 16*wave .. +15 : 16 chained MFMAs over k
         {
@@ -433,77 +542,65 @@ __global__ __launch_bounds__(256) void k_bcd(const float* __restrict__ X, const 
             int row = r0 + lane;
             float* ur = &u_s[lane * LRF_RP];
             if (row < nrows) {
-                long grow = (long)bd.row0 + row;
                 if (MODE == 0) {
-                    const int8_t* up = U + pd.u_off + grow * R;
-                    for (int r = 0; r < R; r++) ur[r] = (float)up[r];
+                    for (int r = 0; r < R; r++) ur[r] = (float)uold_s[lane * R + r];
                 } else if (MODE == 2) {
-                    const float* up = U0 + pd.u0_off + grow * R;
+                    const float* up = U0 + pd.u0_off + ((long)bd.row0 + row) * R;
                     for (int r = 0; r < R; r++) ur[r] = up[r];
                 }
-                gs_dispatch(R, &a_s[lane * LRF_RP], ur, b_s, den_s, pd.native_t2_u != 0, lo, hi);
-                int8_t* uo = U + pd.u_off + grow * R;
-                for (int r = 0; r < R; r++) uo[r] = (int8_t)ur[r];
+                gs_dispatch(R, &a_s[lane * LRF_RP], ur, bt, pd.native_t2_u != 0, gp);
                 for (int r = R; r < LRF_RP; r++) ur[r] = 0.f;
             } else {
                 for (int r = 0; r < LRF_RP; r++) ur[r] = 0.f;
             }
         }
         __syncthreads();
-        // ---- partial a' = X^T U for columns 16*wave .. +15: chain over the 64 rows of the sub-tile
+        // ---- int8 U out (coalesced bytes), partial a' = X^T U for columns 16*wave..+15, partial b' = U^T U
         {
+            int lim = (nrows - r0 < 64 ? nrows - r0 : 64) * R;
+            for (int e = tid; e < lim; e += 256) {
+                int row = (e * invR) >> 16, r = e - row * R;
+                Ub[(long)r0 * R + e] = (int8_t)u_s[row * LRF_RP + r];
+            }
             const float* xc = &Xs[lq * XS_LD + 16 * wave + li];
             const float* uc = &u_s[lq * LRF_RP + li];
 #pragma unroll
-            for (int s = 0; s < 16; s++)
-                accP = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[4 * s * XS_LD], uc[4 * s * LRF_RP], accP, 0, 0, 0);
+            for (int s = 0; s < 16; s++) {
+                float ub = uc[4 * s * LRF_RP];
+                accP = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[4 * s * XS_LD], ub, accP, 0, 0, 0);
+                if ((s & 3) == wave) accQ = __builtin_amdgcn_mfma_f32_16x16x4f32(ub, ub, accQ, 0, 0, 0);
+            }
         }
     }
-    // D[i = 4*lq + reg (column 16*wave + i)][j = li (r)]
-    float* Pp = Ppart + ((long)pd.blk0 + bd.blk) * 64 * LRF_RP;
+    // a' partial: D[i = 4*lq + reg (column 16*wave + i)][j = li (r)]
+    const long slot = (long)pd.blk0 + bd.blk;
+    float* Pp = Ppart + slot * 64 * LRF_RP;
 #pragma unroll
     for (int reg = 0; reg < 4; reg++) Pp[(16 * wave + 4 * lq + reg) * LRF_RP + li] = accP[reg];
+    // b' partial: the four waves hold disjoint row subsets; integers, so the sum order is immaterial
+    __syncthreads();
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) a_s[wave * 256 + (4 * lq + reg) * LRF_RP + li] = accQ[reg];
+    __syncthreads();
+    Qpart[slot * LRF_RP * LRF_RP + tid] = ((a_s[tid] + a_s[256 + tid]) + a_s[512 + tid]) + a_s[768 + tid];
 }
 
 // ------------------------------------------------------------------------------------------------
 // K3b: V update for one matrix per workgroup: a' = sum of the block partials (in block order),
-// b' = U^T U (exact integers), Gauss-Seidel over the R columns for the 64 rows of V.
+// b' = U^T U (sum of exact integer partials), Gauss-Seidel over the R columns for the 64 rows of V,
+// then the b table (v.mT @ v) of the new V for the next U update.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_vupdate(const PlaneDesc* __restrict__ planes, const int8_t* __restrict__ U,
-                                                 const float* __restrict__ Ppart, float* __restrict__ Vf,
-                                                 int8_t* __restrict__ V8, float lo, float hi, int write_i8)
+__global__ __launch_bounds__(256) void k_vupdate(const PlaneDesc* __restrict__ planes, const float* __restrict__ Ppart,
+                                                 const float* __restrict__ Qpart, float* __restrict__ Vf,
+                                                 float* __restrict__ Bf, int8_t* __restrict__ V8, GsParams gp,
+                                                 int write_i8)
 {
-    __shared__ int q_i[LRF_RP * LRF_RP];
-    __shared__ __attribute__((aligned(16))) float b_s[LRF_RP * LRF_RP];
-    __shared__ float den_s[LRF_RP];
+    __shared__ __attribute__((aligned(16))) float bt_s[LRF_BT_STRIDE];
     __shared__ __attribute__((aligned(16))) float a_s[64 * LRF_RP];
     __shared__ __attribute__((aligned(16))) float v_s[64 * LRF_RP];
 
     const PlaneDesc pd = planes[blockIdx.x];
-    const int R = pd.R, M = pd.M, tid = threadIdx.x;
-    for (int i = tid; i < LRF_RP * LRF_RP; i += 256) q_i[i] = 0;
-    __syncthreads();
-    // b' = U^T U: exact in int32 (|u| <= 128, M < 2^17 checked on the host)
-    {
-        int qa[LRF_RP * (LRF_RP + 1) / 2];
-        const int npair = R * (R + 1) / 2;
-        for (int i = 0; i < npair; i++) qa[i] = 0;
-        const int8_t* Up = U + pd.u_off;
-        for (int m = tid; m < M; m += 256) {
-            int u[LRF_RP];
-            for (int r = 0; r < R; r++) u[r] = Up[(long)m * R + r];
-            int n = 0;
-            for (int j = 0; j < R; j++)
-                for (int r = j; r < R; r++) qa[n++] += u[j] * u[r];
-        }
-        int n = 0;
-        for (int j = 0; j < R; j++)
-            for (int r = j; r < R; r++) {
-                int v = qa[n++];
-                for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-                if ((tid & 63) == 0) atomicAdd(&q_i[j * LRF_RP + r], v);
-            }
-    }
+    const int R = pd.R, tid = threadIdx.x;
     // a' = ((P0 + P1) + P2) + ...
     for (int i = tid; i < 64 * LRF_RP; i += 256) {
         const float* Pp = Ppart + (long)pd.blk0 * 64 * LRF_RP + i;
@@ -512,17 +609,22 @@ __global__ __launch_bounds__(256) void k_vupdate(const PlaneDesc* __restrict__ p
         a_s[i] = acc;
         v_s[i] = Vf[(long)blockIdx.x * 64 * LRF_RP + i];
     }
-    __syncthreads();
-    for (int i = tid; i < R * R; i += 256) {
-        int j = i / R, r = i - j * R;
-        float q = (float)(j <= r ? q_i[j * LRF_RP + r] : q_i[r * LRF_RP + j]);
-        b_s[j * LRF_RP + r] = q;
-        if (j == r) den_s[r] = (q + 0.f) + LRF_EPS;
+    {
+        const float* Qp = Qpart + (long)pd.blk0 * LRF_RP * LRF_RP + tid;
+        float q = Qp[0];
+        for (int b = 1; b < pd.nblk; b++) q = q + Qp[(long)b * LRF_RP * LRF_RP];
+        int j = tid >> 4, r = tid & 15;
+        bt_s[tid] = q;
+        if (j == r) {
+            float den = (q + 0.f) + LRF_EPS;
+            bt_s[LRF_BT_DEN + r] = den;
+            bt_s[LRF_BT_RDEN + r] = 1.0f / den;
+        }
     }
     __syncthreads();
     if (tid < 64) {
         bool native = (long)(R - 1) * 64 < 400;
-        gs_dispatch(R, &a_s[tid * LRF_RP], &v_s[tid * LRF_RP], b_s, den_s, native, lo, hi);
+        gs_dispatch(R, &a_s[tid * LRF_RP], &v_s[tid * LRF_RP], bt_s, native, gp);
         float* Vp = Vf + (long)blockIdx.x * 64 * LRF_RP + tid * LRF_RP;
         for (int r = 0; r < R; r++) Vp[r] = v_s[tid * LRF_RP + r];
         if (write_i8) {
@@ -530,6 +632,8 @@ __global__ __launch_bounds__(256) void k_vupdate(const PlaneDesc* __restrict__ p
             for (int r = 0; r < R; r++) vo[r] = (int8_t)v_s[tid * LRF_RP + r];
         }
     }
+    __syncthreads();
+    if (!write_i8) make_btable(v_s, 64, R, Bf + (long)blockIdx.x * LRF_BT_STRIDE, tid, 256);
 }
 
 // loads caller-supplied fp32 V0 [B][64][R] into the padded Vf table (lrf_qmf_bcd_f32)
