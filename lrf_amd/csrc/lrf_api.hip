@@ -4,6 +4,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -212,7 +213,7 @@ static int upload_tables(lrf_ctx* c, const Tables& t)
     size_t np = t.planes.size(), nb = t.blocks.size();
     if ((rc = ensure(c, c->vf, np * 64 * LRF_RP * sizeof(float)))) return rc;
     if ((rc = ensure(c, c->wf, np * 64 * LRF_RP * sizeof(float)))) return rc;
-    if ((rc = ensure(c, c->bf, np * LRF_BT_STRIDE * sizeof(float)))) return rc;
+    if ((rc = ensure(c, c->bf, np * LRF_GT_STRIDE * sizeof(float)))) return rc;
     if ((rc = ensure(c, c->ppart, nb * 64 * LRF_RP * sizeof(float)))) return rc;
     if ((rc = ensure(c, c->qpart, nb * LRF_RP * LRF_RP * sizeof(float)))) return rc;
     return LRF_OK;
@@ -268,23 +269,36 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
     float* qp = (float*)c->qpart.p;
     int nb = (int)t.blocks.size(), np = (int)t.planes.size();
     GsParams gp = make_gs(lo, hi);
+    int rmax = 1;
+    for (const PlaneDesc& pd : t.planes) rmax = pd.R > rmax ? pd.R : rmax;
     int rc = run_bprep(c, np);
     if (rc) return rc;
     for (int it = 0; it < K; it++) {
         {
             Prof p(c, LRF_K_BCD);
-            if (it == 0 && first_mode == 1)
-                hipLaunchKernelGGL(k_bcd<1>, dim3(nb), dim3(256), 0, c->stream, X, pl, bl, vf, wf, bf, U0, U, pp, qp, gp);
-            else if (it == 0 && first_mode == 2)
-                hipLaunchKernelGGL(k_bcd<2>, dim3(nb), dim3(256), 0, c->stream, X, pl, bl, vf, wf, bf, U0, U, pp, qp, gp);
-            else
-                hipLaunchKernelGGL(k_bcd<0>, dim3(nb), dim3(256), 0, c->stream, X, pl, bl, vf, wf, bf, U0, U, pp, qp, gp);
+            int mode = (it == 0) ? first_mode : 0;
+#define LRF_LAUNCH_BCD(MODE, RMAX)                                                                                   \
+    hipLaunchKernelGGL((k_bcd<MODE, RMAX>), dim3(nb), dim3(256), 0, c->stream, X, pl, bl, vf, wf, bf, U0, U, pp, qp, gp)
+            if (rmax <= 8) {
+                if (mode == 1) LRF_LAUNCH_BCD(1, 8);
+                else if (mode == 2) LRF_LAUNCH_BCD(2, 8);
+                else LRF_LAUNCH_BCD(0, 8);
+            } else {
+                if (mode == 1) LRF_LAUNCH_BCD(1, 16);
+                else if (mode == 2) LRF_LAUNCH_BCD(2, 16);
+                else LRF_LAUNCH_BCD(0, 16);
+            }
+#undef LRF_LAUNCH_BCD
             LAUNCH_CHECK();
         }
         {
             Prof p(c, LRF_K_VUPDATE);
-            hipLaunchKernelGGL(k_vupdate, dim3(np), dim3(256), 0, c->stream, pl, (const float*)pp, (const float*)qp, vf, bf, V, gp,
-                               it == K - 1 ? 1 : 0);
+            if (rmax <= 8)
+                hipLaunchKernelGGL(k_vupdate<8>, dim3(np), dim3(256), 0, c->stream, pl, (const float*)pp, (const float*)qp, vf, bf,
+                                   V, gp, it == K - 1 ? 1 : 0);
+            else
+                hipLaunchKernelGGL(k_vupdate<16>, dim3(np), dim3(256), 0, c->stream, pl, (const float*)pp, (const float*)qp, vf,
+                                   bf, V, gp, it == K - 1 ? 1 : 0);
             LAUNCH_CHECK();
         }
     }
@@ -320,6 +334,7 @@ int lrf_ctx_create(int device, lrf_ctx** out)
         return set_err(LRF_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
     }
     c->stream = c->own_stream;
+    if (const char* e = getenv("LRF_DEBUG_INIT_SWEEPS")) c->init_sweeps = atoi(e); // developer timing aid only
     *out = c;
     return LRF_OK;
 }
@@ -567,5 +582,14 @@ int lrf_qmf_decode_rgb_u8(lrf_ctx* c, const int8_t* U, const int8_t* V, int64_t 
     LAUNCH_CHECK();
     return LRF_OK;
 }
+
+#ifdef LRF_STAMPS
+int lrf_debug_read_stamps(lrf_ctx* c, unsigned long long* out_host, int n)
+{
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * (size_t)n));
+    return LRF_OK;
+}
+#endif
 
 } // extern "C"

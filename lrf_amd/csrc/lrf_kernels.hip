@@ -21,6 +21,16 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 #define LRF_EPS 1e-16f
 
+// Diagnostic build only (-DLRF_STAMPS, never shipped): per-phase cycle sums of k_bcd, wave 0 of each workgroup.
+#ifdef LRF_STAMPS
+__device__ unsigned long long g_stamps[8 * 16384];
+#define STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime()
+#define STAMP_ADD(acc, a, b) acc += (b) - (a)
+#else
+#define STAMP(var)
+#define STAMP_ADD(acc, a, b)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // K1: uint8 RGB -> patch matrices (YCbCr, area down-sampled chroma, reflect pad, patchify)
 // ------------------------------------------------------------------------------------------------
@@ -157,10 +167,17 @@ __global__ __launch_bounds__(256) void k_init(const float* __restrict__ X, const
 #pragma unroll
     for (int i = 0; i < 10; i++) acc[i] = (f64x4){0.0, 0.0, 0.0, 0.0};
     const int nsteps = (M + 3) >> 2;
-    for (int s = wave; s < nsteps; s += 4) {
+    auto loadx = [&](int s) {
         int row = 4 * s + lq;
         f32x4 x = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (row < M) x = *reinterpret_cast<const f32x4*>(Xp + (long)row * 64 + 4 * li);
+        if (s < nsteps && row < M) x = *reinterpret_cast<const f32x4*>(Xp + (long)row * 64 + 4 * li);
+        return x;
+    };
+    f32x4 xa = loadx(wave), xb = loadx(wave + 4);
+    for (int s = wave; s < nsteps; s += 4) {
+        f32x4 x = xa;
+        xa = xb;
+        xb = loadx(s + 8); // two steps ahead
         double xd[4] = {(double)x[0], (double)x[1], (double)x[2], (double)x[3]};
         int n = 0;
 #pragma unroll
@@ -207,7 +224,7 @@ __global__ __launch_bounds__(256) void k_init(const float* __restrict__ X, const
                 pq[2 * tid + 1] = q;
                 double apq = G[p * 64 + q], app = G[p * 64 + p], aqq = G[q * 64 + q];
                 double c = 1.0, s = 0.0;
-                if (apq * apq > 1.2325951644078309e-32 * fabs(app * aqq)) {
+                if (apq * apq > 8.271806125530277e-25 * fabs(app * aqq)) { // |apq| > 2^-40 sqrt(|app aqq|)
                     double tau = (aqq - app) / (2.0 * apq);
                     double tt = 1.0 / (fabs(tau) + sqrt(1.0 + tau * tau));
                     if (tau < 0.0) tt = -tt;
@@ -219,38 +236,42 @@ __global__ __launch_bounds__(256) void k_init(const float* __restrict__ X, const
                 cs[2 * tid + 1] = s;
             }
             __syncthreads();
-            { // row phase: thread = (column k, group of 8 pairs)
-                int k = tid & 63, grp = tid >> 6;
+            { // fused phase.  Block (i, j) = rows (p_i, q_i) x columns (p_j, q_j) of G needs only rotations i
+              // and j: row phase then column phase in registers, same per-element arithmetic as two LDS passes.
+              // lanes <-> column pair j (distinct columns: at most 2-way bank conflicts), 4 row pairs per thread.
+                const int j = tid & 31;
+                const double cj = cs[2 * j], sj = cs[2 * j + 1];
+                const int pj = pq[2 * j], qj = pq[2 * j + 1];
 #pragma unroll
-                for (int ii = 0; ii < 8; ii++) {
-                    int i = grp * 8 + ii;
-                    double c = cs[2 * i], s = cs[2 * i + 1];
-                    if (s != 0.0) {
-                        int p = pq[2 * i], q = pq[2 * i + 1];
-                        double gp = G[p * 64 + k], gq = G[q * 64 + k];
-                        G[p * 64 + k] = c * gp - s * gq;
-                        G[q * 64 + k] = s * gp + c * gq;
+                for (int kk = 0; kk < 4; kk++) {
+                    const int i = (tid >> 5) + 8 * kk;
+                    const double ci = cs[2 * i], si = cs[2 * i + 1];
+                    const int pi = pq[2 * i], qi = pq[2 * i + 1];
+                    if (si != 0.0 || sj != 0.0) {
+                        double g00 = G[pi * 64 + pj], g01 = G[pi * 64 + qj], g10 = G[qi * 64 + pj], g11 = G[qi * 64 + qj];
+                        if (si != 0.0) { // A <- J^T A on rows (p_i, q_i)
+                            double t0 = ci * g00 - si * g10, t1 = si * g00 + ci * g10;
+                            g00 = t0; g10 = t1;
+                            t0 = ci * g01 - si * g11; t1 = si * g01 + ci * g11;
+                            g01 = t0; g11 = t1;
+                        }
+                        if (sj != 0.0) { // A <- A J on columns (p_j, q_j)
+                            double t0 = cj * g00 - sj * g01, t1 = sj * g00 + cj * g01;
+                            g00 = t0; g01 = t1;
+                            t0 = cj * g10 - sj * g11; t1 = sj * g10 + cj * g11;
+                            g10 = t0; g11 = t1;
+                            if (i == j) { g01 = 0.0; g10 = 0.0; } // (p,q), (q,p) annihilated
+                        }
+                        G[pi * 64 + pj] = g00; G[pi * 64 + qj] = g01; G[qi * 64 + pj] = g10; G[qi * 64 + qj] = g11;
                     }
-                }
-            }
-            __syncthreads();
-            { // column phase on G and E: thread = (pair i, 8 rows)
-                int i = tid & 31;
-                double c = cs[2 * i], s = cs[2 * i + 1];
-                if (s != 0.0) {
-                    int p = pq[2 * i], q = pq[2 * i + 1];
+                    if (sj != 0.0) { // E <- E J : rows 2i, 2i+1
 #pragma unroll
-                    for (int kk = 0; kk < 8; kk++) {
-                        int k = (tid >> 5) + 8 * kk;
-                        double gp = G[k * 64 + p], gq = G[k * 64 + q];
-                        double np_ = c * gp - s * gq, nq_ = s * gp + c * gq;
-                        if (k == p) nq_ = 0.0; // (p,q) annihilated
-                        if (k == q) np_ = 0.0; // (q,p)
-                        G[k * 64 + p] = np_;
-                        G[k * 64 + q] = nq_;
-                        double ep = E[k * 64 + p], eq = E[k * 64 + q];
-                        E[k * 64 + p] = c * ep - s * eq;
-                        E[k * 64 + q] = s * ep + c * eq;
+                        for (int rr = 0; rr < 2; rr++) {
+                            const int k = 2 * i + rr;
+                            double ep = E[k * 64 + pj], eq = E[k * 64 + qj];
+                            E[k * 64 + pj] = cj * ep - sj * eq;
+                            E[k * 64 + qj] = sj * ep + cj * eq;
+                        }
                     }
                 }
             }
@@ -305,7 +326,7 @@ __global__ __launch_bounds__(256) void k_init(const float* __restrict__ X, const
 
 // ------------------------------------------------------------------------------------------------
 // Gauss-Seidel over the R columns of one row (qmf.py:108-119).  a[] = (x @ v) row, u[] = current
-// row of the factor being updated (in/out).  bt: the per-matrix table {b[RP][RP], den[RP], rden[RP]}
+// row of the factor being updated (in/out).  gt: the per-matrix table of b = v.mT @ v (layout below)
 // with b = v.mT @ v, den[r] = (b[r][r] + 0) + eps, rden = 1/den (uniform across lanes: scalar loads
 // when it lives in global memory).  `native` selects the ATen small-product order for `uu @ bb`.
 //
@@ -313,9 +334,13 @@ __global__ __launch_bounds__(256) void k_init(const float* __restrict__ X, const
 // quotient, so unless q~ sits within `1/2 - fthr` of a rounding tie its nearest integer is the same;
 // only then (or never, beyond the clamp range) is the IEEE division evaluated.  Results are identical.
 // ------------------------------------------------------------------------------------------------
-#define LRF_BT_DEN (LRF_RP * LRF_RP)
-#define LRF_BT_RDEN (LRF_RP * LRF_RP + LRF_RP)
-#define LRF_BT_STRIDE (LRF_RP * LRF_RP + 2 * LRF_RP)
+// Table layout ("gt"), LRF_GT_LD floats per column r, so that one column's operands are contiguous:
+//   gt[r*LD + n], n < R-1 : b[j_n][r] for the j != r in increasing order (the `bb` vector of qmf.py:114)
+//   gt[r*LD + 16] = 1/den[r],  gt[r*LD + 17] = den[r] = (b[r][r] + 0) + eps
+#define LRF_GT_LD 20
+#define LRF_GT_RDEN 16
+#define LRF_GT_DEN 17
+#define LRF_GT_STRIDE (LRF_RP * LRF_GT_LD)
 
 struct GsParams {
     float lo, hi;      // clamp
@@ -323,84 +348,118 @@ struct GsParams {
     float fthr;        // |q~ - rint(q~)| <= fthr: rint(q~) == rint(fl(num/den))
 };
 
-template <int R>
-__device__ __forceinline__ void gs_row(const float* a, float* u, const float* __restrict__ bt, bool native,
-                                       const GsParams gp)
+// term2 = uu . bb in the reference's order (qmf.py:115): ATen native chain or the MKL single-column tree
+template <int K, bool NATIVE>
+__device__ __forceinline__ float gs_term2(const float* uu, const float* bb)
 {
+    if (K == 0) return 0.f;
+    if (NATIVE) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            float p = uu[k] * bb[k];
+            acc = acc + p;
+        }
+        return acc;
+    }
+    if (K == 1) return uu[0] * bb[0];
+    float odd = fmaf(uu[1], bb[1], uu[0] * bb[0]); // oracle/lrf_oracle.c dot_mkl_n1
+    constexpr int last_odd = ((K - 1) & 1) ? K - 1 : K - 2;
+#pragma unroll
+    for (int k = last_odd; k >= 3; k -= 2) odd = odd + uu[k] * bb[k];
+    if (K < 3) return odd;
+    float even = uu[2] * bb[2];
+#pragma unroll
+    for (int k = 4; k < K; k += 2) even = even + uu[k] * bb[k];
+    return odd + even;
+}
+
+// One row, all R columns.  EXACT = false: branch-free speculative solve with q~ = num * (1/den); returns true
+// when some column sat too close to a rounding tie (or anything else made the shortcut unsafe) — the caller
+// then re-solves the row with EXACT = true (IEEE division), which is what the reference computes.
+template <int R, bool NATIVE, bool EXACT>
+__device__ __forceinline__ bool gs_row(const float* a, float* u, const float* __restrict__ gt, const GsParams gp)
+{
+    constexpr int K = R - 1;
+    // Preload the whole table in straight-line code: one batch of (scalar or LDS) loads and a single wait.
+    float bbv[R][K > 0 ? K : 1], rden[R], den[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        float uu[R > 1 ? R - 1 : 1], bb[R > 1 ? R - 1 : 1];
+#pragma unroll
+        for (int k = 0; k < K; k++) bbv[r][k] = gt[r * LRF_GT_LD + k];
+        rden[r] = gt[r * LRF_GT_LD + LRF_GT_RDEN];
+        den[r] = gt[r * LRF_GT_LD + LRF_GT_DEN];
+    }
+    bool unsafe = false;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        float uu[K > 0 ? K : 1];
         int n = 0;
 #pragma unroll
         for (int j = 0; j < R; j++)
-            if (j != r) {
-                uu[n] = u[j];
-                bb[n] = bt[j * LRF_RP + r];
-                n++;
-            }
-        constexpr int K = R - 1;
-        float term2 = 0.f;
-        if (K > 0) {
-            if (native) {
-                float acc = 0.f;
-#pragma unroll
-                for (int k = 0; k < K; k++) {
-                    float p = uu[k] * bb[k];
-                    acc = acc + p;
-                }
-                term2 = acc;
-            } else if (K == 1) {
-                term2 = uu[0] * bb[0];
-            } else { // MKL single-column order (oracle/lrf_oracle.c dot_mkl_n1)
-                float odd = fmaf(uu[1], bb[1], uu[0] * bb[0]);
-                constexpr int last_odd = ((K - 1) & 1) ? K - 1 : K - 2;
-#pragma unroll
-                for (int k = last_odd; k >= 3; k -= 2) odd = odd + uu[k] * bb[k];
-                if (K < 3) term2 = odd;
-                else {
-                    float even = uu[2] * bb[2];
-#pragma unroll
-                    for (int k = 4; k < K; k += 2) even = even + uu[k] * bb[k];
-                    term2 = odd + even;
-                }
-            }
+            if (j != r) uu[n++] = u[j];
+        float num = (a[r] - gs_term2<K, NATIVE>(uu, bbv[r])) + LRF_EPS;
+        float val;
+        if (EXACT) {
+            val = rintf(num / den[r]);
+        } else {
+            float q = num * rden[r];
+            float nq = rintf(q);
+            bool inside = fabsf(q) < gp.flimit;          // false for NaN: falls to val = q, clamp handles it
+            unsafe |= inside && !(fabsf(q - nq) <= gp.fthr);
+            val = inside ? nq : q;
         }
-        float num = (a[r] - term2) + LRF_EPS;
-        float q = num * bt[LRF_BT_RDEN + r];
-        float nq = rintf(q);
-        float val = nq;
-        if (fabsf(q) >= gp.flimit) val = q;
-        else if (fabsf(q - nq) > gp.fthr) val = rintf(num / bt[LRF_BT_DEN + r]);
         u[r] = fminf(fmaxf(val, gp.lo), gp.hi);
     }
+    return unsafe;
 }
 
-template <int R>
-__device__ __forceinline__ void gs_row_lds(const float* a_row, float* u_row, const float* __restrict__ bt, bool native,
-                                           const GsParams gp)
+// One row through LDS: a_row[0..R) in, u_row[0..LRF_RP) out (zero padded).  The old row comes from int8 bytes
+// (uold_row, packed R per row) when FROM_I8, else from u_row itself.  All loops have compile-time bounds so the
+// LDS reads/writes are issued as batches (a runtime-R loop costs one exposed LDS latency per element).
+template <int R, bool FROM_I8>
+__device__ __forceinline__ void gs_row_lds(const float* a_row, float* u_row, const int8_t* uold_row,
+                                           const float* __restrict__ gt, bool native, const GsParams gp)
 {
-    float a[R], u[R];
+    float a[R], u0[R], u[R];
 #pragma unroll
-    for (int r = 0; r < R; r++) { a[r] = a_row[r]; u[r] = u_row[r]; }
-    gs_row<R>(a, u, bt, native, gp);
+    for (int r = 0; r < R; r++) {
+        a[r] = a_row[r];
+        u0[r] = FROM_I8 ? (float)uold_row[r] : u_row[r];
+        u[r] = u0[r];
+    }
+    bool unsafe = native ? gs_row<R, true, false>(a, u, gt, gp) : gs_row<R, false, false>(a, u, gt, gp);
+    if (__any(unsafe)) { // rare (about one wave in a few hundred): redo with the reference's IEEE division
 #pragma unroll
-    for (int r = 0; r < R; r++) u_row[r] = u[r];
+        for (int r = 0; r < R; r++) u[r] = u0[r];
+        if (native) gs_row<R, true, true>(a, u, gt, gp);
+        else gs_row<R, false, true>(a, u, gt, gp);
+    }
+    float o[LRF_RP];
+#pragma unroll
+    for (int r = 0; r < LRF_RP; r++) o[r] = (r < R) ? u[r < R ? r : 0] : 0.f;
+#pragma unroll
+    for (int r = 0; r < LRF_RP; r += 4) *reinterpret_cast<f32x4*>(u_row + r) = (f32x4){o[r], o[r + 1], o[r + 2], o[r + 3]};
 }
 
-__device__ __forceinline__ void gs_dispatch(int R, const float* a_row, float* u_row, const float* __restrict__ bt,
-                                            bool native, const GsParams gp)
+template <int RMAX, bool FROM_I8>
+__device__ __forceinline__ void gs_dispatch(int R, const float* a_row, float* u_row, const int8_t* uold_rows, int lane,
+                                            const float* __restrict__ gt, bool native, const GsParams gp)
 {
     switch (R) {
-#define LRF_CASE(r) case r: gs_row_lds<r>(a_row, u_row, bt, native, gp); break;
+#define LRF_CASE(r)                                                                                              \
+    case r:                                                                                                      \
+        if (r <= RMAX) gs_row_lds<(r <= RMAX ? r : 1), FROM_I8>(a_row, u_row, uold_rows + lane * r, gt, native, gp); \
+        break;
         LRF_CASE(1) LRF_CASE(2) LRF_CASE(3) LRF_CASE(4) LRF_CASE(5) LRF_CASE(6) LRF_CASE(7) LRF_CASE(8)
         LRF_CASE(9) LRF_CASE(10) LRF_CASE(11) LRF_CASE(12) LRF_CASE(13) LRF_CASE(14) LRF_CASE(15) LRF_CASE(16)
 #undef LRF_CASE
     }
 }
 
-// b = v.mT @ v (R x R) with den / rden, from a [depth][LRF_RP] factor: thread (j, r).
+// gt table of b = v.mT @ v (R x R) from a [depth][LRF_RP] factor: thread (j, r).
 // ATen uses its native kernel when depth*R*R < 400, MKL (k-ordered fma chain) otherwise.
-__device__ __forceinline__ void make_btable(const float* Vp, int depth, int R, float* bt, int tid, int nthreads)
+__device__ __forceinline__ void make_gtable(const float* Vp, int depth, int R, float* gt, int tid, int nthreads)
 {
     bool native = (long)depth * R * R < 400;
     for (int i = tid; i < R * R; i += nthreads) {
@@ -414,11 +473,12 @@ __device__ __forceinline__ void make_btable(const float* Vp, int depth, int R, f
         } else {
             for (int k = 0; k < depth; k++) acc = fmaf(Vp[k * LRF_RP + j], Vp[k * LRF_RP + r], acc);
         }
-        bt[j * LRF_RP + r] = acc;
         if (j == r) {
             float den = (acc + 0.f) + LRF_EPS;
-            bt[LRF_BT_DEN + r] = den;
-            bt[LRF_BT_RDEN + r] = 1.0f / den;
+            gt[r * LRF_GT_LD + LRF_GT_DEN] = den;
+            gt[r * LRF_GT_LD + LRF_GT_RDEN] = 1.0f / den;
+        } else {
+            gt[r * LRF_GT_LD + (j < r ? j : j - 1)] = acc;
         }
     }
 }
@@ -430,7 +490,7 @@ __global__ __launch_bounds__(256) void k_bprep(const PlaneDesc* __restrict__ pla
     __shared__ float v_s[64 * LRF_RP];
     for (int i = threadIdx.x; i < 64 * LRF_RP; i += 256) v_s[i] = Vf[(long)blockIdx.x * 64 * LRF_RP + i];
     __syncthreads();
-    make_btable(v_s, 64, planes[blockIdx.x].R, Bf + (long)blockIdx.x * LRF_BT_STRIDE, threadIdx.x, 256);
+    make_gtable(v_s, 64, planes[blockIdx.x].R, Bf + (long)blockIdx.x * LRF_GT_STRIDE, threadIdx.x, 256);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -443,7 +503,7 @@ __global__ __launch_bounds__(256) void k_bprep(const PlaneDesc* __restrict__ pla
 // ------------------------------------------------------------------------------------------------
 #define XS_LD 66 // LDS row stride (dwords) of the X sub-tile: conflict-free B-operand reads
 
-template <int MODE>
+template <int MODE, int RMAX>
 __global__ __launch_bounds__(256) void k_bcd(const float* __restrict__ X, const PlaneDesc* __restrict__ planes,
                                              const BlockDesc* __restrict__ blocks, const float* __restrict__ Vf,
                                              const float* __restrict__ Wf, const float* __restrict__ Bf,
@@ -458,11 +518,12 @@ __global__ __launch_bounds__(256) void k_bcd(const float* __restrict__ X, const 
     const BlockDesc bd = blocks[blockIdx.x];
     const PlaneDesc pd = planes[bd.plane];
     const int R = pd.R;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // provably wave-uniform (scalar branches below)
     const int li = lane & 15, lq = lane >> 4;
     const float* Xp = X + pd.x_off + (long)bd.row0 * 64;
     const float* Vp = Vf + (long)bd.plane * 64 * LRF_RP;
-    const float* bt = Bf + (long)bd.plane * LRF_BT_STRIDE;
+    const float* gt = Bf + (long)bd.plane * LRF_GT_STRIDE;
     int8_t* Ub = U + pd.u_off + (long)bd.row0 * R;
     int nrows = pd.M - bd.row0;
     if (nrows > LRF_KC) nrows = LRF_KC;
@@ -515,13 +576,20 @@ __global__ __launch_bounds__(256) void k_bcd(const float* __restrict__ X, const 
     };
 
     f32x4 accP = (f32x4){0.f, 0.f, 0.f, 0.f}, accQ = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifdef LRF_STAMPS
+    unsigned long long c_stage = 0, c_umfma = 0, c_gs = 0, c_pq = 0, c_g1 = 0, c_g2 = 0, c_g3 = 0;
+#endif
+    STAMP(t_begin);
     issue(0);
     for (int t = 0; t < nsub; t++) {
         const int r0 = t * 64;
+        STAMP(t0);
         __syncthreads(); // previous sub-tile fully consumed
         commit();
         if (t + 1 < nsub) issue(t + 1);
         __syncthreads();
+        STAMP(t1);
+        STAMP_ADD(c_stage, t0, t1);
         // ---- a^T tile for rows 16*wave .. +15 : 16 chained MFMAs over k
         {
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, accw = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -537,24 +605,34 @@ __global__ __launch_bounds__(256) void k_bcd(const float* __restrict__ X, const 
             if (MODE == 1) *reinterpret_cast<f32x4*>(&u_s[(16 * wave + li) * LRF_RP + 4 * lq]) = accw;
         }
         __syncthreads();
+        STAMP(t2);
+        STAMP_ADD(c_umfma, t1, t2);
         // ---- Gauss-Seidel: one wave, lane = row (rotating wave so the VALU work spreads over SIMDs)
         if (wave == (t & 3)) {
+            STAMP(g0);
             int row = r0 + lane;
             float* ur = &u_s[lane * LRF_RP];
             if (row < nrows) {
-                if (MODE == 0) {
-                    for (int r = 0; r < R; r++) ur[r] = (float)uold_s[lane * R + r];
-                } else if (MODE == 2) {
+                if (MODE == 2) {
                     const float* up = U0 + pd.u0_off + ((long)bd.row0 + row) * R;
                     for (int r = 0; r < R; r++) ur[r] = up[r];
                 }
-                gs_dispatch(R, &a_s[lane * LRF_RP], ur, bt, pd.native_t2_u != 0, gp);
-                for (int r = R; r < LRF_RP; r++) ur[r] = 0.f;
+                STAMP(g1);
+                gs_dispatch<RMAX, MODE == 0>(R, &a_s[lane * LRF_RP], ur, uold_s, lane, gt, pd.native_t2_u != 0, gp);
+                STAMP(g2);
+#ifdef LRF_STAMPS
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                STAMP(g3);
+                if (wave == 0) { c_g1 += g1 - g0; c_g2 += g2 - g1; c_g3 += g3 - g2; }
+#endif
             } else {
-                for (int r = 0; r < LRF_RP; r++) ur[r] = 0.f;
+#pragma unroll
+                for (int r = 0; r < LRF_RP; r += 4) *reinterpret_cast<f32x4*>(ur + r) = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
         __syncthreads();
+        STAMP(t3);
+        STAMP_ADD(c_gs, t2, t3);
         // ---- int8 U out (coalesced bytes), partial a' = X^T U for columns 16*wave..+15, partial b' = U^T U
         {
             int lim = (nrows - r0 < 64 ? nrows - r0 : 64) * R;
@@ -565,12 +643,20 @@ __global__ __launch_bounds__(256) void k_bcd(const float* __restrict__ X, const 
             const float* xc = &Xs[lq * XS_LD + 16 * wave + li];
             const float* uc = &u_s[lq * LRF_RP + li];
 #pragma unroll
-            for (int s = 0; s < 16; s++) {
-                float ub = uc[4 * s * LRF_RP];
-                accP = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[4 * s * XS_LD], ub, accP, 0, 0, 0);
-                if ((s & 3) == wave) accQ = __builtin_amdgcn_mfma_f32_16x16x4f32(ub, ub, accQ, 0, 0, 0);
+            for (int s = 0; s < 16; s++)
+                accP = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[4 * s * XS_LD], uc[4 * s * LRF_RP], accP, 0, 0, 0);
+            const float* uq = uc + 16 * wave * LRF_RP; // wave w: row steps 4w .. 4w+3 of the sub-tile
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                float ub = uq[4 * s * LRF_RP];
+                accQ = __builtin_amdgcn_mfma_f32_16x16x4f32(ub, ub, accQ, 0, 0, 0);
             }
         }
+#ifdef LRF_STAMPS
+        asm volatile("" ::"v"(accP[0]), "v"(accQ[0]));
+        STAMP(t4);
+        STAMP_ADD(c_pq, t3, t4);
+#endif
     }
     // a' partial: D[i = 4*lq + reg (column 16*wave + i)][j = li (r)]
     const long slot = (long)pd.blk0 + bd.blk;
@@ -583,6 +669,13 @@ __global__ __launch_bounds__(256) void k_bcd(const float* __restrict__ X, const 
     for (int reg = 0; reg < 4; reg++) a_s[wave * 256 + (4 * lq + reg) * LRF_RP + li] = accQ[reg];
     __syncthreads();
     Qpart[slot * LRF_RP * LRF_RP + tid] = ((a_s[tid] + a_s[256 + tid]) + a_s[512 + tid]) + a_s[768 + tid];
+#ifdef LRF_STAMPS
+    if (tid == 0 && blockIdx.x < 16384) {
+        STAMP(t_end);
+        unsigned long long* o = g_stamps + 8 * blockIdx.x;
+        o[0] = t_end - t_begin; o[1] = c_stage; o[2] = c_umfma; o[3] = c_gs; o[4] = c_pq; o[5] = c_g1; o[6] = c_g2; o[7] = c_g3;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -590,12 +683,13 @@ __global__ __launch_bounds__(256) void k_bcd(const float* __restrict__ X, const 
 // b' = U^T U (sum of exact integer partials), Gauss-Seidel over the R columns for the 64 rows of V,
 // then the b table (v.mT @ v) of the new V for the next U update.
 // ------------------------------------------------------------------------------------------------
+template <int RMAX>
 __global__ __launch_bounds__(256) void k_vupdate(const PlaneDesc* __restrict__ planes, const float* __restrict__ Ppart,
                                                  const float* __restrict__ Qpart, float* __restrict__ Vf,
                                                  float* __restrict__ Bf, int8_t* __restrict__ V8, GsParams gp,
                                                  int write_i8)
 {
-    __shared__ __attribute__((aligned(16))) float bt_s[LRF_BT_STRIDE];
+    __shared__ __attribute__((aligned(16))) float gt_s[LRF_GT_STRIDE];
     __shared__ __attribute__((aligned(16))) float a_s[64 * LRF_RP];
     __shared__ __attribute__((aligned(16))) float v_s[64 * LRF_RP];
 
@@ -614,17 +708,20 @@ __global__ __launch_bounds__(256) void k_vupdate(const PlaneDesc* __restrict__ p
         float q = Qp[0];
         for (int b = 1; b < pd.nblk; b++) q = q + Qp[(long)b * LRF_RP * LRF_RP];
         int j = tid >> 4, r = tid & 15;
-        bt_s[tid] = q;
-        if (j == r) {
-            float den = (q + 0.f) + LRF_EPS;
-            bt_s[LRF_BT_DEN + r] = den;
-            bt_s[LRF_BT_RDEN + r] = 1.0f / den;
+        if (j < R && r < R) {
+            if (j == r) {
+                float den = (q + 0.f) + LRF_EPS;
+                gt_s[r * LRF_GT_LD + LRF_GT_DEN] = den;
+                gt_s[r * LRF_GT_LD + LRF_GT_RDEN] = 1.0f / den;
+            } else {
+                gt_s[r * LRF_GT_LD + (j < r ? j : j - 1)] = q;
+            }
         }
     }
     __syncthreads();
     if (tid < 64) {
         bool native = (long)(R - 1) * 64 < 400;
-        gs_dispatch(R, &a_s[tid * LRF_RP], &v_s[tid * LRF_RP], bt_s, native, gp);
+        gs_dispatch<RMAX, false>(R, &a_s[tid * LRF_RP], &v_s[tid * LRF_RP], nullptr, 0, gt_s, native, gp);
         float* Vp = Vf + (long)blockIdx.x * 64 * LRF_RP + tid * LRF_RP;
         for (int r = 0; r < R; r++) Vp[r] = v_s[tid * LRF_RP + r];
         if (write_i8) {
@@ -633,7 +730,7 @@ __global__ __launch_bounds__(256) void k_vupdate(const PlaneDesc* __restrict__ p
         }
     }
     __syncthreads();
-    if (!write_i8) make_btable(v_s, 64, R, Bf + (long)blockIdx.x * LRF_BT_STRIDE, tid, 256);
+    if (!write_i8) make_gtable(v_s, 64, R, Bf + (long)blockIdx.x * LRF_GT_STRIDE, tid, 256);
 }
 
 // loads caller-supplied fp32 V0 [B][64][R] into the padded Vf table (lrf_qmf_bcd_f32)

@@ -288,8 +288,8 @@ int lrf_oracle_jacobi_f64(double* A, int n, double* E, int max_sweeps)
                 pq[2 * i] = p; pq[2 * i + 1] = q;
                 double apq = A[p * n + q], app = A[p * n + p], aqq = A[q * n + q];
                 double c = 1.0, s = 0.0;
-                /* skip when apq^2 <= 2^-106 |app aqq| (already negligible) */
-                if (apq * apq > 1.2325951644078309e-32 * fabs(app * aqq)) {
+                /* skip when |apq| <= 2^-40 sqrt(|app aqq|): negligible for fp32 factors */
+                if (apq * apq > 8.271806125530277e-25 * fabs(app * aqq)) {
                     double tau = (aqq - app) / (2.0 * apq);
                     double tt = 1.0 / (fabs(tau) + sqrt(1.0 + tau * tau));
                     if (tau < 0.0) tt = -tt;
