@@ -514,6 +514,8 @@ __global__ __launch_bounds__(256) void k_bcd(const float* __restrict__ X, const 
     __shared__ __attribute__((aligned(16))) float a_s[64 * LRF_RP];
     __shared__ __attribute__((aligned(16))) float u_s[64 * LRF_RP];
     __shared__ __attribute__((aligned(16))) int8_t uold_s[64 * LRF_RP];
+    __shared__ __attribute__((aligned(16))) float va_s[16 * 64];
+    __shared__ __attribute__((aligned(16))) float wa_s[MODE == 1 ? 16 * 64 : 4];
 
     const BlockDesc bd = blocks[blockIdx.x];
     const PlaneDesc pd = planes[bd.plane];
@@ -530,12 +532,13 @@ __global__ __launch_bounds__(256) void k_bcd(const float* __restrict__ X, const 
     const int nsub = (nrows + 63) >> 6;
     const int invR = (65536 + R - 1) / R; // (i * invR) >> 16 == i / R for i < 64 * R
 
-    // A operand of a^T = V^T X^T : A[i = r][k]; lane holds V[4s + lq][li]
-    float aV[16], aW[16];
+    // A operand of a^T = V^T X^T : A[i = r][k]; lane needs V[4s + lq][li] at k-step s.  Kept in LDS in
+    // [step][lane] order (conflict-free, one ds_read per MFMA) rather than in 16 VGPRs per wave.
 #pragma unroll
-    for (int s = 0; s < 16; s++) {
-        aV[s] = Vp[(4 * s + lq) * LRF_RP + li];
-        if (MODE == 1) aW[s] = Wf[(long)bd.plane * 64 * LRF_RP + (4 * s + lq) * LRF_RP + li];
+    for (int i = 0; i < 4; i++) {
+        int s_ = 4 * wave + i;
+        va_s[s_ * 64 + lane] = Vp[(4 * s_ + lq) * LRF_RP + li];
+        if (MODE == 1) wa_s[s_ * 64 + lane] = Wf[(long)bd.plane * 64 * LRF_RP + (4 * s_ + lq) * LRF_RP + li];
     }
 
     // prefetch registers: the X sub-tile (4 x float4 per thread) and the old int8 U rows (<= 4 bytes per thread)
@@ -597,8 +600,8 @@ __global__ __launch_bounds__(256) void k_bcd(const float* __restrict__ X, const 
 #pragma unroll
             for (int s = 0; s < 16; s++) {
                 float bx = xr[4 * s];
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aV[s], bx, acc, 0, 0, 0);
-                if (MODE == 1) accw = __builtin_amdgcn_mfma_f32_16x16x4f32(aW[s], bx, accw, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(va_s[s * 64 + lane], bx, acc, 0, 0, 0);
+                if (MODE == 1) accw = __builtin_amdgcn_mfma_f32_16x16x4f32(wa_s[s * 64 + lane], bx, accw, 0, 0, 0);
             }
             // D[i = 4*lq + reg (r)][j = li (row)]
             *reinterpret_cast<f32x4*>(&a_s[(16 * wave + li) * LRF_RP + 4 * lq]) = acc;
