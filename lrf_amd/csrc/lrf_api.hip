@@ -50,7 +50,7 @@ struct lrf_ctx {
     std::vector<hipEvent_t> ev_pool;
     double acc_ms[LRF_K_COUNT] = {0};
     long acc_n[LRF_K_COUNT] = {0};
-    int init_sweeps = 30;
+    int init_sweeps = 0; // developer aid: stop k_init after stage n (0 = run everything)
 };
 
 static int ensure(lrf_ctx* c, DevBuf& b, size_t bytes)
@@ -221,7 +221,7 @@ static int upload_tables(lrf_ctx* c, const Tables& t)
 
 #define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
 
-static const size_t INIT_LDS = 2 * 64 * 64 * sizeof(double) + 64 * sizeof(double) + 64 * sizeof(int) * 2 + 16;
+static const size_t INIT_LDS = sizeof(InitLds);
 
 static int run_init(lrf_ctx* c, const float* X, int nplanes, const int8_t* sign_dev)
 {

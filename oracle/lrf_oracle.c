@@ -26,9 +26,10 @@
  * X^T U reduction, so "the reference" is pinned at one thread.
  *
  * The SVD initialisation (lrf/factorization/qmf.py:42-71 uses LAPACK sgesdd) is NOT a
- * restatement of LAPACK: it is this project's own algorithm (fp64 Gram matrix, cyclic
- * Jacobi eigen-solve in a fixed parallel order, deterministic sign rule), defined here
- * and mirrored operation-for-operation by the HIP kernels.  See DESIGN.md.
+ * restatement of LAPACK: it is this project's own algorithm (fp64 Gram matrix, Householder
+ * tridiagonalisation, multisection + twisted factorisation for the top-R eigen-pairs,
+ * deterministic sign rule), defined here and mirrored operation-for-operation by the HIP
+ * kernels.  See DESIGN.md.  (lrf_oracle_jacobi_f64 is kept as an independent cross-check.)
  */
 #include <math.h>
 #include <stdint.h>
@@ -338,51 +339,241 @@ int lrf_oracle_jacobi_f64(double* A, int n, double* E, int max_sweeps)
     return sweep;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * Top-R eigen-pairs of the 64 x 64 Gram matrix: Householder tridiagonalisation, eigenvalues by
+ * 64-way multisection on Sturm counts, eigenvectors by twisted factorisation + Gram-Schmidt, then
+ * back-transformation.  Every reduction has a fixed shape so that the GPU kernel (one workgroup per
+ * matrix) reproduces it bit for bit:
+ *   tree64(s)   : for off = 32,16,...,1: s[i] += s[i+off] (i < off); result s[0]   (wave butterfly)
+ *   matvec      : four partial k-ordered fma chains over column groups j>>4, combined ((c0+c1)+c2)+c3
+ * ---------------------------------------------------------------------------------------------- */
+#define EN 64
+
+static double tree64(double* s)
+{
+    for (int off = 32; off >= 1; off >>= 1)
+        for (int i = 0; i < off; i++) s[i] = s[i] + s[i + off];
+    return s[0];
+}
+
+/* A (EN x EN, symmetric, destroyed) -> d[EN], e[EN-1]; reflectors H_k = I - tau_k v_k v_k^T with
+ * v_k stored in Vh[k*EN + i] (zero for i <= k). */
+static void tridiagonalize(double* A, double* d, double* e, double* Vh, double* tau)
+{
+    double s[EN], v[EN], p[EN], w[EN];
+    memset(Vh, 0, sizeof(double) * EN * EN);
+    for (int k = 0; k < EN - 2; k++) {
+        for (int i = 0; i < EN; i++) { double x = (i > k) ? A[i * EN + k] : 0.0; s[i] = x * x; }
+        double sigma = tree64(s);
+        tau[k] = 0.0;
+        e[k] = 0.0;
+        if (sigma == 0.0) continue;
+        double x0 = A[(k + 1) * EN + k];
+        double nrm = sqrt(sigma);
+        double alpha = (x0 >= 0.0) ? -nrm : nrm;
+        for (int i = 0; i < EN; i++) v[i] = (i > k + 1) ? A[i * EN + k] : 0.0;
+        v[k + 1] = x0 - alpha;
+        for (int i = 0; i < EN; i++) s[i] = v[i] * v[i];
+        double vn = tree64(s);
+        double t = 2.0 / vn;
+        for (int i = 0; i < EN; i++) {
+            double c[4] = {0.0, 0.0, 0.0, 0.0};
+            if (i > k)
+                for (int j = k + 1; j < EN; j++) c[j >> 4] = fma(A[i * EN + j], v[j], c[j >> 4]);
+            p[i] = t * (((c[0] + c[1]) + c[2]) + c[3]);
+        }
+        for (int i = 0; i < EN; i++) s[i] = p[i] * v[i];
+        double K = (0.5 * t) * tree64(s);
+        for (int i = 0; i < EN; i++) w[i] = fma(-K, v[i], p[i]);
+        for (int i = k + 1; i < EN; i++)
+            for (int j = k + 1; j <= i; j++) { /* canonical (i >= j) formula, mirrored: exactly symmetric */
+                double val = fma(-w[i], v[j], fma(-v[i], w[j], A[i * EN + j]));
+                A[i * EN + j] = val;
+                A[j * EN + i] = val;
+            }
+        e[k] = alpha;
+        tau[k] = t;
+        for (int i = 0; i < EN; i++) Vh[k * EN + i] = v[i];
+    }
+    for (int i = 0; i < EN; i++) d[i] = A[i * EN + i];
+    e[EN - 2] = A[(EN - 1) * EN + (EN - 2)];
+}
+
+/* number of eigenvalues of T smaller than x (Sturm count with the usual pivot guard) */
+static int sturm_count(const double* d, const double* e2, double x, double pivmin)
+{
+    double q = d[0] - x;
+    int cnt = q < 0.0;
+    for (int i = 1; i < EN; i++) {
+        if (fabs(q) < pivmin) q = -pivmin;
+        q = (d[i] - x) - e2[i - 1] / q;
+        cnt += q < 0.0;
+    }
+    return cnt;
+}
+
+/* the R largest eigenvalues of T, descending: 10 passes of 64-way multisection from the Gershgorin hull */
+static void top_eigenvalues(const double* d, const double* e, int R, double* lam, double* pivmin_out)
+{
+    double e2[EN], lo = 0, hi = 0, e2max = 0.0;
+    for (int i = 0; i < EN - 1; i++) { e2[i] = e[i] * e[i]; if (e2[i] > e2max) e2max = e2[i]; }
+    for (int i = 0; i < EN; i++) {
+        double rad = (i > 0 ? fabs(e[i - 1]) : 0.0) + (i < EN - 1 ? fabs(e[i]) : 0.0);
+        double a = d[i] - rad, b = d[i] + rad;
+        if (i == 0 || a < lo) lo = a;
+        if (i == 0 || b > hi) hi = b;
+    }
+    double tn = fabs(lo) > fabs(hi) ? fabs(lo) : fabs(hi);
+    double pivmin = 2.2250738585072014e-300 * (e2max > 1.0 ? e2max : 1.0);
+    double slack = 2.0 * tn * 2.220446049250313e-16 * EN + 2.0 * pivmin;
+    lo -= slack;
+    hi += slack;
+    for (int r = 0; r < R; r++) {
+        int k = EN - 1 - r; /* eigenvalue with exactly k eigenvalues below it */
+        double a = lo, b = hi;
+        for (int pass = 0; pass < 10; pass++) {
+            double h = (b - a) / 65.0;
+            int j = EN;
+            double xs[EN];
+            for (int i = 0; i < EN; i++) {
+                xs[i] = a + h * (double)(i + 1);
+                if (j == EN && sturm_count(d, e2, xs[i], pivmin) > k) j = i;
+            }
+            double na = (j == 0) ? a : xs[j - 1], nb = (j == EN) ? b : xs[j];
+            a = na;
+            b = nb;
+        }
+        lam[r] = 0.5 * (a + b);
+    }
+    *pivmin_out = pivmin;
+}
+
+/* eigenvector of T for eigenvalue lam by twisted factorisation (not normalised) */
+static void twisted_vector(const double* d, const double* e, double lam, double pivmin, double* x)
+{
+    double Dp[EN], Dm[EN];
+    Dp[0] = d[0] - lam;
+    for (int i = 1; i < EN; i++) {
+        double q = Dp[i - 1];
+        if (fabs(q) < pivmin) q = -pivmin;
+        Dp[i] = (d[i] - lam) - (e[i - 1] * e[i - 1]) / q;
+    }
+    Dm[EN - 1] = d[EN - 1] - lam;
+    for (int i = EN - 2; i >= 0; i--) {
+        double q = Dm[i + 1];
+        if (fabs(q) < pivmin) q = -pivmin;
+        Dm[i] = (d[i] - lam) - (e[i] * e[i]) / q;
+    }
+    int k = 0;
+    double best = 0.0;
+    for (int i = 0; i < EN; i++) {
+        double g = fabs((Dp[i] + Dm[i]) - (d[i] - lam));
+        if (i == 0 || g < best) { best = g; k = i; }
+    }
+    x[k] = 1.0;
+    for (int i = k - 1; i >= 0; i--) {
+        double q = Dp[i];
+        if (fabs(q) < pivmin) q = -pivmin;
+        x[i] = -(e[i] / q) * x[i + 1];
+    }
+    for (int i = k; i < EN - 1; i++) {
+        double q = Dm[i + 1];
+        if (fabs(q) < pivmin) q = -pivmin;
+        x[i + 1] = -(e[i] / q) * x[i];
+    }
+}
+
+/* G (EN x EN symmetric, destroyed) -> lam[R] (descending) and orthonormal eigenvectors Ev[r*EN + j]. */
+int lrf_oracle_top_eig_f64(double* G, int R, double* lam, double* Ev)
+{
+    double d[EN], e[EN], tau[EN], s[EN], pivmin;
+    double* Vh = (double*)malloc(sizeof(double) * EN * EN);
+    double* Z = (double*)malloc(sizeof(double) * EN * R); /* vectors in tridiagonal coordinates */
+    tridiagonalize(G, d, e, Vh, tau);
+    top_eigenvalues(d, e, R, lam, &pivmin);
+    for (int r = 0; r < R; r++) {
+        double* x = Z + r * EN;
+        twisted_vector(d, e, lam[r], pivmin, x);
+        int use_twisted = 1, uidx = 0;
+        for (int i = 0; i < EN; i++) use_twisted &= isfinite(x[i]) != 0;
+        for (;;) {
+            if (use_twisted) { /* scale first: the Gram-Schmidt loss test below is relative */
+                for (int i = 0; i < EN; i++) s[i] = x[i] * x[i];
+                double n0 = sqrt(tree64(s));
+                for (int i = 0; i < EN; i++) x[i] = x[i] / n0;
+            } else { /* deterministic fallback: unit vectors in turn */
+                if (uidx >= EN) { free(Vh); free(Z); return -1; }
+                for (int i = 0; i < EN; i++) x[i] = (i == uidx) ? 1.0 : 0.0;
+                uidx++;
+            }
+            for (int pr = 0; pr < r; pr++) { /* modified Gram-Schmidt against the vectors already fixed */
+                const double* pv = Z + pr * EN;
+                for (int i = 0; i < EN; i++) s[i] = pv[i] * x[i];
+                double c = tree64(s);
+                for (int i = 0; i < EN; i++) x[i] = fma(-c, pv[i], x[i]);
+            }
+            for (int i = 0; i < EN; i++) s[i] = x[i] * x[i];
+            double n2 = tree64(s);
+            if (n2 > 1e-6 && n2 < 1e300) { /* kept (a repeated eigenvalue collapses to ~0 here; NaN fails both) */
+                double nr = sqrt(n2);
+                for (int i = 0; i < EN; i++) x[i] = x[i] / nr;
+                break;
+            }
+            use_twisted = 0;
+        }
+    }
+    for (int r = 0; r < R; r++) { /* back-transform: x <- H_0 H_1 ... H_{n-3} x */
+        double* x = Ev + r * EN;
+        memcpy(x, Z + r * EN, sizeof(double) * EN);
+        for (int k = EN - 3; k >= 0; k--) {
+            if (tau[k] == 0.0) continue;
+            const double* v = Vh + k * EN;
+            for (int i = 0; i < EN; i++) s[i] = v[i] * x[i];
+            double sc = tau[k] * tree64(s);
+            for (int i = 0; i < EN; i++) x[i] = fma(-sc, v[i], x[i]);
+        }
+    }
+    free(Vh);
+    free(Z);
+    return 0;
+}
+
 /* Top-R factors from the Gram eigen-pairs:
  *   sigma_r = sqrt(max(lambda_r,0)); s_r = sqrt(sigma_r)
  *   v0[:,r] = e_r * s_r                 (lrf/factorization/qmf.py:46,48  v = (sqrt(s) Vh)^T)
  *   w0[:,r] = e_r / s_r  (0 if s_r = 0) so that u0 = X w0 = U sqrt(s)   (qmf.py:46-47)
- * Eigenvalues are taken in descending order (ties: lower index first).  Column sign: sign[r] if
- * non-zero, else -1, is imposed on  sum_j (j+1) e_r[j]  (the reference's LAPACK sign is arbitrary;
- * component 0 comes out negative there, which -1 reproduces).  Columns r >= min(M,N) are zero
- * (qmf.py:50-52).  G is N x N (destroyed). */
+ * Column sign: sign[r] if non-zero, else -1, is imposed on  sum_j (j+1) e_r[j]  (the reference's
+ * LAPACK sign is arbitrary; component 0 usually comes out negative there, which -1 reproduces).
+ * Columns r >= min(M,N) are zero (qmf.py:50-52).  G is N x N (destroyed), N must be 64. */
 int lrf_oracle_init_from_gram(double* G, long M, long N, int R, const int8_t* sign, float* v0, float* w0)
 {
     int n = (int)N;
-    if (n & 1) return -1;
-    double* E = (double*)malloc(sizeof(double) * n * n);
-    lrf_oracle_jacobi_f64(G, n, E, 30);
-    int* order = (int*)malloc(sizeof(int) * n);
-    for (int i = 0; i < n; i++) order[i] = i;
-    for (int i = 1; i < n; i++) { /* stable insertion sort, descending */
-        int o = order[i];
-        double key = G[o * n + o];
-        int j = i - 1;
-        while (j >= 0 && G[order[j] * n + order[j]] < key) { order[j + 1] = order[j]; j--; }
-        order[j + 1] = o;
-    }
+    if (n != EN || R > EN) return -1;
     long rmax = M < N ? M : N;
+    int Rc = R < rmax ? R : (int)rmax;
+    double lam[EN];
+    double* Ev = (double*)malloc(sizeof(double) * EN * EN);
+    if (lrf_oracle_top_eig_f64(G, Rc, lam, Ev)) { free(Ev); return -1; }
     for (int r = 0; r < R; r++) {
         if (r >= rmax) {
             for (int j = 0; j < n; j++) { v0[j * R + r] = 0.f; w0[j * R + r] = 0.f; }
             continue;
         }
-        int c = order[r];
-        double lam = G[c * n + c];
-        double sigma = sqrt(lam > 0.0 ? lam : 0.0);
+        const double* E = Ev + r * EN;
+        /* eigenvalues at the multisection noise floor (hull slack ~1e-300) count as zero: no inf in w0 */
+        double sigma = sqrt(lam[r] > 1e-200 ? lam[r] : 0.0);
         double sr = sqrt(sigma);
         double dot = 0.0;
-        for (int j = 0; j < n; j++) dot = fma((double)(j + 1), E[j * n + c], dot);
+        for (int j = 0; j < n; j++) dot = fma((double)(j + 1), E[j], dot);
         double want = (sign && sign[r]) ? (double)sign[r] : -1.0;
         double flip = ((dot < 0.0 ? -1.0 : 1.0) == want) ? 1.0 : -1.0;
         for (int j = 0; j < n; j++) {
-            double e = flip * E[j * n + c];
-            v0[j * R + r] = (float)(e * sr);
-            w0[j * R + r] = (sr > 0.0) ? (float)(e / sr) : 0.f;
+            double ev = flip * E[j];
+            v0[j * R + r] = (float)(ev * sr);
+            w0[j * R + r] = (sr > 0.0) ? (float)(ev / sr) : 0.f;
         }
     }
-    free(order);
-    free(E);
+    free(Ev);
     return 0;
 }
 

@@ -85,6 +85,17 @@ def jacobi_f64(A, max_sweeps=30):
     return np.diag(A).copy(), E, sweeps
 
 
+def top_eig_f64(G, R):
+    """(lam[R] descending, E[64,R]) of a symmetric 64x64 matrix, by the oracle's tridiagonal path."""
+    A = np.array(G, dtype=np.float64, order="C")
+    lam = np.empty(R, np.float64)
+    Ev = np.empty((R, 64), np.float64)
+    lib().lrf_oracle_top_eig_f64.restype = c_int
+    rc = lib().lrf_oracle_top_eig_f64(_ptr(A, _dp), c_int(R), _ptr(lam, _dp), _ptr(Ev, _dp))
+    assert rc == 0
+    return lam, Ev.T.copy()
+
+
 def _sign_arg(sign, R):
     if sign is None:
         return None, None
