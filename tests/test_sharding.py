@@ -1,0 +1,77 @@
+"""CPU suite: the N > 1 path (per-image sharding + metrics gather) with two gloo ranks."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_items, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lrf_amd.sharding import encode_sharded, shard_range
+    g = torch.Generator().manual_seed(3)
+    data = torch.randint(0, 256, (n_items, 3, 8, 8), dtype=torch.uint8, generator=g)
+
+    def load(lo, hi):
+        return data[lo:hi]
+
+    def encode(images):  # stand-in encoder (the GPU one is exercised by the -m gpu suite)
+        return [bytes([int(im.sum()) % 251]) * (1 + int(im[0, 0, 0]) % 5) for im in images]
+
+    def metrics(images, streams):
+        return torch.tensor([[float(len(s)), float(im.float().mean())] for im, s in zip(images, streams)])
+
+    streams, table = encode_sharded(n_items, load, encode, metrics, 2)
+    lo, hi = shard_range(n_items, rank, world)
+    assert len(streams) == hi - lo
+    q.put((rank, table.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_items", [7, 8, 1])
+def test_two_rank_sharding(n_items):
+    from lrf_amd.sharding import shard_range
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_items, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    tables = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # every rank holds the full table, identical to a single-process run
+    g = torch.Generator().manual_seed(3)
+    data = torch.randint(0, 256, (n_items, 3, 8, 8), dtype=torch.uint8, generator=g)
+    want = torch.tensor([[float(1 + int(im[0, 0, 0]) % 5), float(im.float().mean())] for im in data])
+    for r in range(world):
+        assert torch.allclose(tables[r], want)
+    spans = [shard_range(n_items, r, world) for r in range(world)]
+    assert spans[0][0] == 0 and spans[-1][1] == n_items and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def test_shard_range_properties():
+    from lrf_amd.sharding import shard_range
+    for n in (0, 1, 5, 256, 4096, 4097):
+        for w in (1, 2, 4, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert sum(hi - lo for lo, hi in spans) == n
+            assert all(0 <= lo <= hi <= n for lo, hi in spans)
