@@ -185,20 +185,29 @@ __global__ __launch_bounds__(256) void k_init(const float* __restrict__ X, const
             if (s < nsteps && row < M) x = *reinterpret_cast<const f32x4*>(Xp + (long)row * 64 + 4 * li);
             return x;
         };
-        f32x4 xa = loadx(wave), xb = loadx(wave + 4);
-        for (int s = wave; s < nsteps; s += 4) {
-            f32x4 x = xa;
-            xa = xb;
-            xb = loadx(s + 8); // two steps ahead
-            double xd[4] = {(double)x[0], (double)x[1], (double)x[2], (double)x[3]};
-            int n = 0;
+        // four steps per iteration, the next four prefetched meanwhile (a step past the end loads zeros, and an
+        // MFMA on zeros leaves the accumulators unchanged bit for bit)
+        f32x4 cur[4], nxt[4];
 #pragma unroll
-            for (int t = 0; t < 4; t++)
+        for (int u = 0; u < 4; u++) cur[u] = loadx(wave + 4 * u);
+        for (int s = wave; s < nsteps; s += 16) {
 #pragma unroll
-                for (int u = t; u < 4; u++) {
-                    acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(xd[t], xd[u], acc[n], 0, 0, 0);
-                    n++;
-                }
+            for (int u = 0; u < 4; u++) nxt[u] = loadx(s + 16 + 4 * u);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                f32x4 x = cur[u];
+                double xd[4] = {(double)x[0], (double)x[1], (double)x[2], (double)x[3]};
+                int n = 0;
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+#pragma unroll
+                    for (int v = t; v < 4; v++) {
+                        acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(xd[t], xd[v], acc[n], 0, 0, 0);
+                        n++;
+                    }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) cur[u] = nxt[u];
         }
         // G = ((g0 + g1) + g2) + g3, in wave order.  f64 C/D layout: col = lane&15, row = (lane>>4) + 4*reg.
         for (int w = 0; w < 4; w++) {
@@ -676,7 +685,11 @@ __global__ __launch_bounds__(256) void k_bcd(const float* __restrict__ X, const 
         for (int i = 0; i < 4; i++) {
             int e = i * 256 + tid, row = e >> 4, c4 = e & 15;
             xpre[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifndef LRF_ABLATE_LOADS
             if (r0 + row < nrows) xpre[i] = *reinterpret_cast<const f32x4*>(Xp + (long)(r0 + row) * 64 + 4 * c4);
+#else
+            xpre[i] = (f32x4){(float)e, 1.f, 2.f, (float)t};
+#endif
         }
         if (MODE == 0) {
             int lim = (nrows - r0 < 64 ? nrows - r0 : 64) * R;
@@ -723,11 +736,19 @@ __global__ __launch_bounds__(256) void k_bcd(const float* __restrict__ X, const 
         {
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, accw = (f32x4){0.f, 0.f, 0.f, 0.f};
             const float* xr = &Xs[(16 * wave + li) * XS_LD + lq];
+            // operands through named arrays; hipcc interleaves the LDS reads with the dependent MFMA chain itself
+            // (forcing all reads first with sched_barrier measured 4% slower)
+            float bx[16], av[16], aw[MODE == 1 ? 16 : 1];
 #pragma unroll
             for (int s = 0; s < 16; s++) {
-                float bx = xr[4 * s];
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(va_s[s * 64 + lane], bx, acc, 0, 0, 0);
-                if (MODE == 1) accw = __builtin_amdgcn_mfma_f32_16x16x4f32(wa_s[s * 64 + lane], bx, accw, 0, 0, 0);
+                bx[s] = xr[4 * s];
+                av[s] = va_s[s * 64 + lane];
+                if (MODE == 1) aw[s] = wa_s[s * 64 + lane];
+            }
+#pragma unroll
+            for (int s = 0; s < 16; s++) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bx[s], acc, 0, 0, 0);
+                if (MODE == 1) accw = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[s], bx[s], accw, 0, 0, 0);
             }
             // D[i = 4*lq + reg (r)][j = li (row)]
             *reinterpret_cast<f32x4*>(&a_s[(16 * wave + li) * LRF_RP + 4 * lq]) = acc;
@@ -747,7 +768,22 @@ __global__ __launch_bounds__(256) void k_bcd(const float* __restrict__ X, const 
                     for (int r = 0; r < R; r++) ur[r] = up[r];
                 }
                 STAMP(g1);
+#ifdef LRF_ABLATE_GS
+                {
+                    f32x4 a0 = *reinterpret_cast<const f32x4*>(&a_s[lane * LRF_RP]), a1 = *reinterpret_cast<const f32x4*>(&a_s[lane * LRF_RP + 4]);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        a0[q] = (q < R) ? fminf(fmaxf(rintf(a0[q] * 1e-4f), gp.lo), gp.hi) : 0.f;
+                        a1[q] = (q + 4 < R) ? fminf(fmaxf(rintf(a1[q] * 1e-4f), gp.lo), gp.hi) : 0.f;
+                    }
+                    *reinterpret_cast<f32x4*>(ur) = a0;
+                    *reinterpret_cast<f32x4*>(ur + 4) = a1;
+                    *reinterpret_cast<f32x4*>(ur + 8) = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    *reinterpret_cast<f32x4*>(ur + 12) = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+#else
                 gs_dispatch<RMAX, MODE == 0>(R, &a_s[lane * LRF_RP], ur, uold_s, lane, gt, pd.native_t2_u != 0, gp);
+#endif
                 STAMP(g2);
 #ifdef LRF_STAMPS
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -771,14 +807,19 @@ __global__ __launch_bounds__(256) void k_bcd(const float* __restrict__ X, const 
             }
             const float* xc = &Xs[lq * XS_LD + 16 * wave + li];
             const float* uc = &u_s[lq * LRF_RP + li];
-#pragma unroll
-            for (int s = 0; s < 16; s++)
-                accP = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[4 * s * XS_LD], uc[4 * s * LRF_RP], accP, 0, 0, 0);
+            float px[16], pu[16], qu[4];
             const float* uq = uc + 16 * wave * LRF_RP; // wave w: row steps 4w .. 4w+3 of the sub-tile
 #pragma unroll
-            for (int s = 0; s < 4; s++) {
-                float ub = uq[4 * s * LRF_RP];
-                accQ = __builtin_amdgcn_mfma_f32_16x16x4f32(ub, ub, accQ, 0, 0, 0);
+            for (int s = 0; s < 16; s++) {
+                px[s] = xc[4 * s * XS_LD];
+                pu[s] = uc[4 * s * LRF_RP];
+            }
+#pragma unroll
+            for (int s = 0; s < 4; s++) qu[s] = uq[4 * s * LRF_RP];
+#pragma unroll
+            for (int s = 0; s < 16; s++) {
+                accP = __builtin_amdgcn_mfma_f32_16x16x4f32(px[s], pu[s], accP, 0, 0, 0);
+                if ((s & 3) == 3) accQ = __builtin_amdgcn_mfma_f32_16x16x4f32(qu[s >> 2], qu[s >> 2], accQ, 0, 0, 0);
             }
         }
 #ifdef LRF_STAMPS
@@ -824,18 +865,33 @@ __global__ __launch_bounds__(256) void k_vupdate(const PlaneDesc* __restrict__ p
 
     const PlaneDesc pd = planes[blockIdx.x];
     const int R = pd.R, tid = threadIdx.x;
-    // a' = ((P0 + P1) + P2) + ...
+    // a' = ((P0 + P1) + P2) + ... : the partials are loaded in independent batches of 8 (one exposed memory
+    // latency per batch instead of one per block) and added in block order
     for (int i = tid; i < 64 * LRF_RP; i += 256) {
         const float* Pp = Ppart + (long)pd.blk0 * 64 * LRF_RP + i;
-        float acc = Pp[0];
-        for (int b = 1; b < pd.nblk; b++) acc = acc + Pp[(long)b * 64 * LRF_RP];
+        float acc = 0.f;
+        for (int b0 = 0; b0 < pd.nblk; b0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = (b0 + k < pd.nblk) ? Pp[(long)(b0 + k) * 64 * LRF_RP] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (b0 + k < pd.nblk) acc = (b0 + k == 0) ? v[k] : acc + v[k];
+        }
         a_s[i] = acc;
         v_s[i] = Vf[(long)blockIdx.x * 64 * LRF_RP + i];
     }
     {
         const float* Qp = Qpart + (long)pd.blk0 * LRF_RP * LRF_RP + tid;
-        float q = Qp[0];
-        for (int b = 1; b < pd.nblk; b++) q = q + Qp[(long)b * LRF_RP * LRF_RP];
+        float q = 0.f;
+        for (int b0 = 0; b0 < pd.nblk; b0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = (b0 + k < pd.nblk) ? Qp[(long)(b0 + k) * LRF_RP * LRF_RP] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (b0 + k < pd.nblk) q = (b0 + k == 0) ? v[k] : q + v[k];
+        }
         int j = tid >> 4, r = tid & 15;
         if (j < R && r < R) {
             if (j == r) {
