@@ -4,8 +4,9 @@ from .codec import (qmf_decode, qmf_decode_batch, qmf_encode, qmf_encode_batch, 
 from .container import (bytes_to_dict, combine_bytes, decode_matrix, decode_tensor, dict_to_bytes, encode_matrix,
                         encode_tensor, separate_bytes)
 from .factorization import QMF
+from .harness import eval_compression, rd_sweep
 from .metrics import bits_per_pixel, compression_ratio, mse, psnr
 
 __all__ = ["qmf_encode", "qmf_decode", "qmf_encode_batch", "qmf_decode_batch", "qmf_factorize_batch", "qmf_ranks",
-           "QMF", "psnr", "mse", "bits_per_pixel", "compression_ratio", "combine_bytes", "separate_bytes",
+           "QMF", "eval_compression", "rd_sweep", "psnr", "mse", "bits_per_pixel", "compression_ratio", "combine_bytes", "separate_bytes",
            "dict_to_bytes", "bytes_to_dict", "encode_matrix", "decode_matrix", "encode_tensor", "decode_tensor"]

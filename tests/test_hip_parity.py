@@ -206,3 +206,50 @@ def test_batched_streams_roundtrip():
     dec = lrf_amd.qmf_decode_batch(streams).cpu()
     for b in range(3):
         assert torch.equal(dec[b], lrf_amd.qmf_decode(streams[b]))
+
+
+def test_rd_sweep_against_reference(oracle):
+    """Config-3 style sweep (experiments/comparison/eval.py:83-100) through the eval_compression harness: every quality up
+    to 25 (ranks up to 16).  HIP == oracle exactly; against the reference (default signs, and for R > 7 an unpinned MKL
+    order) PSNR within 0.1 dB and stream size within 3%."""
+    import json
+    import os
+
+    import lrf_amd
+    from conftest import GOLDEN, make_image
+    from lrf_amd.codec import parse_stream
+    sw = json.load(open(os.path.join(GOLDEN, "sweep_smooth.json")))
+    img = make_image(sw["spec"])
+    for rec in sw["records"]:
+        out = lrf_amd.eval_compression(img, lrf_amd.qmf_encode, lrf_amd.qmf_decode, reconstruct=True, quality=rec["quality"])
+        meta, fac = parse_stream(lrf_amd.qmf_encode(img, quality=rec["quality"]))
+        assert meta["rank"] == rec["ranks"]
+        assert abs(out["PSNR (dB)"] - rec["psnr"]) < 0.1, (rec["quality"], out["PSNR (dB)"], rec["psnr"])
+        assert abs(out["bit rate (bpp)"] / rec["bpp"] - 1) < 0.03
+        assert out["encoding time (ms)"] > 0 and out["decoding time (ms)"] > 0 and out["SSIM"] is None
+        X = oracle.rgb_to_planes(img.numpy())
+        for c in range(3):
+            u, v = oracle.qmf_decompose(X[c], rec["ranks"][c], 10, (-16, 15))
+            assert np.array_equal(fac[2 * c], u.astype(np.int8)) and np.array_equal(fac[2 * c + 1], v.astype(np.int8)), \
+                (rec["quality"], c)
+
+
+def test_clic_sized_image(oracle):
+    """BASELINE config 4 geometry (2048 wide x 1365 high: odd height, 3-row pooling windows, reflect pad, M = 43776):
+    two images against the oracle, bit for bit."""
+    import lrf_amd
+    from lrf_amd.codec import split_factors
+    H, W = 1365, 2048
+    g = torch.Generator(device="cuda").manual_seed(4)
+    imgs = torch.randint(0, 256, (2, 3, H, W), dtype=torch.uint8, device="cuda", generator=g)
+    ranks = lrf_amd.qmf_ranks((H, W), quality=7)
+    U, V = lrf_amd.qmf_factorize_batch(imgs, ranks)
+    b = 1
+    got = split_factors(U[b].cpu().numpy(), V[b].cpu().numpy(), (H, W), ranks)
+    X = oracle.rgb_to_planes(imgs[b].cpu().numpy())
+    for c in range(3):
+        u, v = oracle.qmf_decompose(X[c], ranks[c], 10, (-16, 15))
+        assert np.array_equal(got[2 * c], u.astype(np.int8)) and np.array_equal(got[2 * c + 1], v.astype(np.int8))
+    ctx = lrf_amd._lib.context(0)
+    dec = ctx.decode_rgb(U[b:b + 1], V[b:b + 1], H, W, ranks)[0].cpu().numpy()
+    assert np.array_equal(dec, oracle.planes_to_rgb(got[0::2], got[1::2], H, W))

@@ -142,5 +142,29 @@ def main():
         json.dump(index, f, indent=1, sort_keys=True)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) == 1:
     main()
+
+
+def gen_sweep():
+    """R-D sweep fixture (experiments/comparison/eval.py:83-100 protocol): reference (bytes, bpp, PSNR) per quality."""
+    torch.set_num_threads(1)
+    ns = ref_loader.load()
+    spec = dict(kind="smooth", seed=21, H=128, W=192)
+    img = make_image(spec)
+    out = {"spec": spec, "records": []}
+    for q in (1, 2, 3.5, 5, 7, 10, 12.5, 15, 20, 25):
+        enc = ns.cqmf.qmf_encode(img, quality=q)
+        dec = ns.cqmf.qmf_decode(enc)
+        mse = torch.mean((img.float() - dec.float()) ** 2, dim=(-3, -2, -1))
+        meta = json.loads(ns.cutils.separate_bytes(enc, 2)[0].decode())
+        out["records"].append({"quality": q, "bytes": len(enc), "bpp": len(enc) * 8 / (img.shape[-2] * img.shape[-1]),
+                               "psnr": (20 * torch.log10(255 / torch.sqrt(mse))).item(), "ranks": meta["rank"]})
+    out["image_sha256"] = hashlib.sha256(img.numpy().tobytes()).hexdigest()
+    with open(os.path.join(OUT, "sweep_smooth.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(out["records"])
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "sweep":
+    gen_sweep()
