@@ -162,7 +162,7 @@ def main():
             "kernels": {k: {a: round(b, 5) for a, b in v.items()} for k, v in kern.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(images[:64].cpu().numpy())
+            out["cpu_baseline"] = cpu_baseline(images.cpu().numpy())
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

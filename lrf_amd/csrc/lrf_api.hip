@@ -51,6 +51,7 @@ struct lrf_ctx {
     double acc_ms[LRF_K_COUNT] = {0};
     long acc_n[LRF_K_COUNT] = {0};
     int init_sweeps = 0; // developer aid: stop k_init after stage n (0 = run everything)
+    std::vector<char> table_key; // bytes of the descriptor tables now resident on the device
 };
 
 static int ensure(lrf_ctx* c, DevBuf& b, size_t bytes)
@@ -206,9 +207,16 @@ static int check_params(int64_t M, int64_t N, int R, int K, int lo, int hi)
 
 static int upload_tables(lrf_ctx* c, const Tables& t)
 {
-    int rc = upload(c, c->planes, t.planes.data(), t.planes.size() * sizeof(PlaneDesc));
+    // the tables only depend on the call's geometry: skip the (synchronising) upload when nothing changed
+    size_t pb = t.planes.size() * sizeof(PlaneDesc), bb = t.blocks.size() * sizeof(BlockDesc);
+    std::vector<char> key(pb + bb);
+    memcpy(key.data(), t.planes.data(), pb);
+    memcpy(key.data() + pb, t.blocks.data(), bb);
+    if (key == c->table_key) return LRF_OK;
+    c->table_key.clear();
+    int rc = upload(c, c->planes, t.planes.data(), pb);
     if (rc) return rc;
-    rc = upload(c, c->blocks, t.blocks.data(), t.blocks.size() * sizeof(BlockDesc));
+    rc = upload(c, c->blocks, t.blocks.data(), bb);
     if (rc) return rc;
     size_t np = t.planes.size(), nb = t.blocks.size();
     if ((rc = ensure(c, c->vf, np * 64 * LRF_RP * sizeof(float)))) return rc;
@@ -216,6 +224,7 @@ static int upload_tables(lrf_ctx* c, const Tables& t)
     if ((rc = ensure(c, c->bf, np * LRF_GT_STRIDE * sizeof(float)))) return rc;
     if ((rc = ensure(c, c->ppart, nb * 64 * LRF_RP * sizeof(float)))) return rc;
     if ((rc = ensure(c, c->qpart, nb * LRF_RP * LRF_RP * sizeof(float)))) return rc;
+    c->table_key.swap(key);
     return LRF_OK;
 }
 
