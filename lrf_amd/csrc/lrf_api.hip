@@ -230,18 +230,23 @@ static int upload_tables(lrf_ctx* c, const Tables& t)
 
 #define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
 
-static const size_t INIT_LDS = sizeof(InitLds);
-
-static int run_init(lrf_ctx* c, const float* X, int nplanes, const int8_t* sign_dev)
+static int run_init(lrf_ctx* c, const float* X, const Tables& t, const int8_t* sign_dev)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)k_init, hipFuncAttributeMaxDynamicSharedMemorySize, (int)INIT_LDS));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_init<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InitLds<8>)));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_init<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InitLds<16>)));
         attr_set = true;
     }
+    int rmax = 1, nplanes = (int)t.planes.size();
+    for (const PlaneDesc& pd : t.planes) rmax = pd.R > rmax ? pd.R : rmax;
     Prof p(c, LRF_K_INIT);
-    hipLaunchKernelGGL(k_init, dim3(nplanes), dim3(256), INIT_LDS, c->stream, X, (const PlaneDesc*)c->planes.p, sign_dev,
-                       (float*)c->vf.p, (float*)c->wf.p, c->init_sweeps);
+    if (rmax <= 8)
+        hipLaunchKernelGGL(k_init<8>, dim3(nplanes), dim3(256), sizeof(InitLds<8>), c->stream, X, (const PlaneDesc*)c->planes.p,
+                           sign_dev, (float*)c->vf.p, (float*)c->wf.p, c->init_sweeps);
+    else
+        hipLaunchKernelGGL(k_init<16>, dim3(nplanes), dim3(256), sizeof(InitLds<16>), c->stream, X, (const PlaneDesc*)c->planes.p,
+                           sign_dev, (float*)c->vf.p, (float*)c->wf.p, c->init_sweeps);
     LAUNCH_CHECK();
     return LRF_OK;
 }
@@ -497,7 +502,7 @@ int lrf_qmf_decompose_f32(lrf_ctx* c, const float* X, int64_t B, int64_t M, int6
     Tables t;
     uniform_tables(t, B, M, R, sign != nullptr);
     if ((rc = upload_tables(c, t))) return rc;
-    if ((rc = run_init(c, X, (int)t.planes.size(), sign))) return rc;
+    if ((rc = run_init(c, X, t, sign))) return rc;
     return run_bcd(c, X, t, K, lo, hi, 1, nullptr, U, V);
 }
 
@@ -529,7 +534,7 @@ int lrf_qmf_svd_init_f32(lrf_ctx* c, const float* X, int64_t B, int64_t M, int64
     Tables t;
     uniform_tables(t, B, M, R, sign != nullptr);
     if ((rc = upload_tables(c, t))) return rc;
-    if ((rc = run_init(c, X, (int)t.planes.size(), sign))) return rc;
+    if ((rc = run_init(c, X, t, sign))) return rc;
     hipLaunchKernelGGL(k_emit_init, dim3((unsigned)t.blocks.size()), dim3(256), 0, c->stream, X, (const PlaneDesc*)c->planes.p,
                        (const BlockDesc*)c->blocks.p, (const float*)c->vf.p, (const float*)c->wf.p, U0, V0);
     LAUNCH_CHECK();
@@ -564,7 +569,7 @@ int lrf_qmf_encode_rgb_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_t H, 
             add_plane(t, b * g.img_floats + g.p[ch].xoff, b * u_img + uoff[ch], b * v_img + voff[ch], 0, 0, g.p[ch].M, R[ch],
                       sign ? (int)(b * s_img + soff[ch]) : -1);
     if ((rc = upload_tables(c, t))) return rc;
-    if ((rc = run_init(c, X, (int)t.planes.size(), sign))) return rc;
+    if ((rc = run_init(c, X, t, sign))) return rc;
     return run_bcd(c, X, t, K, lo, hi, 1, nullptr, U, V);
 }
 

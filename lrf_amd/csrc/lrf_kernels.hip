@@ -147,23 +147,27 @@ __device__ __forceinline__ double wave_tree64(double v)
     return __shfl(v, 0, 64);
 }
 
+// LDS carve of k_init; ZR = 8 or 16 eigenvectors' worth of scratch (chosen on the host from the largest rank
+// of the call, so that R <= 8 batches fit three workgroups per CU)
+template <int ZR>
 struct InitLds {
     double A[64 * 64];      // Gram matrix, then (row k) the Householder vector v_k
-    double D1[64 * 16];     // twisted factorisation scratch [i][r]
-    double D2[64 * 16];
-    double Z[16 * 64];      // eigenvectors in tridiagonal coordinates, then in the original basis
+    double D1[64 * ZR];     // twisted factorisation scratch [i][r]
+    double D2[64 * ZR];
+    double Z[ZR * 64];      // eigenvectors in tridiagonal coordinates, then in the original basis
     double cpart[4 * 64];   // matvec partial chains
     double v[64], w[64], d[64], e[64], e2[64], tau[64], lam[16];
     double scal[8];         // [0] t, [1] pivmin, [2] lo, [3] hi
     int flag[4];
 };
 
+template <int ZR>
 __global__ __launch_bounds__(256) void k_init(const float* __restrict__ X, const PlaneDesc* __restrict__ planes,
                                               const int8_t* __restrict__ sign, float* __restrict__ Vf,
                                               float* __restrict__ Wf, int debug_stop)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    InitLds& L = *reinterpret_cast<InitLds*>(smem);
+    InitLds<ZR>& L = *reinterpret_cast<InitLds<ZR>*>(smem);
     double* G = L.A;
 
     const PlaneDesc pd = planes[blockIdx.x];
@@ -361,33 +365,33 @@ __global__ __launch_bounds__(256) void k_init(const float* __restrict__ X, const
         for (int i = 1; i < 64; i++) {
             if (fabs(q) < pivmin) q = -pivmin;
             q = (L.d[i] - lam) - L.e2[i - 1] / q;
-            Dp[i * 16] = q;
+            Dp[i * ZR] = q;
         }
         q = L.d[63] - lam;
-        Dm[63 * 16] = q;
+        Dm[63 * ZR] = q;
         for (int i = 62; i >= 0; i--) {
             if (fabs(q) < pivmin) q = -pivmin;
             q = (L.d[i] - lam) - L.e2[i] / q;
-            Dm[i * 16] = q;
+            Dm[i * ZR] = q;
         }
         int kt = 0;
         double best = 0.0;
         for (int i = 0; i < 64; i++) {
-            double g = fabs((Dp[i * 16] + Dm[i * 16]) - (L.d[i] - lam));
+            double g = fabs((Dp[i * ZR] + Dm[i * ZR]) - (L.d[i] - lam));
             if (i == 0 || g < best) { best = g; kt = i; }
         }
         double* x = L.Z + r * 64;
         double xv = 1.0;
         x[kt] = 1.0;
         for (int i = kt - 1; i >= 0; i--) {
-            double qq = Dp[i * 16];
+            double qq = Dp[i * ZR];
             if (fabs(qq) < pivmin) qq = -pivmin;
             xv = -(L.e[i] / qq) * xv;
             x[i] = xv;
         }
         xv = 1.0;
         for (int i = kt; i < 63; i++) {
-            double qq = Dm[(i + 1) * 16];
+            double qq = Dm[(i + 1) * ZR];
             if (fabs(qq) < pivmin) qq = -pivmin;
             xv = -(L.e[i] / qq) * xv;
             x[i + 1] = xv;
