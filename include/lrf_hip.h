@@ -142,6 +142,27 @@ int lrf_qmf_encode_rgb_u8(lrf_ctx* ctx, const uint8_t* rgb, int64_t B, int64_t H
 int lrf_qmf_decode_rgb_u8(lrf_ctx* ctx, const int8_t* U, const int8_t* V, int64_t B, int64_t H, int64_t W,
                           const int R[3], uint8_t* rgb);
 
+/* ---- the SVD baseline ------------------------------------------------- */
+
+/*
+ * svd_encode, default branch (color_space="RGB", patch 8x8, uint8 factors), everything between image.float() and the byte
+ * container: pad_image(reflect) + patchify to X [M,192] (lrf/compression/svd.py:160-162), the top-R singular pairs
+ * u = U sqrt(s), v = (sqrt(s) Vh)^T (:179-183; fp64 Gram + eigen-solve instead of LAPACK, tolerance-checked) and
+ * quantize(., uint8) of both (:185-187, lrf/compression/utils.py:185-220).
+ *   U [B,M,R] uint8, V [B,192,R] uint8, qparams [B,4] float = (scale_u, min_u, scale_v, min_v), all device memory.
+ *   sign optional [B,R] as in lrf_qmf_decompose_f32.
+ */
+int lrf_svd_encode_rgb_u8(lrf_ctx* ctx, const uint8_t* rgb, int64_t B, int64_t H, int64_t W, int R, const int8_t* sign,
+                          uint8_t* U, uint8_t* V, float* qparams);
+
+/*
+ * svd_decode, RGB branch: dequantize (lrf/compression/utils.py:223-243), u @ v.mT, depatchify, unpad_image, to_dtype(uint8)
+ * (lrf/compression/svd.py:310-326,359).  qparams6 [B,6] float (device) = (scale_u, min_u, qmin_u, scale_v, min_v, qmin_v)
+ * where qmin is the smallest stored code of the tensor (dequantize subtracts `q.min()`).
+ */
+int lrf_svd_decode_rgb_u8(lrf_ctx* ctx, const uint8_t* U, const uint8_t* V, int64_t B, int64_t H, int64_t W, int R,
+                          const float* qparams6, uint8_t* rgb);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,6 +61,8 @@ def load():
                                               c_int, c_void_p, c_void_p, c_void_p]
         lib.lrf_qmf_decode_rgb_u8.argtypes = [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, ctypes.POINTER(c_int),
                                               c_void_p]
+        lib.lrf_svd_encode_rgb_u8.argtypes = [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
+        lib.lrf_svd_decode_rgb_u8.argtypes = [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p]
         _lib = lib
         return lib
 
@@ -69,7 +71,7 @@ EXPORTS = ["lrf_last_error", "lrf_device_count", "lrf_version", "lrf_ctx_create"
            "lrf_ctx_synchronize", "lrf_ctx_workspace_bytes", "lrf_ctx_profile", "lrf_ctx_kernel_time",
            "lrf_ctx_profile_reset", "lrf_malloc", "lrf_free", "lrf_memcpy_h2d", "lrf_memcpy_d2h", "lrf_plane_dims",
            "lrf_qmf_planes_from_rgb_u8", "lrf_qmf_decompose_f32", "lrf_qmf_bcd_f32", "lrf_qmf_svd_init_f32",
-           "lrf_qmf_encode_rgb_u8", "lrf_qmf_decode_rgb_u8"]
+           "lrf_qmf_encode_rgb_u8", "lrf_qmf_decode_rgb_u8", "lrf_svd_encode_rgb_u8", "lrf_svd_decode_rgb_u8"]
 
 
 def check(rc):
@@ -215,6 +217,35 @@ class Context:
         return rgb
 
 
+def _svd_methods():
+    def svd_encode_rgb(self, rgb, R, sign=None):
+        """rgb uint8 [B,3,H,W] (CUDA) -> (U uint8 [B,M,R], V uint8 [B,192,R], qparams float [B,4])"""
+        import torch
+        rgb = rgb.contiguous()
+        B, C, H, W = rgb.shape
+        assert C == 3 and rgb.dtype == torch.uint8
+        M = ((H + 7) // 8) * ((W + 7) // 8)
+        U = torch.empty((B, M, R), dtype=torch.uint8, device=rgb.device)
+        V = torch.empty((B, 192, R), dtype=torch.uint8, device=rgb.device)
+        qp = torch.empty((B, 4), dtype=torch.float32, device=rgb.device)
+        self.use_torch_stream()
+        check(self._lib.lrf_svd_encode_rgb_u8(self._h, _dptr(rgb), B, H, W, int(R), _dptr(sign), _dptr(U), _dptr(V), _dptr(qp)))
+        return U, V, qp
+
+    def svd_decode_rgb(self, U, V, qparams6, H, W):
+        import torch
+        U, V, qparams6 = U.contiguous(), V.contiguous(), qparams6.float().contiguous()
+        B, _, R = U.shape
+        rgb = torch.empty((B, 3, H, W), dtype=torch.uint8, device=U.device)
+        self.use_torch_stream()
+        check(self._lib.lrf_svd_decode_rgb_u8(self._h, _dptr(U), _dptr(V), B, H, W, int(R), _dptr(qparams6), _dptr(rgb)))
+        return rgb
+
+    Context.svd_encode_rgb = svd_encode_rgb
+    Context.svd_decode_rgb = svd_decode_rgb
+
+
+_svd_methods()
 _contexts = {}
 
 

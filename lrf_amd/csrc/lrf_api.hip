@@ -12,6 +12,7 @@
 
 #include "../../include/lrf_hip.h"
 #include "lrf_kernels.hip"
+#include "lrf_svd_kernels.hip"
 
 static thread_local char g_err[512] = "";
 
@@ -41,6 +42,7 @@ struct lrf_ctx {
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
     DevBuf planes, blocks, vf, wf, bf, ppart, qpart, x, sign;
+    DevBuf sx, sg, svn, swn, suf, smm; // SVD baseline workspace
     // host staging for descriptor tables (pinned)
     void* h_stage = nullptr;
     size_t h_stage_cap = 0;
@@ -360,7 +362,8 @@ void lrf_ctx_destroy(lrf_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     fold_events(c);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-    DevBuf* bufs[] = {&c->planes, &c->blocks, &c->vf, &c->wf, &c->bf, &c->ppart, &c->qpart, &c->x, &c->sign};
+    DevBuf* bufs[] = {&c->planes, &c->blocks, &c->vf, &c->wf, &c->bf, &c->ppart, &c->qpart, &c->x, &c->sign,
+                      &c->sx, &c->sg, &c->svn, &c->swn, &c->suf, &c->smm};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -605,5 +608,84 @@ int lrf_debug_read_stamps(lrf_ctx* c, unsigned long long* out_host, int n)
     return LRF_OK;
 }
 #endif
+
+/* ---- SVD baseline (lrf.svd_encode / svd_decode, default RGB branch) ---- */
+static int svd_geom(int64_t H, int64_t W, int* hp, int* wp, int* top, int* left, int* nw, int* M)
+{
+    if (H < 1 || W < 1) return set_err(LRF_EINVAL, "bad image size");
+    int64_t ph = (8 - H % 8) % 8, pw = (8 - W % 8) % 8;
+    if (ph / 2 >= H || ph - ph / 2 >= H || pw / 2 >= W || pw - pw / 2 >= W)
+        return set_err(LRF_EINVAL, "reflect padding larger than the image (%ldx%ld)", (long)H, (long)W);
+    *hp = (int)(H + ph); *wp = (int)(W + pw); *top = (int)(ph / 2); *left = (int)(pw / 2);
+    *nw = *wp / 8; *M = (*hp / 8) * (*wp / 8);
+    return LRF_OK;
+}
+
+int lrf_svd_encode_rgb_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_t H, int64_t W, int R, const int8_t* sign,
+                          uint8_t* U, uint8_t* V, float* qparams)
+{
+    if (!c || !rgb || !U || !V || !qparams) return set_err(LRF_EINVAL, "NULL argument");
+    if (B < 1 || B > 65535) return set_err(LRF_EINVAL, "B=%ld out of range [1,65535]", (long)B);
+    if (R < 1) return set_err(LRF_EINVAL, "rank must be >= 1 (got %d)", R);
+    if (R > LRF_MAX_RANK) return set_err(LRF_ENOTSUP, "rank %d > %d not implemented", R, LRF_MAX_RANK);
+    int hp, wp, top, left, nw, M, rc;
+    if ((rc = svd_geom(H, W, &hp, &wp, &top, &left, &nw, &M))) return rc;
+    const int N = 192, nc = 3;
+    HIP_TRY(hipSetDevice(c->device));
+    long xs = (long)M * N;
+    if ((rc = ensure(c, c->sx, (size_t)B * xs * sizeof(float)))) return rc;
+    if ((rc = ensure(c, c->sg, (size_t)B * N * N * sizeof(double)))) return rc;
+    if ((rc = ensure(c, c->svn, (size_t)B * N * R * sizeof(float)))) return rc;
+    if ((rc = ensure(c, c->swn, (size_t)B * N * R * sizeof(float)))) return rc;
+    if ((rc = ensure(c, c->suf, (size_t)B * M * R * sizeof(float)))) return rc;
+    if ((rc = ensure(c, c->smm, (size_t)B * 4 * sizeof(float)))) return rc;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_eig_n, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(EigLds)));
+        attr_set = true;
+    }
+    float* X = (float*)c->sx.p;
+    double* G = (double*)c->sg.p;
+    float* Vn = (float*)c->svn.p;
+    float* Wn = (float*)c->swn.p;
+    float* Uf = (float*)c->suf.p;
+    float* mm = (float*)c->smm.p;
+    hipLaunchKernelGGL(k_patchify_rgb, dim3(hp / 8, (unsigned)B), dim3(256), 0, c->stream, rgb, (int)H, (int)W, top, left, nw, xs, X);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_gram_blk, dim3(nc * (nc + 1) / 2, (unsigned)B), dim3(256), 0, c->stream, (const float*)X, xs, M, N, nc, G);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_eig_n, dim3((unsigned)B), dim3(256), sizeof(EigLds), c->stream, G, N, M, R, sign, Vn, Wn);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_xw_n, dim3((unsigned)(((long)M * R + 255) / 256), (unsigned)B), dim3(256), 0, c->stream, (const float*)X, xs, M,
+                       N, R, (const float*)Wn, Uf);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_minmax, dim3((unsigned)B), dim3(256), 0, c->stream, (const float*)Uf, (long)M * R, (long)M * R, mm);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_minmax, dim3((unsigned)B), dim3(256), 0, c->stream, (const float*)Vn, (long)N * R, (long)N * R, mm + 2 * B);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_quantize_u8, dim3((unsigned)(((long)M * R + 255) / 256), (unsigned)B), dim3(256), 0, c->stream,
+                       (const float*)Uf, (long)M * R, (long)M * R, (const float*)mm, U, qparams, 4, 0);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_quantize_u8, dim3((unsigned)(((long)N * R + 255) / 256), (unsigned)B), dim3(256), 0, c->stream,
+                       (const float*)Vn, (long)N * R, (long)N * R, (const float*)(mm + 2 * B), V, qparams, 4, 2);
+    LAUNCH_CHECK();
+    return LRF_OK;
+}
+
+int lrf_svd_decode_rgb_u8(lrf_ctx* c, const uint8_t* U, const uint8_t* V, int64_t B, int64_t H, int64_t W, int R,
+                          const float* qparams6, uint8_t* rgb)
+{
+    if (!c || !U || !V || !qparams6 || !rgb) return set_err(LRF_EINVAL, "NULL argument");
+    if (B < 1 || B > 65535) return set_err(LRF_EINVAL, "B=%ld out of range [1,65535]", (long)B);
+    if (R < 1 || R > 192) return set_err(LRF_EINVAL, "rank %d out of range", R);
+    int hp, wp, top, left, nw, M, rc;
+    if ((rc = svd_geom(H, W, &hp, &wp, &top, &left, &nw, &M))) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    long n4 = 3L * H * ((W + 3) / 4);
+    hipLaunchKernelGGL(k_svd_decode, dim3((unsigned)((n4 + 255) / 256), (unsigned)B), dim3(256), 0, c->stream, U, V, (int)H, (int)W, top,
+                       left, nw, M, R, qparams6, rgb);
+    LAUNCH_CHECK();
+    return LRF_OK;
+}
 
 } // extern "C"

@@ -821,3 +821,65 @@ void lrf_oracle_dequantize_u8(const uint8_t* qv, long n, float scale, float minv
         if (qv[i] < qm) qm = qv[i];
     for (long i = 0; i < n; i++) t[i] = ((float)qv[i] - (float)qm) * scale + minv;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * SVD baseline, default branch of svd_encode (color_space="RGB", patch 8x8, uint8 factors):
+ * lrf/compression/svd.py:156-193.  Tolerance-checked path: the top-R pairs come
+ * from the fp64 Gram matrix and the cyclic Jacobi solver above (any even n), not from LAPACK.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* u = U sqrt(s) [M,R], v = (sqrt(s) Vh)^T [N,R] (svd.py:179-183); sign as in lrf_oracle_init_from_gram. */
+int lrf_oracle_svd_topr(const float* X, long M, long N, int R, const int8_t* sign, float* u, float* v)
+{
+    int n = (int)N;
+    if (n & 1) return -1;
+    double* G = (double*)malloc(sizeof(double) * n * n);
+    double* E = (double*)malloc(sizeof(double) * n * n);
+    float* w = (float*)malloc(sizeof(float) * n * R);
+    int* order = (int*)malloc(sizeof(int) * n);
+    lrf_oracle_gram_f64(X, M, N, G);
+    lrf_oracle_jacobi_f64(G, n, E, 40);
+    for (int i = 0; i < n; i++) order[i] = i;
+    for (int i = 1; i < n; i++) {
+        int o = order[i];
+        double key = G[o * n + o];
+        int j = i - 1;
+        while (j >= 0 && G[order[j] * n + order[j]] < key) { order[j + 1] = order[j]; j--; }
+        order[j + 1] = o;
+    }
+    for (int r = 0; r < R; r++) {
+        int c = order[r];
+        double lam = G[c * n + c];
+        double sr = sqrt(sqrt(lam > 1e-200 ? lam : 0.0));
+        double dot = 0.0;
+        for (int j = 0; j < n; j++) dot = fma((double)(j + 1), E[j * n + c], dot);
+        double want = (sign && sign[r]) ? (double)sign[r] : -1.0;
+        double flip = ((dot < 0.0 ? -1.0 : 1.0) == want) ? 1.0 : -1.0;
+        for (int j = 0; j < n; j++) {
+            double ev = flip * E[j * n + c];
+            v[j * R + r] = (float)(ev * sr);
+            w[j * R + r] = (sr > 0.0) ? (float)(ev / sr) : 0.f;
+        }
+    }
+    mm_mkl(X, N, 1, w, R, 1, u, R, M, N, R);
+    free(G); free(E); free(w); free(order);
+    return 0;
+}
+
+/* svd_decode arithmetic for the RGB branch (svd.py:310-326): dequantize, u @ v.mT, depatchify, unpad, to_dtype. */
+int lrf_oracle_svd_decode_rgb(const uint8_t* qu, const uint8_t* qv, long M, int R, float su, float mu, float sv, float mv,
+                              long H, long W, uint8_t* rgb)
+{
+    long N = 192, Hp = H + (8 - H % 8) % 8, Wp = W + (8 - W % 8) % 8;
+    float* u = (float*)malloc(sizeof(float) * M * R);
+    float* v = (float*)malloc(sizeof(float) * N * R);
+    float* X = (float*)malloc(sizeof(float) * M * N);
+    float* img = (float*)malloc(sizeof(float) * 3 * H * W);
+    lrf_oracle_dequantize_u8(qu, M * R, su, mu, u);
+    lrf_oracle_dequantize_u8(qv, N * R, sv, mv, v);
+    lrf_oracle_reconstruct(u, v, M, N, R, X);
+    lrf_oracle_depatchify_unpad(X, 3, Hp, Wp, H, W, 8, 8, img);
+    lrf_oracle_to_u8(img, 3 * H * W, rgb);
+    free(u); free(v); free(X); free(img);
+    return 0;
+}

@@ -197,3 +197,27 @@ def to_u8(x):
     out = np.empty(x.shape, np.uint8)
     lib().lrf_oracle_to_u8(_ptr(x, _fp), c_long(x.size), _ptr(out, _u8p))
     return out
+
+
+def svd_topr(X, R, sign=None):
+    """(u [M,R], v [N,R]) = (U sqrt(s), V sqrt(s)) of the top-R singular triplets (svd_encode's factors before quantisation)."""
+    X = _f32(X)
+    M, N = X.shape
+    u = np.empty((M, R), np.float32)
+    v = np.empty((N, R), np.float32)
+    keep, sp = _sign_arg(sign, R)
+    lib().lrf_oracle_svd_topr.restype = c_int
+    rc = lib().lrf_oracle_svd_topr(_ptr(X, _fp), c_long(M), c_long(N), c_int(R), sp, _ptr(u, _fp), _ptr(v, _fp))
+    assert rc == 0
+    return u, v
+
+
+def svd_decode_rgb(qu, qv, quant_u, quant_v, H, W):
+    qu = np.ascontiguousarray(qu, dtype=np.uint8)
+    qv = np.ascontiguousarray(qv, dtype=np.uint8)
+    M, R = qu.shape
+    out = np.empty((3, H, W), np.uint8)
+    rc = lib().lrf_oracle_svd_decode_rgb(_ptr(qu, _u8p), _ptr(qv, _u8p), c_long(M), c_int(R), c_float(quant_u[0]), c_float(quant_u[1]),
+                                         c_float(quant_v[0]), c_float(quant_v[1]), c_long(H), c_long(W), _ptr(out, _u8p))
+    assert rc == 0
+    return out

@@ -103,3 +103,31 @@ def test_quantize_roundtrip(oracle):
     back = oracle.dequantize_u8(q, sc, mn)
     assert q.min() == 0 and q.max() == 255
     assert np.abs(back - t).max() <= sc * 1.001
+
+
+@pytest.mark.parametrize("name", ["svd_tiny_q2p5", "svd_smooth_q2p5"])
+def test_svd_baseline_oracle(name, oracle):
+    """SVD baseline (lrf/compression/svd.py default branch): the oracle decodes the reference's bytes exactly and its
+    encoder side agrees with the reference's uint8 codes to within one step (fp32 LAPACK vs fp64 Gram route)."""
+    import json
+    import os
+
+    from conftest import GOLDEN
+    from lrf_amd.container import bytes_to_dict, decode_tensor, separate_bytes
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    img = z["image"]
+    meta_b, fac_b = separate_bytes(z["encoded"].tobytes(), 2)
+    meta = bytes_to_dict(meta_b)
+    qu, qv = [decode_tensor(f) for f in separate_bytes(fac_b, 2)]
+    dec = oracle.svd_decode_rgb(qu, qv, meta["quantization"]["u"], meta["quantization"]["v"], img.shape[1], img.shape[2])
+    assert hashlib.sha256(dec.tobytes()).hexdigest() == str(z["decoded_sha256"])
+    X = oracle.pad_patchify(img.astype(np.float32))
+    rvf = oracle.dequantize_u8(qv, *meta["quantization"]["v"])
+    _, ov = oracle.svd_topr(X, qu.shape[1])
+    sign = np.where((ov.astype(np.float64) * rvf).sum(0) >= 0, -1, 1).astype(np.int8)
+    u, v = oracle.svd_topr(X, qu.shape[1], sign)
+    for t, q, (sc, mn) in ((u, qu, meta["quantization"]["u"]), (v, qv, meta["quantization"]["v"])):
+        got, s2, m2 = oracle.quantize_u8(t)
+        assert abs(s2 / sc - 1) < 1e-4 and abs(m2 - mn) < 1e-4 * abs(mn) + 1e-4
+        d = np.abs(got.astype(np.int32) - q.astype(np.int32))
+        assert (d <= 1).mean() >= 0.995 and d.max() <= 2
