@@ -1,0 +1,32 @@
+/*
+ * lrf_pack.h — C ABI of liblrf_pack.so: the reference's byte container for QMF factor sets, packed on host threads.
+ *
+ * Restates lrf/compression/utils.py:246-300 (combine_bytes: left fold of len32_be(p1) || p1 || p2),
+ * :354-390 (encode_matrix, mode "col": every column zlib-compressed at level 9 behind the JSON header
+ * {"num_fibers": R, "mode": "col", "dtype": "int8"}) and the stream layout of lrf/compression/qmf.py:288-290.
+ * Host memory only; zlib is the system libz (the one CPython's zlib module uses), so the bytes equal the reference's.
+ */
+#ifndef LRF_PACK_H
+#define LRF_PACK_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/*
+ * Packs B images.  Image b's factors: U + b*u_stride holds [M0,R0] [M1,R1] [M2,R2] int8 row-major back to back,
+ * V + b*v_stride three [64,R_c] matrices (the layout lrf_qmf_encode_rgb_u8 writes).  `metadata` is the UTF-8 JSON of
+ * the image metadata (identical for every image of the batch).  On return out[b] points to a malloc'ed stream of
+ * out_len[b] bytes (release with lrf_pack_free).  threads <= 0: one per hardware thread, at most 64.
+ * Returns 0, or a negative value (-1 bad argument, -4 out of memory, -5 zlib error).
+ */
+int lrf_pack_qmf_streams(const int8_t* U, int64_t u_stride, const int8_t* V, int64_t v_stride, int64_t B,
+                         const int64_t M[3], const int R[3], const char* metadata, int64_t metadata_len,
+                         int threads, uint8_t** out, int64_t* out_len);
+void lrf_pack_free(uint8_t* p);
+const char* lrf_pack_zlib_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -92,9 +92,70 @@ def pack_image(factors, image_hw, ranks, bounds, patch_size=(8, 8), dtype_name="
     return combine_bytes([dict_to_bytes(metadata), combine_bytes([encode_tensor(f) for f in factors])])
 
 
+_PACK_POOL = None
+_PACK_LIB = None
+
+
+def _pack_lib():
+    """liblrf_pack.so (include/lrf_pack.h): the same container built by native host threads."""
+    global _PACK_LIB
+    if _PACK_LIB is None:
+        import ctypes
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblrf_pack.so")
+        lib = ctypes.CDLL(path)
+        lib.lrf_pack_qmf_streams.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                             ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int), ctypes.c_char_p,
+                                             ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
+                                             ctypes.POINTER(ctypes.c_int64)]
+        lib.lrf_pack_free.argtypes = [ctypes.c_void_p]
+        lib.lrf_pack_free.restype = None
+        _PACK_LIB = lib
+    return _PACK_LIB
+
+
+def pack_streams_native(Uh: np.ndarray, Vh: np.ndarray, image_hw, ranks, bounds, patch_size=(8, 8), dtype_name="uint8",
+                        threads: int = 0) -> list:
+    """All images of a batch -> byte streams through liblrf_pack.so (byte-identical to pack_image)."""
+    import ctypes
+    H, W = image_hw
+    dims = _lib.plane_dims(H, W)
+    metadata = dict_to_bytes({
+        "dtype": dtype_name, "color space": "YCbCr", "patch": True, "bounds": bounds, "patch size": patch_size,
+        "original size": [[d[0], d[1]] for d in dims], "padded size": [[d[2], d[3]] for d in dims], "rank": list(ranks)})
+    Uh = np.ascontiguousarray(Uh, dtype=np.int8)
+    Vh = np.ascontiguousarray(Vh, dtype=np.int8)
+    B = Uh.shape[0]
+    M = (ctypes.c_int64 * 3)(*[d[4] for d in dims])
+    R = (ctypes.c_int * 3)(*[int(r) for r in ranks])
+    out = (ctypes.c_void_p * B)()
+    lens = (ctypes.c_int64 * B)()
+    rc = _pack_lib().lrf_pack_qmf_streams(Uh.ctypes.data_as(ctypes.c_void_p), Uh.shape[1], Vh.ctypes.data_as(ctypes.c_void_p),
+                                          Vh.shape[1], B, M, R, metadata, len(metadata), int(threads), out, lens)
+    if rc:
+        raise RuntimeError(f"lrf_pack_qmf_streams failed ({rc})")
+    streams = []
+    for b in range(B):
+        streams.append(ctypes.string_at(out[b], lens[b]))
+        _pack_lib().lrf_pack_free(out[b])
+    return streams
+
+
+def _pack_pool(workers):
+    """zlib releases the GIL, so the per-column zlib-9 packing of finished images scales over host threads
+    (SURVEY.md §8f N2); the streams stay byte-identical to the serial ones."""
+    global _PACK_POOL
+    from concurrent.futures import ThreadPoolExecutor
+    if _PACK_POOL is None or _PACK_POOL._max_workers != workers:
+        _PACK_POOL = ThreadPoolExecutor(max_workers=workers)
+    return _PACK_POOL
+
+
 def qmf_encode_batch(images: torch.Tensor, rank=None, quality=None, bounds=(-16, 15), num_iters: int = 10,
-                     init_sign=None) -> list:
-    """Batched qmf_encode (default branch) -> list of byte streams, one per image."""
+                     init_sign=None, pack_workers: Optional[int] = None) -> list:
+    """Batched qmf_encode (default branch) -> list of byte streams, one per image.  The factorisation of the whole batch
+    runs on the GPU; the byte containers are packed by liblrf_pack.so on native host threads (`pack_workers` = 0: one per
+    hardware thread), or, with pack_workers="python", by the Python container code on a thread pool."""
     assert (rank, quality) != (None, None), "Either 'rank' or 'quality' must be specified."
     ctx = _lib.context(images.device.index if images.is_cuda else None)
     dev = images if images.is_cuda else images.cuda(ctx.device)
@@ -103,8 +164,18 @@ def qmf_encode_batch(images: torch.Tensor, rank=None, quality=None, bounds=(-16,
     U, V = qmf_factorize_batch(dev, ranks, num_iters, bounds, init_sign)
     Uh, Vh = U.cpu().numpy(), V.cpu().numpy()
     dtype_name = str(images.dtype).split(".")[-1]
-    return [pack_image(split_factors(Uh[b], Vh[b], (H, W), ranks), (H, W), ranks, bounds, (8, 8), dtype_name)
-            for b in range(images.shape[0])]
+    if pack_workers != "python" and not (isinstance(pack_workers, int) and pack_workers < 0):
+        return pack_streams_native(Uh, Vh, (H, W), ranks, bounds, (8, 8), dtype_name, threads=pack_workers or 0)
+    pack_workers = None if pack_workers == "python" else -pack_workers
+
+    def pack(b):
+        return pack_image(split_factors(Uh[b], Vh[b], (H, W), ranks), (H, W), ranks, bounds, (8, 8), dtype_name)
+
+    import os
+    workers = pack_workers if pack_workers is not None else min(32, os.cpu_count() or 1)
+    if workers <= 1 or images.shape[0] == 1:
+        return [pack(b) for b in range(images.shape[0])]
+    return list(_pack_pool(workers).map(pack, range(images.shape[0])))
 
 
 def qmf_encode(image: torch.Tensor, rank=None, quality=None, color_space: str = "YCbCr",

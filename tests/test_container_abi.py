@@ -86,3 +86,25 @@ def test_unsupported_branches_raise():
         lrf_amd.qmf_encode(img, quality=7, color_space="RGB")
     with pytest.raises(NotImplementedError):
         lrf_amd.qmf_encode(img, quality=7, patch=False)
+
+
+def test_native_packer_matches_reference_streams():
+    """liblrf_pack.so (include/lrf_pack.h) rebuilds the reference's byte streams from their own factors, and exports
+    what its header declares."""
+    import ctypes
+
+    from lrf_amd.codec import pack_streams_native, parse_stream
+    header = open(os.path.join(ROOT, "include", "lrf_pack.h")).read()
+    declared = set(re.findall(r"\b(lrf_pack_[a-z0-9_]+)\s*\(", header))
+    lib = ctypes.CDLL(os.path.join(ROOT, "lrf_amd", "liblrf_pack.so"))
+    assert declared == {"lrf_pack_qmf_streams", "lrf_pack_free", "lrf_pack_zlib_version"}
+    for name in declared:
+        assert hasattr(lib, name)
+    for name in ("s1_r7", "odd_q7", "tiny_rank1", "tiny_q20", "zero_q7", "nat_q7"):
+        case = Case(name)
+        meta, fac = parse_stream(case.encoded)
+        U = np.concatenate([f.ravel() for f in fac[0::2]])[None]
+        V = np.concatenate([f.ravel() for f in fac[1::2]])[None]
+        U3, V3 = np.repeat(U, 3, 0), np.repeat(V, 3, 0)
+        out = pack_streams_native(U3, V3, case.image.shape[-2:], meta["rank"], meta["bounds"], meta["patch size"], threads=2)
+        assert out == [case.encoded] * 3

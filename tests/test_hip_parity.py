@@ -302,3 +302,14 @@ def test_svd_baseline_against_reference(name, oracle):
     assert np.all(np.abs(sig / ref_sig - 1) < 2e-2)  # through uint8 quantisation; the fp32 factors themselves are checked below
     ou, ov = oracle.svd_topr(X, gu.shape[1], sign)
     assert np.all(np.abs((ov.astype(np.float64) ** 2).sum(0) / ref_sig - 1) < 1e-4)
+
+
+def test_threaded_packing_is_byte_identical():
+    import lrf_amd
+    g = torch.Generator().manual_seed(9)
+    imgs = torch.randint(0, 256, (12, 3, 64, 64), dtype=torch.uint8, generator=g)
+    a = lrf_amd.qmf_encode_batch(imgs, rank=4, pack_workers="python")   # Python container code, thread pool
+    b = lrf_amd.qmf_encode_batch(imgs, rank=4, pack_workers=4)          # liblrf_pack.so, 4 native threads
+    c = lrf_amd.qmf_encode_batch(imgs, rank=4)                          # liblrf_pack.so, one thread per core
+    assert a == b == c and len(a) == 12
+    assert a[3] == lrf_amd.qmf_encode(imgs[3], rank=4)
