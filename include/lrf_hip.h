@@ -38,7 +38,7 @@ extern "C" {
 #define LRF_EHIP (-3)        /* a HIP runtime call failed; see lrf_last_error() */
 #define LRF_ENOMEM (-4)
 
-#define LRF_MAX_RANK 16      /* largest rank the BCD kernels take in this build */
+#define LRF_MAX_RANK 64      /* largest rank (ranks above 16 run on the untuned big-rank kernels) */
 #define LRF_PATCH_ELEMS 64   /* N = p*q handled by the kernels in this build (8x8 patches) */
 
 typedef struct lrf_ctx lrf_ctx;

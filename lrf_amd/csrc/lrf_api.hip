@@ -13,6 +13,7 @@
 #include "../../include/lrf_hip.h"
 #include "lrf_kernels.hip"
 #include "lrf_svd_kernels.hip"
+#include "lrf_bigrank_kernels.hip"
 
 static thread_local char g_err[512] = "";
 
@@ -207,6 +208,15 @@ static int check_params(int64_t M, int64_t N, int R, int K, int lo, int hi)
     return LRF_OK;
 }
 
+// padded rank of the V / W / partial tables: 16 (one MFMA tile, the tuned kernels) or 64 (lrf_bigrank_kernels.hip)
+static int table_rmax(const Tables& t)
+{
+    int rmax = 1;
+    for (const PlaneDesc& pd : t.planes) rmax = pd.R > rmax ? pd.R : rmax;
+    return rmax;
+}
+static int table_rp(const Tables& t) { return table_rmax(t) <= 16 ? 16 : LRF_RPB; }
+
 static int upload_tables(lrf_ctx* c, const Tables& t)
 {
     // the tables only depend on the call's geometry: skip the (synchronising) upload when nothing changed
@@ -221,11 +231,12 @@ static int upload_tables(lrf_ctx* c, const Tables& t)
     rc = upload(c, c->blocks, t.blocks.data(), bb);
     if (rc) return rc;
     size_t np = t.planes.size(), nb = t.blocks.size();
-    if ((rc = ensure(c, c->vf, np * 64 * LRF_RP * sizeof(float)))) return rc;
-    if ((rc = ensure(c, c->wf, np * 64 * LRF_RP * sizeof(float)))) return rc;
-    if ((rc = ensure(c, c->bf, np * LRF_GT_STRIDE * sizeof(float)))) return rc;
-    if ((rc = ensure(c, c->ppart, nb * 64 * LRF_RP * sizeof(float)))) return rc;
-    if ((rc = ensure(c, c->qpart, nb * LRF_RP * LRF_RP * sizeof(float)))) return rc;
+    size_t rp = (size_t)table_rp(t), gts = rp == 16 ? (size_t)LRF_GT_STRIDE : (size_t)LRF_GTB_STRIDE;
+    if ((rc = ensure(c, c->vf, np * 64 * rp * sizeof(float)))) return rc;
+    if ((rc = ensure(c, c->wf, np * 64 * rp * sizeof(float)))) return rc;
+    if ((rc = ensure(c, c->bf, np * gts * sizeof(float)))) return rc;
+    if ((rc = ensure(c, c->ppart, nb * 64 * rp * sizeof(float)))) return rc;
+    if ((rc = ensure(c, c->qpart, nb * rp * rp * sizeof(float)))) return rc;
     c->table_key.swap(key);
     return LRF_OK;
 }
@@ -238,17 +249,18 @@ static int run_init(lrf_ctx* c, const float* X, const Tables& t, const int8_t* s
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_init<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InitLds<8>)));
         HIP_TRY(hipFuncSetAttribute((const void*)k_init<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InitLds<16>)));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_init<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InitLds<64>)));
         attr_set = true;
     }
-    int rmax = 1, nplanes = (int)t.planes.size();
-    for (const PlaneDesc& pd : t.planes) rmax = pd.R > rmax ? pd.R : rmax;
+    int rmax = table_rmax(t), rp = table_rp(t), nplanes = (int)t.planes.size();
     Prof p(c, LRF_K_INIT);
-    if (rmax <= 8)
-        hipLaunchKernelGGL(k_init<8>, dim3(nplanes), dim3(256), sizeof(InitLds<8>), c->stream, X, (const PlaneDesc*)c->planes.p,
-                           sign_dev, (float*)c->vf.p, (float*)c->wf.p, c->init_sweeps);
-    else
-        hipLaunchKernelGGL(k_init<16>, dim3(nplanes), dim3(256), sizeof(InitLds<16>), c->stream, X, (const PlaneDesc*)c->planes.p,
-                           sign_dev, (float*)c->vf.p, (float*)c->wf.p, c->init_sweeps);
+#define LRF_LAUNCH_INIT(ZR)                                                                                          \
+    hipLaunchKernelGGL(k_init<ZR>, dim3(nplanes), dim3(256), sizeof(InitLds<ZR>), c->stream, X, (const PlaneDesc*)c->planes.p, \
+                       sign_dev, (float*)c->vf.p, (float*)c->wf.p, c->init_sweeps, rp)
+    if (rmax <= 8) LRF_LAUNCH_INIT(8);
+    else if (rmax <= 16) LRF_LAUNCH_INIT(16);
+    else LRF_LAUNCH_INIT(64);
+#undef LRF_LAUNCH_INIT
     LAUNCH_CHECK();
     return LRF_OK;
 }
@@ -264,10 +276,14 @@ static GsParams make_gs(int lo, int hi)
     return gp;
 }
 
-static int run_bprep(lrf_ctx* c, int nplanes)
+static int run_bprep(lrf_ctx* c, int nplanes, int rp)
 {
-    hipLaunchKernelGGL(k_bprep, dim3(nplanes), dim3(256), 0, c->stream, (const PlaneDesc*)c->planes.p, (const float*)c->vf.p,
-                       (float*)c->bf.p);
+    if (rp == 16)
+        hipLaunchKernelGGL(k_bprep, dim3(nplanes), dim3(256), 0, c->stream, (const PlaneDesc*)c->planes.p, (const float*)c->vf.p,
+                           (float*)c->bf.p);
+    else
+        hipLaunchKernelGGL(k_bprep_big, dim3(nplanes), dim3(256), 0, c->stream, (const PlaneDesc*)c->planes.p,
+                           (const float*)c->vf.p, (float*)c->bf.p);
     LAUNCH_CHECK();
     return LRF_OK;
 }
@@ -285,17 +301,33 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
     float* qp = (float*)c->qpart.p;
     int nb = (int)t.blocks.size(), np = (int)t.planes.size();
     GsParams gp = make_gs(lo, hi);
-    int rmax = 1;
-    for (const PlaneDesc& pd : t.planes) rmax = pd.R > rmax ? pd.R : rmax;
-    int rc = run_bprep(c, np);
+    int rmax = table_rmax(t), rp = table_rp(t);
+    int rc = run_bprep(c, np, rp);
     if (rc) return rc;
+    if (rp != 16) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_big<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BigLds)));
+            HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_big<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BigLds)));
+            HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_big<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BigLds)));
+            HIP_TRY(hipFuncSetAttribute((const void*)k_vupdate_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BigVLds)));
+            attr_set = true;
+        }
+    }
     for (int it = 0; it < K; it++) {
         {
             Prof p(c, LRF_K_BCD);
             int mode = (it == 0) ? first_mode : 0;
 #define LRF_LAUNCH_BCD(MODE, RMAX)                                                                                   \
     hipLaunchKernelGGL((k_bcd<MODE, RMAX>), dim3(nb), dim3(256), 0, c->stream, X, pl, bl, vf, wf, bf, U0, U, pp, qp, gp)
-            if (rmax <= 8) {
+#define LRF_LAUNCH_BIG(MODE)                                                                                         \
+    hipLaunchKernelGGL((k_bcd_big<MODE>), dim3(nb), dim3(256), sizeof(BigLds), c->stream, X, pl, bl, vf, wf, bf, U0, U, pp, qp, \
+                       gp.lo, gp.hi)
+            if (rp != 16) {
+                if (mode == 1) LRF_LAUNCH_BIG(1);
+                else if (mode == 2) LRF_LAUNCH_BIG(2);
+                else LRF_LAUNCH_BIG(0);
+            } else if (rmax <= 8) {
                 if (mode == 1) LRF_LAUNCH_BCD(1, 8);
                 else if (mode == 2) LRF_LAUNCH_BCD(2, 8);
                 else LRF_LAUNCH_BCD(0, 8);
@@ -305,16 +337,21 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
                 else LRF_LAUNCH_BCD(0, 16);
             }
 #undef LRF_LAUNCH_BCD
+#undef LRF_LAUNCH_BIG
             LAUNCH_CHECK();
         }
         {
             Prof p(c, LRF_K_VUPDATE);
-            if (rmax <= 8)
+            int last = it == K - 1 ? 1 : 0;
+            if (rp != 16)
+                hipLaunchKernelGGL(k_vupdate_big, dim3(np), dim3(256), sizeof(BigVLds), c->stream, pl, (const float*)pp,
+                                   (const float*)qp, vf, bf, V, gp.lo, gp.hi, last);
+            else if (rmax <= 8)
                 hipLaunchKernelGGL(k_vupdate<8>, dim3(np), dim3(256), 0, c->stream, pl, (const float*)pp, (const float*)qp, vf, bf,
-                                   V, gp, it == K - 1 ? 1 : 0);
+                                   V, gp, last);
             else
                 hipLaunchKernelGGL(k_vupdate<16>, dim3(np), dim3(256), 0, c->stream, pl, (const float*)pp, (const float*)qp, vf,
-                                   bf, V, gp, it == K - 1 ? 1 : 0);
+                                   bf, V, gp, last);
             LAUNCH_CHECK();
         }
     }
@@ -521,7 +558,7 @@ int lrf_qmf_bcd_f32(lrf_ctx* c, const float* X, int64_t B, int64_t M, int64_t N,
     uniform_tables(t, B, M, R, false);
     if ((rc = upload_tables(c, t))) return rc;
     hipLaunchKernelGGL(k_load_v0, dim3((unsigned)t.planes.size()), dim3(256), 0, c->stream, (const PlaneDesc*)c->planes.p, V0,
-                       (float*)c->vf.p);
+                       (float*)c->vf.p, table_rp(t));
     LAUNCH_CHECK();
     return run_bcd(c, X, t, K, lo, hi, 2, U0, U, V);
 }
@@ -539,7 +576,7 @@ int lrf_qmf_svd_init_f32(lrf_ctx* c, const float* X, int64_t B, int64_t M, int64
     if ((rc = upload_tables(c, t))) return rc;
     if ((rc = run_init(c, X, t, sign))) return rc;
     hipLaunchKernelGGL(k_emit_init, dim3((unsigned)t.blocks.size()), dim3(256), 0, c->stream, X, (const PlaneDesc*)c->planes.p,
-                       (const BlockDesc*)c->blocks.p, (const float*)c->vf.p, (const float*)c->wf.p, U0, V0);
+                       (const BlockDesc*)c->blocks.p, (const float*)c->vf.p, (const float*)c->wf.p, U0, V0, table_rp(t));
     LAUNCH_CHECK();
     return LRF_OK;
 }

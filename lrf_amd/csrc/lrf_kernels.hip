@@ -156,7 +156,7 @@ struct InitLds {
     double D2[64 * ZR];
     double Z[ZR * 64];      // eigenvectors in tridiagonal coordinates, then in the original basis
     double cpart[4 * 64];   // matvec partial chains
-    double v[64], w[64], d[64], e[64], e2[64], tau[64], lam[16];
+    double v[64], w[64], d[64], e[64], e2[64], tau[64], lam[ZR < 16 ? 16 : ZR];
     double scal[8];         // [0] t, [1] pivmin, [2] lo, [3] hi
     int flag[4];
 };
@@ -164,7 +164,7 @@ struct InitLds {
 template <int ZR>
 __global__ __launch_bounds__(256) void k_init(const float* __restrict__ X, const PlaneDesc* __restrict__ planes,
                                               const int8_t* __restrict__ sign, float* __restrict__ Vf,
-                                              float* __restrict__ Wf, int debug_stop)
+                                              float* __restrict__ Wf, int debug_stop, int rp)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     InitLds<ZR>& L = *reinterpret_cast<InitLds<ZR>*>(smem);
@@ -433,10 +433,10 @@ __global__ __launch_bounds__(256) void k_init(const float* __restrict__ X, const
     __syncthreads();
 
     // ---- back-transformation x <- H_0 ... H_61 x, sign, scaling, output: one wave per vector
-    float* Vp = Vf + (long)blockIdx.x * 64 * LRF_RP;
-    float* Wp = Wf + (long)blockIdx.x * 64 * LRF_RP;
-    for (int i = tid; i < 64 * LRF_RP; i += 256) {
-        if ((i & (LRF_RP - 1)) >= Rc) { Vp[i] = 0.f; Wp[i] = 0.f; } // padding and the r >= min(M,N) columns
+    float* Vp = Vf + (long)blockIdx.x * 64 * rp; // rp: padded rank (row pitch) of the V / W tables, a power of two
+    float* Wp = Wf + (long)blockIdx.x * 64 * rp;
+    for (int i = tid; i < 64 * rp; i += 256) {
+        if ((i & (rp - 1)) >= Rc) { Vp[i] = 0.f; Wp[i] = 0.f; } // padding and the r >= min(M,N) columns
     }
     for (int r = wave; r < Rc; r += 4) {
         const int i = lane;
@@ -458,8 +458,8 @@ __global__ __launch_bounds__(256) void k_init(const float* __restrict__ X, const
         double want = sg ? (double)sg : -1.0;
         double flip = ((dot < 0.0 ? -1.0 : 1.0) == want) ? 1.0 : -1.0;
         double ev = flip * x;
-        Vp[i * LRF_RP + r] = (float)(ev * sr);
-        Wp[i * LRF_RP + r] = (sr > 0.0) ? (float)(ev / sr) : 0.f;
+        Vp[i * rp + r] = (float)(ev * sr);
+        Wp[i * rp + r] = (sr > 0.0) ? (float)(ev / sr) : 0.f;
     }
 }
 
@@ -922,13 +922,13 @@ __global__ __launch_bounds__(256) void k_vupdate(const PlaneDesc* __restrict__ p
     if (!write_i8) make_gtable(v_s, 64, R, Bf + (long)blockIdx.x * LRF_GT_STRIDE, tid, 256);
 }
 
-// loads caller-supplied fp32 V0 [B][64][R] into the padded Vf table (lrf_qmf_bcd_f32)
-__global__ void k_load_v0(const PlaneDesc* __restrict__ planes, const float* __restrict__ V0, float* __restrict__ Vf)
+// loads caller-supplied fp32 V0 [B][64][R] into the padded Vf table (lrf_qmf_bcd_f32); rp = padded rank
+__global__ void k_load_v0(const PlaneDesc* __restrict__ planes, const float* __restrict__ V0, float* __restrict__ Vf, int rp)
 {
     const PlaneDesc pd = planes[blockIdx.x];
-    for (int i = threadIdx.x; i < 64 * LRF_RP; i += blockDim.x) {
-        int j = i / LRF_RP, r = i - j * LRF_RP;
-        Vf[(long)blockIdx.x * 64 * LRF_RP + i] = (r < pd.R) ? V0[pd.v0_off + (long)j * pd.R + r] : 0.f;
+    for (int i = threadIdx.x; i < 64 * rp; i += blockDim.x) {
+        int j = i / rp, r = i - j * rp;
+        Vf[(long)blockIdx.x * 64 * rp + i] = (r < pd.R) ? V0[pd.v0_off + (long)j * pd.R + r] : 0.f;
     }
 }
 
@@ -936,25 +936,25 @@ __global__ void k_load_v0(const PlaneDesc* __restrict__ planes, const float* __r
 __global__ __launch_bounds__(256) void k_emit_init(const float* __restrict__ X, const PlaneDesc* __restrict__ planes,
                                                    const BlockDesc* __restrict__ blocks, const float* __restrict__ Vf,
                                                    const float* __restrict__ Wf, float* __restrict__ U0,
-                                                   float* __restrict__ V0)
+                                                   float* __restrict__ V0, int rp)
 {
     const BlockDesc bd = blocks[blockIdx.x];
     const PlaneDesc pd = planes[bd.plane];
     const int R = pd.R;
     int nrows = pd.M - bd.row0;
     if (nrows > LRF_KC) nrows = LRF_KC;
-    const float* Wp = Wf + (long)bd.plane * 64 * LRF_RP;
+    const float* Wp = Wf + (long)bd.plane * 64 * rp;
     for (int i = threadIdx.x; i < nrows * R; i += 256) {
         int m = i / R, r = i - m * R;
         const float* x = X + pd.x_off + (long)(bd.row0 + m) * 64;
         float acc = 0.f;
-        for (int k = 0; k < 64; k++) acc = fmaf(x[k], Wp[k * LRF_RP + r], acc);
+        for (int k = 0; k < 64; k++) acc = fmaf(x[k], Wp[k * rp + r], acc);
         U0[pd.u0_off + (long)(bd.row0 + m) * R + r] = acc;
     }
     if (bd.blk == 0)
         for (int i = threadIdx.x; i < 64 * R; i += 256) {
             int j = i / R, r = i - j * R;
-            V0[pd.v0_off + i] = Vf[(long)bd.plane * 64 * LRF_RP + j * LRF_RP + r];
+            V0[pd.v0_off + i] = Vf[(long)bd.plane * 64 * rp + j * rp + r];
         }
 }
 

@@ -153,7 +153,7 @@ def gen_sweep():
     spec = dict(kind="smooth", seed=21, H=128, W=192)
     img = make_image(spec)
     out = {"spec": spec, "records": []}
-    for q in (1, 2, 3.5, 5, 7, 10, 12.5, 15, 20, 25):
+    for q in (1, 2, 3.5, 5, 7, 10, 12.5, 15, 20, 25, 32, 40, 60):
         enc = ns.cqmf.qmf_encode(img, quality=q)
         dec = ns.cqmf.qmf_decode(enc)
         mse = torch.mean((img.float() - dec.float()) ** 2, dim=(-3, -2, -1))
