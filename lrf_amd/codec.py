@@ -41,8 +41,8 @@ def _check_hip_branch(color_space, scale_factor, patch, patch_size, bounds, dtyp
              not (k == "eps" and v == 1e-16)}
     if extra:
         raise NotImplementedError(f"QMF options {sorted(extra)} are not on the HIP path")
-    if num_iters < 1:
-        raise NotImplementedError("num_iters=0 (float SVD factors cast to int8) is not on the HIP path")
+    if num_iters < 0:
+        raise ValueError("num_iters must be >= 0")
     lo, hi = math.ceil(bounds[0]), math.floor(bounds[1])
     return num_iters, lo, hi, init_sign
 
@@ -193,9 +193,30 @@ def qmf_encode(image: torch.Tensor, rank=None, quality=None, color_space: str = 
     ranks = qmf_ranks((H, W), rank, quality)
     ctx = _lib.context(image.device.index if image.is_cuda else None)
     dev = (image if image.is_cuda else image.cuda(ctx.device)).unsqueeze(0)
-    U, V = qmf_factorize_batch(dev, ranks, num_iters, (lo, hi), init_sign)
-    factors = split_factors(U[0].cpu().numpy(), V[0].cpu().numpy(), (H, W), ranks)
+    if num_iters == 0:
+        factors = _svd_init_factors(ctx, dev, ranks, init_sign)
+    else:
+        U, V = qmf_factorize_batch(dev, ranks, num_iters, (lo, hi), init_sign)
+        factors = split_factors(U[0].cpu().numpy(), V[0].cpu().numpy(), (H, W), ranks)
     return pack_image(factors, (H, W), ranks, bounds, patch_size, str(image.dtype).split(".")[-1])
+
+
+def _svd_init_factors(ctx, dev, ranks, init_sign):
+    """num_iters=0 (experiments/ablation_numiters/eval.py:51): the float SVD factors go straight through `.to(int8)`
+    (lrf/compression/qmf.py:258-260), i.e. torch's truncating cast, done here with torch itself on the host."""
+    H, W = dev.shape[-2:]
+    X = ctx.planes_from_rgb(dev)[0]
+    factors, off, soff = [], 0, 0
+    for (_, _, _, _, M), R in zip(_lib.plane_dims(H, W), ranks):
+        x = X[off:off + M * 64].reshape(1, M, 64)
+        off += M * 64
+        sign = None
+        if init_sign is not None:
+            sign = torch.as_tensor(init_sign, dtype=torch.int8).reshape(-1)[soff:soff + R].reshape(1, R).contiguous().cuda(dev.device)
+        soff += R
+        u0, v0 = ctx.svd_init(x, R, sign)
+        factors += [u0[0].cpu().to(torch.int8).numpy(), v0[0].cpu().to(torch.int8).numpy()]
+    return factors
 
 
 def parse_stream(encoded_image: bytes):
