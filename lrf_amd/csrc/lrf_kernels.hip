@@ -24,7 +24,15 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 // Diagnostic build only (-DLRF_STAMPS, never shipped): per-phase cycle sums of k_bcd, wave 0 of each workgroup.
 #ifdef LRF_STAMPS
 __device__ unsigned long long g_stamps[8 * 16384];
-#define STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime()
+__device__ __forceinline__ unsigned long long stamp_now()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define STAMP(var) unsigned long long var = stamp_now()
 #define STAMP_ADD(acc, a, b) acc += (b) - (a)
 #else
 #define STAMP(var)
@@ -140,11 +148,43 @@ __global__ __launch_bounds__(256) void k_planes(const uint8_t* __restrict__ rgb,
 // ------------------------------------------------------------------------------------------------
 // tree64 of the oracle: lane i ends with s[i] + s[i+off] for off = 32..1; lane 0 holds the result,
 // which is broadcast.  (Lanes >= off compute unused values.)
+// The partner fetches of the tree without the LDS crossbar: lane i needs lane i + off.
+//   off = 32: v_permlane32_swap (upper half of one register <-> lower half of the other)
+//   off = 16: v_permlane16_swap (odd 16-lane rows <-> even rows)
+//   off <= 8: DPP row_shl inside the 16-lane row
+// Only lanes < off need a correct partner, which is exactly what these give; lane 0 ends with the tree sum.
+__device__ __forceinline__ double partner_32(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(b[1], a[1]); // second result: lanes 0-31 hold the former lanes 32-63
+}
+__device__ __forceinline__ double partner_16(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double(b[1], a[1]); // second result: even rows hold the former odd rows
+}
+template <int OFF>
+__device__ __forceinline__ double partner_row(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x100 + OFF, 0xf, 0xf, true); // row_shl:OFF -> lane i reads lane i + OFF
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x100 + OFF, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_tree64(double v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_down(v, off, 64);
-    return __shfl(v, 0, 64);
+    v = v + partner_32(v);
+    v = v + partner_16(v);
+    v = v + partner_row<8>(v);
+    v = v + partner_row<4>(v);
+    v = v + partner_row<2>(v);
+    v = v + partner_row<1>(v);
+    int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
 }
 
 // LDS carve of k_init; ZR = 8 or 16 eigenvectors' worth of scratch (chosen on the host from the largest rank
