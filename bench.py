@@ -73,11 +73,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs a GPU"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # LRF_BENCH_REHEARSAL=1: development aid for boxes with fewer GPUs than ranks — ranks share the visible GPUs and the
+    # (tiny) collectives run over gloo, because RCCL refuses two ranks on one device.  Never set by the driver.
+    rehearsal = os.environ.get("LRF_BENCH_REHEARSAL") == "1"
+    dev_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    cdev = torch.device("cpu") if rehearsal else dev  # where the collective payloads live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import lrf_amd
     from lrf_amd import _lib
@@ -88,7 +96,7 @@ def main():
     dims = _lib.plane_dims(H, W)
     U = torch.empty((B, sum(d[4] * r for d, r in zip(dims, RANKS))), dtype=torch.int8, device=dev)
     V = torch.empty((B, 64 * sum(RANKS)), dtype=torch.int8, device=dev)
-    ctx = _lib.context(local_rank)
+    ctx = _lib.context(dev_index)
 
     def step():
         lrf_amd.qmf_factorize_batch(images, RANKS, NUM_ITERS, BOUNDS, out=(U, V))
@@ -111,10 +119,10 @@ def main():
     dt = time.perf_counter() - t0
     ctx.profile(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        stats = torch.tensor([float(B * H * W * args.steps), dt], dtype=torch.float64, device=dev)
+        stats = torch.tensor([float(B * H * W * args.steps), dt], dtype=torch.float64, device=cdev)
         gathered = [torch.zeros_like(stats) for _ in range(world)]
         dist.all_gather(gathered, stats)  # final metrics gather (the only payload collective)
         total_px = sum(float(s[0]) for s in gathered)
