@@ -1,13 +1,13 @@
 """eval_compression — the reference's per-image evaluation protocol (lrf/utils/misc.py:59-121) for this path:
-one encode call and one decode call, wall-clock milliseconds each, then compression ratio, bpp and PSNR.
-SSIM needs skimage (absent here) and is reported as None."""
+one encode call and one decode call, wall-clock milliseconds each, then compression ratio, bpp, PSNR and SSIM
+(metrics.ssim restates scikit-image's algorithm; scikit-image itself is absent from this image)."""
 import time
 from typing import Callable
 
 import numpy as np
 import torch
 
-from .metrics import bits_per_pixel, compression_ratio, psnr
+from .metrics import bits_per_pixel, compression_ratio, psnr, ssim
 
 
 def _sync():
@@ -33,7 +33,7 @@ def eval_compression(image, encoder: Callable, decoder: Callable, reconstruct: b
         "compression ratio": compression_ratio(image, encoded),
         "bit rate (bpp)": bits_per_pixel(image.shape[-2:], encoded),
         "PSNR (dB)": psnr(image, reconstructed).item(),
-        "SSIM": None,
+        "SSIM": ssim(image, reconstructed).item(),
         "encoding time (ms)": encoding_time,
         "decoding time (ms)": decoding_time,
     }

@@ -108,3 +108,33 @@ def test_native_packer_matches_reference_streams():
         U3, V3 = np.repeat(U, 3, 0), np.repeat(V, 3, 0)
         out = pack_streams_native(U3, V3, case.image.shape[-2:], meta["rank"], meta["bounds"], meta["patch size"], threads=2)
         assert out == [case.encoded] * 3
+
+
+def test_ssim_matches_direct_window_statistics():
+    """metrics.ssim against a direct evaluation of the SSIM definition on every full 7x7 window (the cropped region
+    never touches the border, so the filter's border mode drops out) — and its defining properties."""
+    import numpy as np
+    import torch
+    from numpy.lib.stride_tricks import sliding_window_view
+
+    from lrf_amd.metrics import ssim
+
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 256, (3, 24, 31), dtype=np.uint8)
+    b = np.clip(a.astype(np.int32) + rng.integers(-20, 21, a.shape), 0, 255).astype(np.uint8)
+    rng_a = float(a.max() - a.min())
+    c1, c2 = (0.01 * rng_a) ** 2, (0.03 * rng_a) ** 2
+    vals = []
+    for x, y in zip(a.astype(np.float64), b.astype(np.float64)):
+        wx = sliding_window_view(x, (7, 7)).reshape(-1, 49)
+        wy = sliding_window_view(y, (7, 7)).reshape(-1, 49)
+        ux, uy = wx.mean(1), wy.mean(1)
+        vx, vy = wx.var(1, ddof=1), wy.var(1, ddof=1)
+        vxy = ((wx - ux[:, None]) * (wy - uy[:, None])).sum(1) / 48.0
+        vals.append((((2 * ux * uy + c1) * (2 * vxy + c2)) / ((ux * ux + uy * uy + c1) * (vx + vy + c2))).mean())
+    got = ssim(torch.from_numpy(a), torch.from_numpy(b)).item()
+    assert abs(got - float(np.mean(vals))) < 1e-9
+    assert abs(ssim(torch.from_numpy(a), torch.from_numpy(a)).item() - 1.0) < 1e-12
+    assert got < 1.0
+    with pytest.raises(ValueError):
+        ssim(torch.zeros(3, 4, 4), torch.zeros(3, 4, 4))
