@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#define XS_LD 66 // LDS row stride (dwords) of the X sub-tile: conflict-free B-operand reads
 #define LRF_RPB 64                      // padded rank
 #define LRF_GTB_LD 68                   // gt table pitch: <= 63 `bb` entries, [64] = 1/den (unused here), [65] = den
 #define LRF_GTB_DEN 65

@@ -34,9 +34,17 @@ __device__ __forceinline__ unsigned long long stamp_now()
 }
 #define STAMP(var) unsigned long long var = stamp_now()
 #define STAMP_ADD(acc, a, b) acc += (b) - (a)
+__device__ unsigned long long g_gsp[4 * 16384];
+#ifndef LRF_GS_PROBE
+#define LRF_GS_PROBE 0
+#endif
+static constexpr int getenv_probe_dummy = LRF_GS_PROBE;
+#define GSP_ADD(slot, a, b)                                                                     \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 16384) atomicAdd(&g_gsp[4 * blockIdx.x + (slot)], (b) - (a))
 #else
 #define STAMP(var)
 #define STAMP_ADD(acc, a, b)
+#define GSP_ADD(slot, a, b)
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -569,6 +577,12 @@ __device__ __forceinline__ bool gs_row(const float* a, float* u, const float* __
         rden[r] = gt[r * LRF_GT_LD + LRF_GT_RDEN];
         den[r] = gt[r * LRF_GT_LD + LRF_GT_DEN];
     }
+#ifdef LRF_STAMPS
+    STAMP(gq0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    STAMP(gq1);
+    if (!EXACT) GSP_ADD(1, gq0, gq1);
+#endif
     bool unsafe = false;
 #pragma unroll
     for (int r = 0; r < R; r++) {
@@ -590,6 +604,11 @@ __device__ __forceinline__ bool gs_row(const float* a, float* u, const float* __
         }
         u[r] = fminf(fmaxf(val, gp.lo), gp.hi);
     }
+#ifdef LRF_STAMPS
+    asm volatile("" ::"v"(u[R - 1]));
+    STAMP(gq2);
+    if (!EXACT) GSP_ADD(2, gq1, gq2);
+#endif
     return unsafe;
 }
 
@@ -607,6 +626,12 @@ __device__ __forceinline__ void gs_row_lds(const float* a_row, float* u_row, con
         u0[r] = FROM_I8 ? (float)uold_row[r] : u_row[r];
         u[r] = u0[r];
     }
+#ifdef LRF_STAMPS
+    STAMP(gl0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    STAMP(gl1);
+    GSP_ADD(0, gl0, gl1);
+#endif
     bool unsafe = native ? gs_row<R, true, false>(a, u, gt, gp) : gs_row<R, false, false>(a, u, gt, gp);
     if (__any(unsafe)) { // rare (about one wave in a few hundred): redo with the reference's IEEE division
 #pragma unroll
@@ -614,6 +639,10 @@ __device__ __forceinline__ void gs_row_lds(const float* a_row, float* u_row, con
         if (native) gs_row<R, true, true>(a, u, gt, gp);
         else gs_row<R, false, true>(a, u, gt, gp);
     }
+#ifdef LRF_STAMPS
+    STAMP(gl2);
+    GSP_ADD(3, gl1, gl2);
+#endif
     float o[LRF_RP];
 #pragma unroll
     for (int r = 0; r < LRF_RP; r++) o[r] = (r < R) ? u[r < R ? r : 0] : 0.f;
@@ -675,12 +704,28 @@ __global__ __launch_bounds__(256) void k_bprep(const PlaneDesc* __restrict__ pla
 // ------------------------------------------------------------------------------------------------
 // K3: one BCD half-iteration over X: U update (row local) fused with the partials of the following V
 // update, a' = X^T U (fp32 chain over the block's rows) and b' = U^T U (exact).  One workgroup (4 waves)
-// per (matrix, 384-row block); 64-row sub-tiles staged through LDS, the next sub-tile prefetched into
-// registers while the current one is processed.
+// per (matrix, 384-row block), six 64-row sub-tiles.
+// The row-major MFMA operand (a = X V: lane = row) comes straight from global memory: float4 loads one
+// sub-tile ahead, then a 4x4 transpose across the four 16-lane rows with v_permlane16_swap /
+// v_permlane32_swap.  The same registers are then stored to LDS (XOR-swizzled, conflict-free both ways)
+// in the shadow of the Gauss-Seidel, for the transposed operand of a' = X^T U.
 // MODE 0: old U from int8 (iterations >= 2); MODE 1: first iteration, old U = X @ W0 computed here;
 // MODE 2: first iteration, old U = caller's fp32 U0.
 // ------------------------------------------------------------------------------------------------
-#define XS_LD 66 // LDS row stride (dwords) of the X sub-tile: conflict-free B-operand reads
+// 4x4 transpose between the four 16-lane rows of a wave and the four components of c:
+// in: component i of lane row j = M[j][i]; out: component t of lane row j = M[t][j].
+__device__ __forceinline__ void rows_transpose4(f32x4& c)
+{
+    unsigned c0 = __float_as_uint(c[0]), c1 = __float_as_uint(c[1]), c2 = __float_as_uint(c[2]), c3 = __float_as_uint(c[3]);
+    auto s01 = __builtin_amdgcn_permlane16_swap(c0, c1, false, false); // c0.row1 <-> c1.row0, c0.row3 <-> c1.row2
+    auto s23 = __builtin_amdgcn_permlane16_swap(c2, c3, false, false);
+    auto s02 = __builtin_amdgcn_permlane32_swap(s01[0], s23[0], false, false); // upper half of the first <-> lower half of the second
+    auto s13 = __builtin_amdgcn_permlane32_swap(s01[1], s23[1], false, false);
+    c[0] = __uint_as_float(s02[0]);
+    c[1] = __uint_as_float(s13[0]);
+    c[2] = __uint_as_float(s02[1]);
+    c[3] = __uint_as_float(s13[1]);
+}
 
 template <int MODE, int RMAX>
 __global__ __launch_bounds__(256) void k_bcd(const float* __restrict__ X, const PlaneDesc* __restrict__ planes,
@@ -689,7 +734,9 @@ __global__ __launch_bounds__(256) void k_bcd(const float* __restrict__ X, const 
                                              const float* __restrict__ U0, int8_t* __restrict__ U,
                                              float* __restrict__ Ppart, float* __restrict__ Qpart, GsParams gp)
 {
-    __shared__ __attribute__((aligned(16))) float Xs[64 * XS_LD];
+    // X sub-tile for the a' = X^T U operand: element (m, n) at m * 64 + (n ^ xs_swz(m)); both the dword stores
+    // (lane = row m, 4 columns apart) and the dword loads (lane = column n, 4 rows) touch 32 distinct banks per half wave
+    __shared__ __attribute__((aligned(16))) float Xs[64 * 64];
     __shared__ __attribute__((aligned(16))) float a_s[64 * LRF_RP];
     __shared__ __attribute__((aligned(16))) float u_s[64 * LRF_RP];
     __shared__ __attribute__((aligned(16))) int8_t uold_s[64 * LRF_RP];
@@ -720,43 +767,33 @@ __global__ __launch_bounds__(256) void k_bcd(const float* __restrict__ X, const 
         if (MODE == 1) wa_s[s_ * 64 + lane] = Wf[(long)bd.plane * 64 * LRF_RP + (4 * s_ + lq) * LRF_RP + li];
     }
 
-    // prefetch registers: the X sub-tile (4 x float4 per thread) and the old int8 U rows (<= 4 bytes per thread)
-    f32x4 xpre[4];
-    int8_t upre[4];
+    // prefetch registers: this lane's quarter of its row of the next sub-tile (row 16*wave + li, columns
+    // 16q + 4lq .. +3) and the old int8 U rows (<= 4 bytes per thread)
+    f32x4 xq[4];
+    int8_t upre[RMAX / 4];
+    // Rows past the end of the block are clamped to its last row instead of masked (no branches, so the compiler
+    // counts outstanding loads exactly): their `a` values are never used and their U rows are zero, so they add
+    // fma(x, 0, acc) = acc to the partials.
+    constexpr int NB = RMAX / 4; // int8 U bytes per thread and sub-tile: 64 * RMAX / 256
     auto issue = [&](int t) {
         const int r0 = t * 64;
+        int row = r0 + 16 * wave + li;
+        row = row < nrows ? row : nrows - 1;
+        const float* src = Xp + (long)row * 64 + 4 * lq;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            int e = i * 256 + tid, row = e >> 4, c4 = e & 15;
-            xpre[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < 4; q++) {
 #ifndef LRF_ABLATE_LOADS
-            if (r0 + row < nrows) xpre[i] = *reinterpret_cast<const f32x4*>(Xp + (long)(r0 + row) * 64 + 4 * c4);
+            xq[q] = *reinterpret_cast<const f32x4*>(src + 16 * q);
 #else
-            xpre[i] = (f32x4){(float)e, 1.f, 2.f, (float)t};
+            xq[q] = (f32x4){(float)lane, 1.f, 2.f, (float)t};
 #endif
         }
         if (MODE == 0) {
             int lim = (nrows - r0 < 64 ? nrows - r0 : 64) * R;
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
+            for (int i = 0; i < NB; i++) {
                 int e = i * 256 + tid;
-                upre[i] = (e < lim) ? Ub[(long)r0 * R + e] : (int8_t)0;
-            }
-        }
-    };
-    auto commit = [&]() {
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            int e = i * 256 + tid, row = e >> 4, c4 = e & 15;
-            float2* d = reinterpret_cast<float2*>(&Xs[row * XS_LD + 4 * c4]);
-            d[0] = make_float2(xpre[i][0], xpre[i][1]);
-            d[1] = make_float2(xpre[i][2], xpre[i][3]);
-        }
-        if (MODE == 0) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                int e = i * 256 + tid;
-                if (e < 64 * R) uold_s[e] = upre[i];
+                upre[i] = Ub[(long)r0 * R + (e < lim ? e : lim - 1)];
             }
         }
     };
@@ -767,25 +804,30 @@ __global__ __launch_bounds__(256) void k_bcd(const float* __restrict__ X, const 
 #endif
     STAMP(t_begin);
     issue(0);
+    __syncthreads(); // va_s / wa_s complete
     for (int t = 0; t < nsub; t++) {
         const int r0 = t * 64;
-        STAMP(t0);
-        __syncthreads(); // previous sub-tile fully consumed
-        commit();
-        if (t + 1 < nsub) issue(t + 1);
-        __syncthreads();
         STAMP(t1);
-        STAMP_ADD(c_stage, t0, t1);
-        // ---- a^T tile for rows 16*wave .. +15 : 16 chained MFMAs over k
+        if (MODE != 0) __syncthreads(); // first iteration only: u_s is also written in the U phase below
+        // ---- B operand of a^T = V^T X^T for rows 16*wave .. +15: bx[4q + t'] = X[row][16q + 4t' + lq]
+        float bx[16];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            rows_transpose4(xq[q]);
+#pragma unroll
+            for (int i = 0; i < 4; i++) bx[4 * q + i] = xq[q][i];
+        }
+#ifdef LRF_STAMPS
+        asm volatile("" ::"v"(bx[15]), "v"(bx[0]));
+        STAMP(u1);
+        STAMP_ADD(c_stage, t1, u1);
+#endif
+        // ---- a^T tile: 16 chained MFMAs over k
         {
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, accw = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const float* xr = &Xs[(16 * wave + li) * XS_LD + lq];
-            // operands through named arrays; hipcc interleaves the LDS reads with the dependent MFMA chain itself
-            // (forcing all reads first with sched_barrier measured 4% slower)
-            float bx[16], av[16], aw[MODE == 1 ? 16 : 1];
+            float av[16], aw[MODE == 1 ? 16 : 1];
 #pragma unroll
             for (int s = 0; s < 16; s++) {
-                bx[s] = xr[4 * s];
                 av[s] = va_s[s * 64 + lane];
                 if (MODE == 1) aw[s] = wa_s[s * 64 + lane];
             }
@@ -798,9 +840,35 @@ __global__ __launch_bounds__(256) void k_bcd(const float* __restrict__ X, const 
             *reinterpret_cast<f32x4*>(&a_s[(16 * wave + li) * LRF_RP + 4 * lq]) = acc;
             if (MODE == 1) *reinterpret_cast<f32x4*>(&u_s[(16 * wave + li) * LRF_RP + 4 * lq]) = accw;
         }
+#ifdef LRF_STAMPS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        STAMP(u2);
+        STAMP_ADD(c_g1, u1, u2);
+#endif
+        if (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < NB; i++) uold_s[i * 256 + tid] = upre[i];
+        }
+#ifdef LRF_STAMPS
+        STAMP(u3);
+        STAMP_ADD(c_g2, u2, u3);
+#endif
         __syncthreads();
         STAMP(t2);
+#ifdef LRF_STAMPS
+        STAMP_ADD(c_g3, u3, t2);
+#endif
         STAMP_ADD(c_umfma, t1, t2);
+        // ---- this wave's 16 rows -> LDS (bx[4q + i] = X[m][(16q + 4i) ^ lq], the bits of lq and 16q + 4i are disjoint),
+        //      then the prefetch of the next sub-tile into the same registers
+        {
+            const int m = 16 * wave + li;
+            const int e = lq ^ (((m & 1) << 4) | (((m >> 1) & 7) << 1));
+            float* xw = &Xs[m * 64];
+#pragma unroll
+            for (int c = 0; c < 16; c++) xw[(4 * c) ^ e] = bx[c];
+        }
+        issue(t + 1 < nsub ? t + 1 : t); // unconditional (the last one re-reads its own tile): exact s_waitcnt counts
         // ---- Gauss-Seidel: one wave, lane = row (rotating wave so the VALU work spreads over SIMDs)
         if (wave == (t & 3)) {
             STAMP(g0);
@@ -832,7 +900,6 @@ __global__ __launch_bounds__(256) void k_bcd(const float* __restrict__ X, const 
 #ifdef LRF_STAMPS
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 STAMP(g3);
-                if (wave == 0) { c_g1 += g1 - g0; c_g2 += g2 - g1; c_g3 += g3 - g2; }
 #endif
             } else {
 #pragma unroll
@@ -844,26 +911,31 @@ __global__ __launch_bounds__(256) void k_bcd(const float* __restrict__ X, const 
         STAMP_ADD(c_gs, t2, t3);
         // ---- int8 U out (coalesced bytes), partial a' = X^T U for columns 16*wave..+15, partial b' = U^T U
         {
-            int lim = (nrows - r0 < 64 ? nrows - r0 : 64) * R;
-            for (int e = tid; e < lim; e += 256) {
-                int row = (e * invR) >> 16, r = e - row * R;
-                Ub[(long)r0 * R + e] = (int8_t)u_s[row * LRF_RP + r];
-            }
-            const float* xc = &Xs[lq * XS_LD + 16 * wave + li];
+            // A operand: X[4s + lq][16*wave + li]; xs_swz(4s + lq) = F0(lq) | 4 * (s & 3)
+            const int f0 = ((lq & 1) << 4) | ((lq >> 1) << 1);
+            const float* xc = &Xs[lq * 64];
+            const int nb = (16 * wave + li) ^ f0;
             const float* uc = &u_s[lq * LRF_RP + li];
             float px[16], pu[16], qu[4];
+#pragma unroll
+            for (int s = 0; s < 16; s++) px[s] = xc[256 * s + (nb ^ (4 * (s & 3)))];
             const float* uq = uc + 16 * wave * LRF_RP; // wave w: row steps 4w .. 4w+3 of the sub-tile
 #pragma unroll
-            for (int s = 0; s < 16; s++) {
-                px[s] = xc[4 * s * XS_LD];
-                pu[s] = uc[4 * s * LRF_RP];
-            }
+            for (int s = 0; s < 16; s++) pu[s] = uc[4 * s * LRF_RP];
 #pragma unroll
             for (int s = 0; s < 4; s++) qu[s] = uq[4 * s * LRF_RP];
 #pragma unroll
             for (int s = 0; s < 16; s++) {
                 accP = __builtin_amdgcn_mfma_f32_16x16x4f32(px[s], pu[s], accP, 0, 0, 0);
                 if ((s & 3) == 3) accQ = __builtin_amdgcn_mfma_f32_16x16x4f32(qu[s >> 2], qu[s >> 2], accQ, 0, 0, 0);
+            }
+            // int8 U out: coalesced bytes, a fixed number of (predicated) stores per thread
+            int lim = (nrows - r0 < 64 ? nrows - r0 : 64) * R;
+#pragma unroll
+            for (int i = 0; i < NB; i++) {
+                int e = i * 256 + tid;
+                int row = (e * invR) >> 16, r = e - row * R;
+                if (e < lim) Ub[(long)r0 * R + e] = (int8_t)u_s[row * LRF_RP + r];
             }
         }
 #ifdef LRF_STAMPS
@@ -888,6 +960,11 @@ __global__ __launch_bounds__(256) void k_bcd(const float* __restrict__ X, const 
         STAMP(t_end);
         unsigned long long* o = g_stamps + 8 * blockIdx.x;
         o[0] = t_end - t_begin; o[1] = c_stage; o[2] = c_umfma; o[3] = c_gs; o[4] = c_pq; o[5] = c_g1; o[6] = c_g2; o[7] = c_g3;
+        if (getenv_probe_dummy == 1) { // GS probe view: replaces the U-phase split
+            __threadfence();
+            o[1] = g_gsp[4 * blockIdx.x + 0]; o[5] = g_gsp[4 * blockIdx.x + 1]; o[6] = g_gsp[4 * blockIdx.x + 2]; o[7] = g_gsp[4 * blockIdx.x + 3];
+            g_gsp[4 * blockIdx.x + 0] = 0; g_gsp[4 * blockIdx.x + 1] = 0; g_gsp[4 * blockIdx.x + 2] = 0; g_gsp[4 * blockIdx.x + 3] = 0;
+        }
     }
 #endif
 }

@@ -7,6 +7,7 @@ from lrf_amd import _lib
 _lib.LIB_PATH = os.path.join(ROOT, "lrf_amd", "liblrf_hip_stamps.so")
 import lrf_amd
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+GSPROBE = os.environ.get("LRF_GS_PROBE") == "1"  # library built with -DLRF_GS_PROBE=1
 g = torch.Generator(device="cuda").manual_seed(0)
 imgs = torch.randint(0, 256, (B, 3, 512, 768), dtype=torch.uint8, device="cuda", generator=g)
 for _ in range(2):
@@ -24,4 +25,6 @@ for name, v in (("stage+barriers", st), ("U mfma", um), ("gauss-seidel", gs), ("
     print(f"  {name:22s} median {np.median(v):8.0f}  share {np.median(v / tot) * 100:5.1f}%  per sub-tile {np.median(v)/6:.0f}")
 print("  other (prologue/epilogue) share %.1f%%" % (100 * np.median((tot - st - um - gs - pq) / tot)))
 g1, g2, g3 = [buf[:, i].astype(np.float64) for i in (5, 6, 7)]
-print(f"  GS on wave 0 (2 of 6 sub-tiles): load/convert {np.median(g1)/2:.0f}  solve {np.median(g2)/2:.0f}  tail {np.median(g3)/2:.0f} cycles per sub-tile")
+print(f"  U phase split per sub-tile: wait+transpose {np.median(st)/6:.0f}  mfma chain {np.median(g1)/6:.0f}  px/commit/prefetch issue {np.median(g2)/6:.0f}  barrier {np.median(g3)/6:.0f}")
+if GSPROBE:
+    print(f"  (GS probe build) per GS call: LDS operand wait {np.median(st)/6:.0f}  table s_load wait {np.median(g1)/6:.0f}  speculative solve {np.median(g2)/6:.0f}  gs_row total {np.median(g3)/6:.0f}")
