@@ -14,6 +14,7 @@
 #include "lrf_kernels.hip"
 #include "lrf_svd_kernels.hip"
 #include "lrf_bigrank_kernels.hip"
+#include "lrf_bcdw_kernel.hip"
 
 static thread_local char g_err[512] = "";
 
@@ -314,12 +315,19 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
             attr_set = true;
         }
     }
+    // k_bcd_w (one wave per block, no barriers) is the default; LRF_BCD_WG=1 selects the 4-wave workgroup kernel k_bcd
+    static const bool wave_variant = !(getenv("LRF_BCD_WG") && getenv("LRF_BCD_WG")[0] == '1');
     for (int it = 0; it < K; it++) {
         {
             Prof p(c, LRF_K_BCD);
             int mode = (it == 0) ? first_mode : 0;
 #define LRF_LAUNCH_BCD(MODE, RMAX)                                                                                   \
-    hipLaunchKernelGGL((k_bcd<MODE, RMAX>), dim3(nb), dim3(256), 0, c->stream, X, pl, bl, vf, wf, bf, U0, U, pp, qp, gp)
+    do {                                                                                                             \
+        if (wave_variant)                                                                                            \
+            hipLaunchKernelGGL((k_bcd_w<MODE, RMAX>), dim3(nb), dim3(64), 0, c->stream, X, pl, bl, vf, wf, bf, U0, U, pp, qp, gp); \
+        else                                                                                                         \
+            hipLaunchKernelGGL((k_bcd<MODE, RMAX>), dim3(nb), dim3(256), 0, c->stream, X, pl, bl, vf, wf, bf, U0, U, pp, qp, gp); \
+    } while (0)
 #define LRF_LAUNCH_BIG(MODE)                                                                                         \
     hipLaunchKernelGGL((k_bcd_big<MODE>), dim3(nb), dim3(256), sizeof(BigLds), c->stream, X, pl, bl, vf, wf, bf, U0, U, pp, qp, \
                        gp.lo, gp.hi)
