@@ -305,6 +305,15 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
     int rmax = table_rmax(t), rp = table_rp(t);
     int rc = run_bprep(c, np, rp);
     if (rc) return rc;
+    {
+        static bool w_attr_set = false;
+        if (!w_attr_set) {
+            HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_w<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LRF_BCDW_LDS));
+            HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_w<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LRF_BCDW_LDS));
+            HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_w<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LRF_BCDW_LDS));
+            w_attr_set = true;
+        }
+    }
     if (rp != 16) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -323,8 +332,9 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
             int mode = (it == 0) ? first_mode : 0;
 #define LRF_LAUNCH_BCD(MODE, RMAX)                                                                                   \
     do {                                                                                                             \
-        if (wave_variant)                                                                                            \
-            hipLaunchKernelGGL((k_bcd_w<MODE, RMAX>), dim3(nb), dim3(64), 0, c->stream, X, pl, bl, vf, wf, bf, U0, U, pp, qp, gp); \
+        if (wave_variant && RMAX == 8)                                                                               \
+            hipLaunchKernelGGL((k_bcd_w<MODE>), dim3((nb + LRF_BCDW_WAVES - 1) / LRF_BCDW_WAVES), dim3(64 * LRF_BCDW_WAVES), LRF_BCDW_LDS, c->stream, X, pl, bl, vf, wf, \
+                               bf, U0, U, pp, qp, gp, nb); \
         else                                                                                                         \
             hipLaunchKernelGGL((k_bcd<MODE, RMAX>), dim3(nb), dim3(256), 0, c->stream, X, pl, bl, vf, wf, bf, U0, U, pp, qp, gp); \
     } while (0)
@@ -370,6 +380,7 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
 extern "C" {
 
 const char* lrf_last_error(void) { return g_err; }
+
 
 int lrf_version(void) { return 1; }
 
