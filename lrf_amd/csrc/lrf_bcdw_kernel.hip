@@ -18,6 +18,7 @@
 // next sub-tile's global loads are in flight during steps 2 to 4.
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned __attribute__((aligned(1))) u32_unaligned;
 
 // diagnostic stamps of this kernel: -DLRF_STAMPS -DLRF_W_STAMPS (tools/dev_stamps_w.py)
 #if defined(LRF_STAMPS) && defined(LRF_W_STAMPS)
@@ -30,9 +31,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #endif
 
 // LDS X tile: element (m, n) of the 64 x 64 sub-tile lives at dword m*64 + 4*((n >> 2) ^ xsw(m)) + (n & 3).
-// xsw is a bijection of m mod 16 with bit 2 = m & 1: the float4 stores (8 consecutive rows, one chunk), the float4
-// row reads (16 rows, one chunk) and the transposed dword reads (16 columns of two adjacent rows) are all conflict-free.
-__device__ __forceinline__ int xsw(int m) { return ((m & 1) << 2) | ((m >> 1) & 3) | (m & 8); }
+// All three access patterns are float4 and conflict-free with xsw(m) = m mod 16: the stores (8 consecutive rows, one
+// chunk), the row reads of the U phase (16 rows, one chunk) and the reads of the a' = X^T u operand (lane (li, lq):
+// chunk li of row 4s + lq — the four components are the operands of four *strided* 16-column tiles {4 li + c}).
+__device__ __forceinline__ int xsw(int m) { return m & 15; }
 
 // V (wave-uniform, constant for the whole block) lives in 32 VGPRs: vreg[r][kb], lane l = V[16 kb + (l & 15)][r].
 // DPP row_newbcast:n hands lane n of every 16-lane row to all lanes of that row, folded into the fma's operand
@@ -41,7 +43,11 @@ __device__ __forceinline__ int xsw(int m) { return ((m & 1) << 2) | ((m >> 1) & 
 template <int KL>
 __device__ __forceinline__ void fmac_row_bcast(float& acc, float v, float x)
 {
+#ifndef LRF_W_NODPP
     asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(v), "v"(x), "n"(KL));
+#else
+    asm("v_fmac_f32_e32 %0, %1, %2" : "+v"(acc) : "v"(v), "v"(x)); // ablation: wrong values, same instruction count
+#endif
 }
 
 // acc[r] = fma(V[k][r], x[k], acc[r]) for k = 0..63 in order: the k-ordered chain of the reference's sgemm
@@ -266,38 +272,49 @@ __global__ __launch_bounds__(64 * LRF_BCDW_WAVES) __attribute__((aligned(4096)))
     }
     tab[4] = gt[(li & 7) * LRF_GT_LD + LRF_GT_DEN];
 
-    // prefetch registers: xq[T][q] = X[r0 + 16T + li][16q + 4lq .. +3]; upre[r] = old int8 U[r0 + lane][r].
+    // prefetch registers: xq[T][q] = X[r0 + 16T + 4q + lq][4li .. +3] (chunk li of the row); upre = old int8 U[r0 + lane][:].
     // Rows past the end of the block are clamped to its last row (finite data, no branches): their u is forced to 0.
     f32x4 xq[4][4];
-    int8_t upre[RMAX];
-    auto issue = [&](int t) {
+    unsigned upre[2]; // the row's R bytes: bytes 0..3 and bytes R-4..R-1 (R >= 4), or bytes 0..R-1 gathered (R < 4)
+    auto issue_x = [&](int t, int T0, int T1) { // rows 16 T0 .. 16 T1 - 1 of sub-tile t: each load is four whole rows (1 KB)
         const int r0 = t * 64;
 #pragma unroll
-        for (int T = 0; T < 4; T++) {
-            int row = r0 + 16 * T + li;
-            row = row < nrows ? row : nrows - 1;
-            const float* src = Xp + (long)row * 64 + 4 * lq;
+        for (int T = T0; T < T1; T++) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) xq[T][q] = *reinterpret_cast<const f32x4*>(src + 16 * q);
+            for (int q = 0; q < 4; q++) {
+                int row = r0 + 16 * T + 4 * q + lq;
+                row = row < nrows ? row : nrows - 1;
+#ifndef LRF_W_NO_LOADS
+                xq[T][q] = *reinterpret_cast<const f32x4*>(Xp + (long)row * 64 + 4 * li);
+#else
+                xq[T][q] = (f32x4){(float)lane, 1.f + q, 2.f + T, (float)t}; // ablation: no HBM traffic for X
+#endif
+            }
         }
+    };
+    auto issue_u = [&](int t) {
+        const int r0 = t * 64;
         if (MODE == 0) {
             int row = r0 + lane;
             row = row < nrows ? row : nrows - 1;
             const int8_t* up = Ub + (long)row * R;
-#pragma unroll
-            for (int r = 0; r < RMAX; r++) upre[r] = up[r < R ? r : R - 1];
+            if (R >= 4) { // two (unaligned, overlapping) dword loads instead of R byte loads
+                upre[0] = *reinterpret_cast<const u32_unaligned*>(up);
+                upre[1] = *reinterpret_cast<const u32_unaligned*>(up + R - 4);
+            } else
+            {
+                unsigned b0 = (uint8_t)up[0], b1 = (uint8_t)up[R > 1 ? 1 : 0], b2 = (uint8_t)up[R > 2 ? 2 : 0];
+                upre[0] = b0 | (b1 << 8) | (b2 << 16);
+                upre[1] = 0;
+            }
         }
     };
 
-    // transposed-operand read bases: X[4s + lq][16c + li] at xb[s & 1][c & 1][256 s + 32 ((c >> 1) ^ ((s >> 1) & 1))]
-    const float* xb[2][2];
-    {
-        const int cb = (li >> 2) ^ (((lq & 1) << 2) | (lq >> 1));
+    // A operand of a' = X^T u, all four column tiles at once: chunk li of row 4s + lq, xp[(s & 3)][64 * 4 * s floats]
+    // (xsw(4s + lq) = 4 (s & 3) + lq: four lane-constant bases, the rest is an immediate offset)
+    const float* xp[4];
 #pragma unroll
-        for (int e = 0; e < 2; e++)
-#pragma unroll
-            for (int k = 0; k < 2; k++) xb[e][k] = &Xs[lq * 64 + 4 * ((cb ^ (4 * k)) ^ (2 * e)) + (li & 3)];
-    }
+    for (int e = 0; e < 4; e++) xp[e] = &Xs[lq * 64 + 4 * (li ^ (4 * e + lq))];
     // B operand of a' = X^T u: u[4s + lq][li] (columns >= 8 are zero); A/B operand of b' = u^T u: two row groups per
     // MFMA, u[4(2h) + lq][li] in columns/rows 0..7 and u[4(2h+1) + lq][li - 8] in 8..15
     const float* ub = &us[lq * RMAX + (li & 7)];
@@ -313,7 +330,8 @@ __global__ __launch_bounds__(64 * LRF_BCDW_WAVES) __attribute__((aligned(4096)))
     unsigned long long c_w1 = 0, c_w2 = 0, c_w3 = 0, c_w4 = 0, c_w5 = 0, c_w6 = 0, c_w7 = 0;
 #endif
     WSTAMP(t_begin);
-    issue(0);
+    issue_x(0, 0, 4);
+    issue_u(0);
     for (int t = 0; t < nsub; t++) {
         const int r0 = t * 64;
         WSTAMP(s0);
@@ -325,19 +343,29 @@ __global__ __launch_bounds__(64 * LRF_BCDW_WAVES) __attribute__((aligned(4096)))
         WSTAMP_ADD(c_w1, s0, s1); // wait for the prefetch
         // ---- 1. sub-tile -> LDS, next sub-tile's loads into the same registers
 #pragma unroll
-        for (int T = 0; T < 4; T++) {
-            const int m = 16 * T + li;
-            const int g = xsw(m);
+        for (int T = 0; T < 4; T++)
 #pragma unroll
-            for (int q = 0; q < 4; q++) *reinterpret_cast<f32x4*>(&Xs[m * 64 + 4 * ((4 * q + lq) ^ g)]) = xq[T][q];
-        }
+            for (int q = 0; q < 4; q++) {
+                const int m = 16 * T + 4 * q + lq; // xsw(m) = 4 q + lq: one lane-constant address, the rest immediate
+                *reinterpret_cast<f32x4*>(&Xs[m * 64 + 4 * (li ^ (4 * q + lq))]) = xq[T][q];
+            }
         float u[RMAX];
         const int row = r0 + lane;
         if constexpr (MODE == 0) {
+            // bytes 4..7 of the row sit in upre[1] from byte 8 - R on
+            const unsigned lo = upre[0], hi = (R > 4) ? upre[1] >> (8 * (8 - R)) : 0u;
 #pragma unroll
-            for (int r = 0; r < RMAX; r++) u[r] = (float)upre[r];
+            for (int r = 0; r < 4; r++) {
+                u[r] = (float)(int)(int8_t)(lo >> (8 * r));
+                u[4 + r] = (float)(int)(int8_t)(hi >> (8 * r));
+            }
         }
-        issue(t + 1 < nsub ? t + 1 : t); // unconditional (the last one re-reads its own tile): exact s_waitcnt counts
+        // The next sub-tile's 16 KB go out in three bursts (here, after the U phase, after the Gauss-Seidel) rather
+        // than as one: at ~10 B/cycle/CU the kernel runs at the memory system's pace and a wave that issues sixteen
+        // loads into full queues just stalls.  Unconditional (the last one re-reads its own tile): exact s_waitcnt counts.
+        const int tn = t + 1 < nsub ? t + 1 : t;
+        issue_x(tn, 0, 2);
+        issue_u(tn);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -366,6 +394,7 @@ __global__ __launch_bounds__(64 * LRF_BCDW_WAVES) __attribute__((aligned(4096)))
 #ifdef LRF_W_STAMPS
         asm volatile("" ::"v"(a[0]), "v"(a[RMAX - 1]));
 #endif
+        issue_x(tn, 2, 3);
         __builtin_amdgcn_sched_barrier(0);
         WSTAMP(s3);
         WSTAMP_ADD(c_w3, s2, s3); // row reads + packed fma
@@ -383,6 +412,7 @@ __global__ __launch_bounds__(64 * LRF_BCDW_WAVES) __attribute__((aligned(4096)))
 #ifdef LRF_W_STAMPS
         asm volatile("" ::"v"(u[0]), "v"(u[RMAX - 1]));
 #endif
+        issue_x(tn, 3, 4);
         __builtin_amdgcn_sched_barrier(0);
         WSTAMP(s5);
         WSTAMP_ADD(c_w5, s3, s5); // Gauss-Seidel
@@ -391,9 +421,21 @@ __global__ __launch_bounds__(64 * LRF_BCDW_WAVES) __attribute__((aligned(4096)))
         for (int r = 0; r < RMAX; r += 4) *reinterpret_cast<f32x4*>(&us[lane * RMAX + r]) = (f32x4){u[r], u[r + 1], u[r + 2], u[r + 3]};
         if (row < nrows) {
             int8_t* uo = Ub + (long)row * R;
+            unsigned lo = 0, hi = 0;
 #pragma unroll
-            for (int r = 0; r < RMAX; r++)
-                if (r < R) uo[r] = (int8_t)u[r];
+            for (int r = 0; r < 4; r++) {
+                lo |= ((unsigned)(int)u[r] & 0xffu) << (8 * r);
+                hi |= ((unsigned)(int)u[4 + r] & 0xffu) << (8 * r);
+            }
+            if (R >= 4) { // bytes 0..3 and bytes R-4..R-1 (overlapping, same values): two dword stores
+                *reinterpret_cast<u32_unaligned*>(uo) = lo;
+                const unsigned long long w = ((unsigned long long)hi << 32) | lo;
+                *reinterpret_cast<u32_unaligned*>(uo + R - 4) = (unsigned)(w >> (8 * (R - 4)));
+            } else {
+                uo[0] = (int8_t)lo;
+                if (R > 1) uo[1] = (int8_t)(lo >> 8);
+                if (R > 2) uo[2] = (int8_t)(lo >> 16);
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -412,13 +454,13 @@ __global__ __launch_bounds__(64 * LRF_BCDW_WAVES) __attribute__((aligned(4096)))
 #ifdef LRF_W_NO_PQ
         accP[0][0] += pu[3] + qu[2];
 #else
+        f32x4 px[16];
+#pragma unroll
+        for (int s = 0; s < 16; s++) px[s] = *reinterpret_cast<const f32x4*>(xp[s & 3] + 256 * s);
 #pragma unroll
         for (int s = 0; s < 16; s++) {
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                float px = xb[s & 1][c & 1][256 * s + 32 * ((c >> 1) ^ ((s >> 1) & 1))];
-                accP[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(px, pu[s], accP[c], 0, 0, 0);
-            }
+            for (int c = 0; c < 4; c++) accP[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(px[s][c], pu[s], accP[c], 0, 0, 0);
             if (s & 1) accQ = __builtin_amdgcn_mfma_f32_16x16x4f32(qu[s >> 1], qu[s >> 1], accQ, 0, 0, 0);
         }
 #endif
@@ -432,13 +474,13 @@ __global__ __launch_bounds__(64 * LRF_BCDW_WAVES) __attribute__((aligned(4096)))
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    // a' partial: D[i = 4*lq + reg (column 16c + i)][j = li (r)]
+    // a' partial: tile c holds the columns 4 i + c: D[i = 4*lq + reg][j = li (r)] -> a'[4 i + c][r]
     const long slot = (long)pd.blk0 + bd.blk;
     float* Pp = Ppart + slot * 64 * LRF_RP;
 #pragma unroll
     for (int c = 0; c < 4; c++)
 #pragma unroll
-        for (int reg = 0; reg < 4; reg++) Pp[(16 * c + 4 * lq + reg) * LRF_RP + li] = accP[c][reg];
+        for (int reg = 0; reg < 4; reg++) Pp[(4 * (4 * lq + reg) + c) * LRF_RP + li] = accP[c][reg];
     // b' partial: D holds the even row groups in its upper-left 8 x 8 block and the odd ones in the lower-right block
     // (exact integers: the order of the final addition is immaterial); the cross blocks are not used
     float* Qp = Qpart + slot * LRF_RP * LRF_RP;

@@ -20,6 +20,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 #define LRF_EPS 1e-16f
+// Kernel entry points are pinned to 4 KB boundaries: k_bcd_w lost a third of its speed at one unlucky offset
+// (lrf_bcdw_kernel.hip), so no kernel's placement is left to whatever precedes it in the code object.
+#define LRF_KALIGN __attribute__((aligned(4096)))
 
 // Diagnostic build only (-DLRF_STAMPS, never shipped): per-phase cycle sums of k_bcd, wave 0 of each workgroup.
 #ifdef LRF_STAMPS
@@ -72,7 +75,7 @@ __device__ __forceinline__ float ycc_of(float r, float g, float b, int c)
 // One workgroup per (patch row of one plane, image): it consumes 8 (luma) or 16 (chroma) full image rows and
 // writes nw complete 256-byte patches.  Thread item = one float4 of a patch (16 consecutive items = one patch,
 // so stores are fully coalesced); int32 arithmetic only, word loads on the aligned interior fast paths.
-__global__ __launch_bounds__(256) void k_planes(const uint8_t* __restrict__ rgb, int H, int W, ImageGeom g,
+__global__ __launch_bounds__(256) LRF_KALIGN void k_planes(const uint8_t* __restrict__ rgb, int H, int W, ImageGeom g,
                                                 float* __restrict__ X)
 {
     const int pr = blockIdx.x;
@@ -210,7 +213,7 @@ struct InitLds {
 };
 
 template <int ZR>
-__global__ __launch_bounds__(256) void k_init(const float* __restrict__ X, const PlaneDesc* __restrict__ planes,
+__global__ __launch_bounds__(256) LRF_KALIGN void k_init(const float* __restrict__ X, const PlaneDesc* __restrict__ planes,
                                               const int8_t* __restrict__ sign, float* __restrict__ Vf,
                                               float* __restrict__ Wf, int debug_stop, int rp)
 {
@@ -728,7 +731,7 @@ __device__ __forceinline__ void rows_transpose4(f32x4& c)
 }
 
 template <int MODE, int RMAX>
-__global__ __launch_bounds__(256) void k_bcd(const float* __restrict__ X, const PlaneDesc* __restrict__ planes,
+__global__ __launch_bounds__(256) LRF_KALIGN void k_bcd(const float* __restrict__ X, const PlaneDesc* __restrict__ planes,
                                              const BlockDesc* __restrict__ blocks, const float* __restrict__ Vf,
                                              const float* __restrict__ Wf, const float* __restrict__ Bf,
                                              const float* __restrict__ U0, int8_t* __restrict__ U,
@@ -975,7 +978,7 @@ __global__ __launch_bounds__(256) void k_bcd(const float* __restrict__ X, const 
 // then the b table (v.mT @ v) of the new V for the next U update.
 // ------------------------------------------------------------------------------------------------
 template <int RMAX>
-__global__ __launch_bounds__(256) void k_vupdate(const PlaneDesc* __restrict__ planes, const float* __restrict__ Ppart,
+__global__ __launch_bounds__(256) LRF_KALIGN void k_vupdate(const PlaneDesc* __restrict__ planes, const float* __restrict__ Ppart,
                                                  const float* __restrict__ Qpart, float* __restrict__ Vf,
                                                  float* __restrict__ Bf, int8_t* __restrict__ V8, GsParams gp,
                                                  int write_i8)
@@ -1089,7 +1092,7 @@ __device__ __forceinline__ float recon_at(const int8_t* __restrict__ Uc, const i
     return acc;
 }
 
-__global__ __launch_bounds__(256) void k_decode(const int8_t* __restrict__ U, const int8_t* __restrict__ V, int H, int W,
+__global__ __launch_bounds__(256) LRF_KALIGN void k_decode(const int8_t* __restrict__ U, const int8_t* __restrict__ V, int H, int W,
                                                 ImageGeom g, int R0, int R1, int R2, long u_img, long v_img,
                                                 uint8_t* __restrict__ rgb)
 {
