@@ -164,7 +164,7 @@ def main():
             "config": {"workload": f"{B} x 512x768x3 uint8 per GPU, YCbCr 4:2:0, 8x8 patches, ranks (7,3,3), "
                                    f"bounds (-16,15), num_iters 10, int8 factors out (BASELINE configs[1])",
                        "global_batch": B * world, "parallelism": f"images sharded over {world} GPU(s), no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": "k_bcd", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_bcd_w", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(bcd_ms, 5)},
             "kernels": {k: {a: round(b, 5) for a, b in v.items()} for k, v in kern.items()},
