@@ -989,33 +989,40 @@ __global__ __launch_bounds__(256) LRF_KALIGN void k_vupdate(const PlaneDesc* __r
 
     const PlaneDesc pd = planes[blockIdx.x];
     const int R = pd.R, tid = threadIdx.x;
-    // a' = ((P0 + P1) + P2) + ... : the partials are loaded in independent batches of 8 (one exposed memory
-    // latency per batch instead of one per block) and added in block order
-    for (int i = tid; i < 64 * LRF_RP; i += 256) {
-        const float* Pp = Ppart + (long)pd.blk0 * 64 * LRF_RP + i;
-        float acc = 0.f;
-        for (int b0 = 0; b0 < pd.nblk; b0 += 8) {
-            float v[8];
+    // a' = ((P0 + P1) + P2) + ... and b' likewise: all the partials of up to 16 blocks (4 elements of a' and one of b'
+    // per thread) are requested before the first one is used — one exposed memory latency per 16 blocks — and then
+    // added in block order.
+    float acc[4] = {0.f, 0.f, 0.f, 0.f}, q = 0.f;
+    {
+        const float* Pp = Ppart + (long)pd.blk0 * 64 * LRF_RP + tid;
+        const float* Qp = Qpart + (long)pd.blk0 * LRF_RP * LRF_RP + tid;
+        const float vold[4] = {Vf[(long)blockIdx.x * 64 * LRF_RP + tid], Vf[(long)blockIdx.x * 64 * LRF_RP + 256 + tid],
+                               Vf[(long)blockIdx.x * 64 * LRF_RP + 512 + tid], Vf[(long)blockIdx.x * 64 * LRF_RP + 768 + tid]};
+        for (int b0 = 0; b0 < pd.nblk; b0 += 16) {
+            float pv[4][16], qv[16];
 #pragma unroll
-            for (int k = 0; k < 8; k++) v[k] = (b0 + k < pd.nblk) ? Pp[(long)(b0 + k) * 64 * LRF_RP] : 0.f;
+            for (int k = 0; k < 16; k++) {
+                const bool ok = b0 + k < pd.nblk;
+                const long blk = ok ? b0 + k : b0;
 #pragma unroll
-            for (int k = 0; k < 8; k++)
-                if (b0 + k < pd.nblk) acc = (b0 + k == 0) ? v[k] : acc + v[k];
+                for (int e = 0; e < 4; e++) pv[e][k] = Pp[blk * 64 * LRF_RP + 256 * e];
+                qv[k] = Qp[blk * LRF_RP * LRF_RP];
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                if (b0 + k < pd.nblk) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) acc[e] = (b0 + k == 0) ? pv[e][k] : acc[e] + pv[e][k];
+                    q = (b0 + k == 0) ? qv[k] : q + qv[k];
+                }
         }
-        a_s[i] = acc;
-        v_s[i] = Vf[(long)blockIdx.x * 64 * LRF_RP + i];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            a_s[256 * e + tid] = acc[e];
+            v_s[256 * e + tid] = vold[e];
+        }
     }
     {
-        const float* Qp = Qpart + (long)pd.blk0 * LRF_RP * LRF_RP + tid;
-        float q = 0.f;
-        for (int b0 = 0; b0 < pd.nblk; b0 += 8) {
-            float v[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) v[k] = (b0 + k < pd.nblk) ? Qp[(long)(b0 + k) * LRF_RP * LRF_RP] : 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; k++)
-                if (b0 + k < pd.nblk) q = (b0 + k == 0) ? v[k] : q + v[k];
-        }
         int j = tid >> 4, r = tid & 15;
         if (j < R && r < R) {
             if (j == r) {
