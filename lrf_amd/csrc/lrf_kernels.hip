@@ -207,7 +207,7 @@ struct InitLds {
     double D2[64 * ZR];
     double Z[ZR * 64];      // eigenvectors in tridiagonal coordinates, then in the original basis
     double cpart[4 * 64];   // matvec partial chains
-    double v[64], w[64], d[64], e[64], e2[64], tau[64], lam[ZR < 16 ? 16 : ZR];
+    double v[128], w[128], d[64], e[64], e2[64], tau[64], lam[ZR < 16 ? 16 : ZR]; // v, w: two buffers (tridiagonalisation)
     double scal[8];         // [0] t, [1] pivmin, [2] lo, [3] hi
     int flag[4];
 };
@@ -288,11 +288,23 @@ __global__ __launch_bounds__(256) LRF_KALIGN void k_init(const float* __restrict
     }
     if (debug_stop == 1) return;
 
-    // ---- Householder tridiagonalisation (oracle: tridiagonalize)
+    // ---- Householder tridiagonalisation (oracle: tridiagonalize).  The matrix lives in registers: thread (lane i,
+    // wave g) holds A[16g + jj][i] (= A[i][16g + jj], the matrix stays exactly symmetric), jj = 0..15.  The LDS copy of
+    // the Gram matrix is dead from here on and its rows are reused for the Householder vectors v_k (read again by the
+    // back-transformation).  Terms the oracle skips (j <= k) are fma(a, 0, c) = c here: v_k[j] = 0 there.
+    double Ar[16];
+#pragma unroll
+    for (int jj = 0; jj < 16; jj++) Ar[jj] = G[(16 * wave + jj) * 64 + lane];
+    __syncthreads();
     for (int k = 0; k < 62; k++) {
-        if (wave == 0) {
+        double* vbuf = L.v + 64 * (k & 1); // v, w double-buffered: one barrier fewer per step
+        double* wbuf = L.w + 64 * (k & 1);
+        if (wave == (k >> 4)) { // the wave that holds row k
             const int i = lane;
-            double x = (i > k) ? G[k * 64 + i] : 0.0; // column k == row k (symmetric); row reads are conflict-free
+            double xk = Ar[0];
+#pragma unroll
+            for (int jj = 1; jj < 16; jj++) xk = ((k & 15) == jj) ? Ar[jj] : xk;
+            double x = (i > k) ? xk : 0.0;
             double sigma = wave_tree64(x * x);
             double tk = 0.0, ek = 0.0, vi = 0.0;
             if (sigma != 0.0) {
@@ -305,52 +317,60 @@ __global__ __launch_bounds__(256) LRF_KALIGN void k_init(const float* __restrict
                 tk = 2.0 / vn;
                 ek = alpha;
             }
-            L.v[i] = vi;
-            if (i > k) G[k * 64 + i] = vi; // row k now stores v_k for the back-transformation
-            if (i == 0) { L.tau[k] = tk; L.e[k] = ek; L.scal[0] = tk; L.flag[0] = (sigma != 0.0); }
+            vbuf[i] = vi;
+            if (i > k) G[k * 64 + i] = vi; // row k of the LDS matrix: v_k for the back-transformation
+            if (i == 0) { L.tau[k] = tk; L.e[k] = ek; L.scal[0] = tk; L.flag[k & 1] = (sigma != 0.0); }
         }
         __syncthreads();
-        if (L.flag[0]) {
-            { // matvec partial chains: thread (row i, column group g); reads A[j][i] == A[i][j]
-                const int i = lane, g = wave;
+        if (L.flag[k & 1]) { // flag double-buffered like v: a wave that skips ahead must not overwrite what others still read
+            double vj[16];
+#pragma unroll
+            for (int jj = 0; jj < 16; jj++) vj[jj] = vbuf[16 * wave + jj];
+            { // matvec partial chains: thread (row i, column group g)
                 double c = 0.0;
-                if (i > k) {
-                    int j0 = 16 * g > k + 1 ? 16 * g : k + 1;
-                    for (int j = j0; j < 16 * g + 16; j++) c = fma(G[j * 64 + i], L.v[j], c);
-                }
-                L.cpart[g * 64 + i] = c;
+#pragma unroll
+                for (int jj = 0; jj < 16; jj++) c = fma(Ar[jj], vj[jj], c);
+                L.cpart[wave * 64 + lane] = (lane > k) ? c : 0.0;
             }
             __syncthreads();
             if (wave == 0) {
                 const int i = lane;
                 double t = L.scal[0];
                 double p = t * (((L.cpart[i] + L.cpart[64 + i]) + L.cpart[128 + i]) + L.cpart[192 + i]);
-                double vi = L.v[i];
+                double vi = vbuf[i];
                 double K = (0.5 * t) * wave_tree64(p * vi);
-                L.w[i] = fma(-K, vi, p);
+                wbuf[i] = fma(-K, vi, p);
             }
             __syncthreads();
             { // rank-2 update, canonical (max,min) formula so that the matrix stays exactly symmetric
                 const int c = lane;
-                const double vc = L.v[c], wc = L.w[c];
-#pragma unroll 4
-                for (int m = 0; m < 16; m++) {
-                    const int r = wave + 4 * m;
-                    if (r > k && c > k) {
-                        const double vr = L.v[r], wr = L.w[r];
-                        const bool rc = r >= c;
-                        const double va = rc ? vr : vc, wa = rc ? wr : wc, vb = rc ? vc : vr, wb = rc ? wc : wr;
-                        G[r * 64 + c] = fma(-wa, vb, fma(-va, wb, G[r * 64 + c]));
-                    }
+                const double vc = vbuf[c], wc = wbuf[c];
+                double wj[16];
+#pragma unroll
+                for (int jj = 0; jj < 16; jj++) wj[jj] = wbuf[16 * wave + jj];
+#pragma unroll
+                for (int jj = 0; jj < 16; jj++) {
+                    const int r = 16 * wave + jj;
+                    const double vr = vj[jj], wr = wj[jj];
+                    const bool rc = r >= c;
+                    const double va = rc ? vr : vc, wa = rc ? wr : wc, vb = rc ? vc : vr, wb = rc ? wc : wr;
+                    const double upd = fma(-wa, vb, fma(-va, wb, Ar[jj]));
+                    Ar[jj] = (r > k && c > k) ? upd : Ar[jj];
                 }
             }
-            __syncthreads();
         }
     }
-    if (tid < 64) {
-        L.d[tid] = G[tid * 64 + tid];
-        if (tid == 62) { L.e[62] = G[63 * 64 + 62]; L.tau[62] = 0.0; }
-        if (tid == 63) { L.e[63] = 0.0; L.tau[63] = 0.0; }
+    __syncthreads();
+    { // d = diag, e[62] = A[63][62]
+        const int i = lane;
+        if (wave == (i >> 4)) {
+            double dv = Ar[0];
+#pragma unroll
+            for (int jj = 1; jj < 16; jj++) dv = ((i & 15) == jj) ? Ar[jj] : dv;
+            L.d[i] = dv;
+        }
+        if (wave == 3 && i == 62) { L.e[62] = Ar[15]; L.tau[62] = 0.0; }
+        if (wave == 3 && i == 63) { L.e[63] = 0.0; L.tau[63] = 0.0; }
     }
     __syncthreads();
     if (debug_stop == 2) return;
