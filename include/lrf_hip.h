@@ -163,6 +163,23 @@ int lrf_svd_encode_rgb_u8(lrf_ctx* ctx, const uint8_t* rgb, int64_t B, int64_t H
 int lrf_svd_decode_rgb_u8(lrf_ctx* ctx, const uint8_t* U, const uint8_t* V, int64_t B, int64_t H, int64_t W, int R,
                           const float* qparams6, uint8_t* rgb);
 
+/* ---------------------------------------------------------------------------------------------------
+ * QMF, RGB colour-space branch: qmf_encode(color_space="RGB", patch=True, patch_size=(8,8))
+ * (lrf/compression/qmf.py:164-187).  One matrix X [M,192] per image (reflect padding to multiples of 8, rows =
+ * patches in row-major order, columns = (c, p, q)), rank R = max(round(min(M,192) * quality / 100), 1) chosen by
+ * the host, QMF(rank=R, bounds, factor=(0,1)).decompose, int8 factors U [B,M,R], V [B,192,R] (device memory).
+ *   U0 [B,M,R] / V0 [B,192,R] fp32 (device), both or neither: the initial factors (lrf/factorization/qmf.py:42-71);
+ *   NULL = this library's SVD initialisation (sign optional [B,R] as in lrf_qmf_decompose_f32).
+ * Ranks up to 24 (the reference's colour-space ablation sweeps quality 0..10 -> R <= 19), K >= 1.
+ * Not tuned (correctness-first kernels, lrf_qmfn_kernels.hip).
+ */
+int lrf_qmf_rgbspace_encode_u8(lrf_ctx* ctx, const uint8_t* rgb, int64_t B, int64_t H, int64_t W, int R, int K, int lo, int hi,
+                               const int8_t* sign, const float* U0, const float* V0, int8_t* U, int8_t* V);
+
+/* qmf_decode, RGB colour-space branch (lrf/compression/qmf.py:311-323, :351): u @ v.mT, depatchify, unpad_image,
+ * to_dtype(uint8).  rgb [B,3,H,W] uint8 (device). */
+int lrf_qmf_rgbspace_decode_u8(lrf_ctx* ctx, const int8_t* U, const int8_t* V, int64_t B, int64_t H, int64_t W, int R, uint8_t* rgb);
+
 #ifdef __cplusplus
 }
 #endif

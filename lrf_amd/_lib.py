@@ -63,6 +63,9 @@ def load():
                                               c_void_p]
         lib.lrf_svd_encode_rgb_u8.argtypes = [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
         lib.lrf_svd_decode_rgb_u8.argtypes = [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p]
+        lib.lrf_qmf_rgbspace_encode_u8.argtypes = [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_void_p,
+                                                   c_void_p, c_void_p, c_void_p, c_void_p]
+        lib.lrf_qmf_rgbspace_decode_u8.argtypes = [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_void_p]
         _lib = lib
         return lib
 
@@ -71,7 +74,8 @@ EXPORTS = ["lrf_last_error", "lrf_device_count", "lrf_version", "lrf_ctx_create"
            "lrf_ctx_synchronize", "lrf_ctx_workspace_bytes", "lrf_ctx_profile", "lrf_ctx_kernel_time",
            "lrf_ctx_profile_reset", "lrf_malloc", "lrf_free", "lrf_memcpy_h2d", "lrf_memcpy_d2h", "lrf_plane_dims",
            "lrf_qmf_planes_from_rgb_u8", "lrf_qmf_decompose_f32", "lrf_qmf_bcd_f32", "lrf_qmf_svd_init_f32",
-           "lrf_qmf_encode_rgb_u8", "lrf_qmf_decode_rgb_u8", "lrf_svd_encode_rgb_u8", "lrf_svd_decode_rgb_u8"]
+           "lrf_qmf_encode_rgb_u8", "lrf_qmf_decode_rgb_u8", "lrf_svd_encode_rgb_u8", "lrf_svd_decode_rgb_u8",
+           "lrf_qmf_rgbspace_encode_u8", "lrf_qmf_rgbspace_decode_u8"]
 
 
 def check(rc):
@@ -241,8 +245,40 @@ def _svd_methods():
         check(self._lib.lrf_svd_decode_rgb_u8(self._h, _dptr(U), _dptr(V), B, H, W, int(R), _dptr(qparams6), _dptr(rgb)))
         return rgb
 
+    def qmf_rgbspace_encode(self, rgb, R, num_iters=10, bounds=(-16, 15), sign=None, init=None):
+        """qmf_encode's RGB colour-space branch: rgb uint8 [B,3,H,W] (CUDA) -> (U int8 [B,M,R], V int8 [B,192,R]).
+        init = (U0 [B,M,R], V0 [B,192,R]) fp32 overrides the SVD initialisation."""
+        import torch
+        rgb = rgb.contiguous()
+        B, C, H, W = rgb.shape
+        assert C == 3 and rgb.dtype == torch.uint8
+        M = ((H + 7) // 8) * ((W + 7) // 8)
+        U = torch.empty((B, M, R), dtype=torch.int8, device=rgb.device)
+        V = torch.empty((B, 192, R), dtype=torch.int8, device=rgb.device)
+        u0 = v0 = None
+        if init is not None:
+            u0, v0 = (t.to(device=rgb.device, dtype=torch.float32).contiguous() for t in init)
+            assert tuple(u0.shape) == (B, M, R) and tuple(v0.shape) == (B, 192, R)
+        if sign is not None:
+            sign = sign.to(device=rgb.device, dtype=torch.int8).contiguous()
+        self.use_torch_stream()
+        check(self._lib.lrf_qmf_rgbspace_encode_u8(self._h, _dptr(rgb), B, H, W, int(R), int(num_iters), int(bounds[0]), int(bounds[1]),
+                                                  _dptr(sign), _dptr(u0), _dptr(v0), _dptr(U), _dptr(V)))
+        return U, V
+
+    def qmf_rgbspace_decode(self, U, V, H, W):
+        import torch
+        U, V = U.contiguous(), V.contiguous()
+        B, _, R = U.shape
+        rgb = torch.empty((B, 3, H, W), dtype=torch.uint8, device=U.device)
+        self.use_torch_stream()
+        check(self._lib.lrf_qmf_rgbspace_decode_u8(self._h, _dptr(U), _dptr(V), B, H, W, int(R), _dptr(rgb)))
+        return rgb
+
     Context.svd_encode_rgb = svd_encode_rgb
     Context.svd_decode_rgb = svd_decode_rgb
+    Context.qmf_rgbspace_encode = qmf_rgbspace_encode
+    Context.qmf_rgbspace_decode = qmf_rgbspace_decode
 
 
 _svd_methods()

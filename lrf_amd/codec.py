@@ -29,13 +29,14 @@ def qmf_ranks(image_hw, rank=None, quality=None):
 
 
 def _check_hip_branch(color_space, scale_factor, patch, patch_size, bounds, dtype, kwargs):
-    if color_space != "YCbCr" or not patch or tuple(patch_size) != (8, 8) or tuple(scale_factor) != (0.5, 0.5):
-        raise NotImplementedError("HIP path covers color_space='YCbCr', patch=True, patch_size=(8,8), "
+    if not patch or tuple(patch_size) != (8, 8) or (color_space == "YCbCr" and tuple(scale_factor) != (0.5, 0.5)):
+        raise NotImplementedError("HIP path covers patch=True, patch_size=(8,8) and, for color_space='YCbCr', "
                                   "scale_factor=(0.5,0.5) (the other qmf_encode branches are SURVEY.md §8f N3)")
     if dtype is not torch.int8:
         raise NotImplementedError("HIP path stores int8 factors only")
     num_iters = kwargs.pop("num_iters", 10)
     init_sign = kwargs.pop("init_sign", None)
+    kwargs.pop("init", None)  # RGB branch only: explicit (u0, v0) fp32 initial factors (tests)
     kwargs.pop("verbose", None)
     extra = {k: v for k, v in kwargs.items() if not (k in ("l2", "l1_ratio") and v in (0, (0, 0))) and
              not (k == "eps" and v == 1e-16)}
@@ -190,15 +191,53 @@ def qmf_encode(image: torch.Tensor, rank=None, quality=None, color_space: str = 
     if image.dtype != torch.uint8:
         raise NotImplementedError("HIP path takes uint8 images")
     H, W = image.shape[-2:]
-    ranks = qmf_ranks((H, W), rank, quality)
     ctx = _lib.context(image.device.index if image.is_cuda else None)
     dev = (image if image.is_cuda else image.cuda(ctx.device)).unsqueeze(0)
+    if color_space == "RGB":
+        return _qmf_encode_rgbspace(ctx, dev, rank, quality, bounds, (lo, hi), patch_size, num_iters, init_sign,
+                                    kwargs.get("init"))
+    ranks = qmf_ranks((H, W), rank, quality)
     if num_iters == 0:
         factors = _svd_init_factors(ctx, dev, ranks, init_sign)
     else:
         U, V = qmf_factorize_batch(dev, ranks, num_iters, (lo, hi), init_sign)
         factors = split_factors(U[0].cpu().numpy(), V[0].cpu().numpy(), (H, W), ranks)
     return pack_image(factors, (H, W), ranks, bounds, patch_size, str(image.dtype).split(".")[-1])
+
+
+def rgbspace_dims(H, W):
+    """(Hp, Wp, M) of the RGB colour-space branch: reflect padding to multiples of 8, one row per 8x8 patch."""
+    Hp, Wp = H + (8 - H % 8) % 8, W + (8 - W % 8) % 8
+    return Hp, Wp, (Hp // 8) * (Wp // 8)
+
+
+def _qmf_encode_rgbspace(ctx, dev, rank, quality, bounds, int_bounds, patch_size, num_iters, init_sign, init):
+    """qmf_encode(color_space="RGB", patch=True) (lrf/compression/qmf.py:164-187, 288-290): one [M,192] matrix."""
+    if isinstance(rank, (list, tuple)) or isinstance(quality, (list, tuple)):
+        raise ValueError("color_space='RGB' takes a scalar rank / quality")
+    H, W = dev.shape[-2:]
+    Hp, Wp, M = rgbspace_dims(H, W)
+    if rank is None:
+        assert quality >= 0 and quality <= 100, "'quality' must be between 0 and 100."
+        R = max(round(min(M, 192) * quality / 100), 1)
+    else:
+        R = rank
+    if num_iters == 0:
+        raise NotImplementedError("num_iters=0 is not on the HIP path for color_space='RGB'")
+    sign = None if init_sign is None else torch.as_tensor(init_sign, dtype=torch.int8).reshape(1, R)
+    U, V = ctx.qmf_rgbspace_encode(dev, R, num_iters, int_bounds, sign, init)
+    metadata = {
+        "dtype": str(dev.dtype).split(".")[-1],
+        "color space": "RGB",
+        "patch": True,
+        "bounds": bounds,
+        "patch size": patch_size,
+        "original size": [H, W],
+        "padded size": [Hp, Wp],
+        "rank": R,
+    }
+    factors = [U[0].cpu().numpy(), V[0].cpu().numpy()]
+    return combine_bytes([dict_to_bytes(metadata), combine_bytes([encode_tensor(f) for f in factors])])
 
 
 def _svd_init_factors(ctx, dev, ranks, init_sign):
@@ -253,7 +292,29 @@ def qmf_decode_batch(streams: Sequence[bytes], device=None) -> torch.Tensor:
     return ctx.decode_rgb(U, V, H, W, m0["rank"])
 
 
+def _qmf_decode_rgbspace(encoded_image: bytes, device=None) -> torch.Tensor:
+    """RGB colour-space branch of qmf_decode (lrf/compression/qmf.py:309-323) -> uint8 CUDA tensor [3,H,W]."""
+    encoded_metadata, encoded_factors = separate_bytes(encoded_image, 2)
+    metadata = bytes_to_dict(encoded_metadata)
+    if not metadata["patch"] or list(metadata["patch size"]) != [8, 8]:
+        raise NotImplementedError("HIP decode covers the 8x8-patch branches only")
+    if metadata["dtype"] != "uint8":
+        raise NotImplementedError("HIP decode writes uint8 images")
+    u, v = (decode_tensor(f) for f in separate_bytes(encoded_factors, 2))
+    H, W = metadata["original size"]
+    Hp, Wp, M = rgbspace_dims(H, W)
+    if list(metadata["padded size"]) != [Hp, Wp] or tuple(u.shape) != (M, metadata["rank"]) or tuple(v.shape) != (192, metadata["rank"]):
+        raise NotImplementedError("stream geometry is not the 8x8 / reflect-padded layout")
+    ctx = _lib.context(device)
+    U = torch.from_numpy(np.ascontiguousarray(u, dtype=np.int8)).unsqueeze(0).cuda(ctx.device)
+    V = torch.from_numpy(np.ascontiguousarray(v, dtype=np.int8)).unsqueeze(0).cuda(ctx.device)
+    return ctx.qmf_rgbspace_decode(U, V, H, W)[0]
+
+
 def qmf_decode(encoded_image: bytes) -> torch.Tensor:
     """Decode a QMF stream -> uint8 tensor [3,H,W] on the CPU, like the reference's lrf.qmf_decode
     (lrf/compression/qmf.py:295-353)."""
+    meta = bytes_to_dict(separate_bytes(encoded_image, 2)[0])
+    if meta["color space"] == "RGB":
+        return _qmf_decode_rgbspace(encoded_image).cpu()
     return qmf_decode_batch([encoded_image])[0].cpu()

@@ -86,11 +86,12 @@ __global__ __launch_bounds__(256) void k_gram_blk(const float* __restrict__ X, l
 }
 
 // ---- top-R eigen-pairs of the N x N Gram matrix in global memory -> v = e sqrt(sigma), w = e / sqrt(sigma) ----
-#define EIG_MAXN 256
+#define EIG_MAXN 192
+#define EIG_ZR 24 // eigenvectors kept in LDS: ranks up to 24 (svd_encode sweeps reach 10, the RGB branch of qmf_encode 19)
 struct EigLds {
     double v[EIG_MAXN], w[EIG_MAXN], d[EIG_MAXN], e[EIG_MAXN], e2[EIG_MAXN], tau[EIG_MAXN];
-    double D1[EIG_MAXN * 16], D2[EIG_MAXN * 16], Z[16 * EIG_MAXN];
-    double part[4 * 16], lam[16], scal[8];
+    double D1[EIG_MAXN * EIG_ZR], D2[EIG_MAXN * EIG_ZR], Z[EIG_ZR * EIG_MAXN];
+    double part[4 * EIG_ZR], lam[EIG_ZR], scal[8];
 };
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -236,33 +237,33 @@ __global__ __launch_bounds__(256) void k_eig_n(double* __restrict__ G, int N, in
         for (int j = 1; j < N; j++) {
             if (fabs(q) < pivmin) q = -pivmin;
             q = (L.d[j] - lam) - L.e2[j - 1] / q;
-            Dp[j * 16] = q;
+            Dp[j * EIG_ZR] = q;
         }
         q = L.d[N - 1] - lam;
-        Dm[(N - 1) * 16] = q;
+        Dm[(N - 1) * EIG_ZR] = q;
         for (int j = N - 2; j >= 0; j--) {
             if (fabs(q) < pivmin) q = -pivmin;
             q = (L.d[j] - lam) - L.e2[j] / q;
-            Dm[j * 16] = q;
+            Dm[j * EIG_ZR] = q;
         }
         int kt = 0;
         double best = 0.0;
         for (int j = 0; j < N; j++) {
-            double g = fabs((Dp[j * 16] + Dm[j * 16]) - (L.d[j] - lam));
+            double g = fabs((Dp[j * EIG_ZR] + Dm[j * EIG_ZR]) - (L.d[j] - lam));
             if (j == 0 || g < best) { best = g; kt = j; }
         }
         double* x = L.Z + r * EIG_MAXN;
         double xv = 1.0;
         x[kt] = 1.0;
         for (int j = kt - 1; j >= 0; j--) {
-            double qq = Dp[j * 16];
+            double qq = Dp[j * EIG_ZR];
             if (fabs(qq) < pivmin) qq = -pivmin;
             xv = -(L.e[j] / qq) * xv;
             x[j] = xv;
         }
         xv = 1.0;
         for (int j = kt; j < N - 1; j++) {
-            double qq = Dm[(j + 1) * 16];
+            double qq = Dm[(j + 1) * EIG_ZR];
             if (fabs(qq) < pivmin) qq = -pivmin;
             xv = -(L.e[j] / qq) * xv;
             x[j + 1] = xv;
@@ -299,24 +300,24 @@ __global__ __launch_bounds__(256) void k_eig_n(double* __restrict__ G, int N, in
         __syncthreads();
     }
     // ---- back-transformation of all vectors at once, then sign / scaling / output
-    double xr[16];
+    double xr[EIG_ZR];
 #pragma unroll
-    for (int r = 0; r < 16; r++) xr[r] = (act && r < Rc) ? L.Z[r * EIG_MAXN + i] : 0.0;
+    for (int r = 0; r < EIG_ZR; r++) xr[r] = (act && r < Rc) ? L.Z[r * EIG_MAXN + i] : 0.0;
     for (int k = N - 3; k >= 0; k--) {
         double tk = L.tau[k];
         if (tk == 0.0) continue;
         double v = (act && i > k) ? A[(long)k * N + i] : 0.0;
-        double pr[16];
+        double pr[EIG_ZR];
 #pragma unroll
-        for (int r = 0; r < 16; r++) pr[r] = wave_sum(v * xr[r]);
+        for (int r = 0; r < EIG_ZR; r++) pr[r] = wave_sum(v * xr[r]);
         if (lane == 0) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) L.part[wave * 16 + r] = pr[r];
+            for (int r = 0; r < EIG_ZR; r++) L.part[wave * EIG_ZR + r] = pr[r];
         }
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            double sc = tk * (((L.part[r] + L.part[16 + r]) + L.part[32 + r]) + L.part[48 + r]);
+        for (int r = 0; r < EIG_ZR; r++) {
+            double sc = tk * (((L.part[r] + L.part[EIG_ZR + r]) + L.part[2 * EIG_ZR + r]) + L.part[3 * EIG_ZR + r]);
             xr[r] = fma(-sc, v, xr[r]);
         }
         __syncthreads();
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(256) void k_eig_n(double* __restrict__ G, int N, in
     float* Vp = Vout + (long)blockIdx.x * N * R;
     float* Wp = Wout + (long)blockIdx.x * N * R;
     for (int r = 0; r < R; r++) {
-        double x = (r < 16) ? xr[r < 16 ? r : 0] : 0.0;
+        double x = (r < EIG_ZR) ? xr[r < EIG_ZR ? r : 0] : 0.0;
         double dot = block_sum((double)(i + 1) * x, L.part, tid);
         float vo = 0.f, wo = 0.f;
         if (r < Rc) {

@@ -221,3 +221,20 @@ def svd_decode_rgb(qu, qv, quant_u, quant_v, H, W):
                                          c_float(quant_v[0]), c_float(quant_v[1]), c_long(H), c_long(W), _ptr(out, _u8p))
     assert rc == 0
     return out
+
+
+# ---- qmf_encode / qmf_decode, RGB colour-space branch (lrf/compression/qmf.py:164-187, 309-323) -----------------
+def qmf_rgbspace_decompose(img_u8, R, num_iters=10, bounds=(-16, 15), sign=None, init=None):
+    """uint8 [3,H,W] -> int8 (u [M,R], v [192,R]): X = patchify(pad(img)), SVD initialisation (svd_topr) unless
+    `init` = (u0, v0) is given, then the same BCD as the 64-column path (lrf_oracle_bcd is written for any N)."""
+    X = pad_patchify(np.asarray(img_u8, dtype=np.float32))
+    u0, v0 = init if init is not None else svd_topr(X, R, sign)
+    return bcd(X, u0, v0, num_iters, bounds)
+
+
+def qmf_rgbspace_decode(u, v, H, W):
+    """int8 factors -> uint8 [3,H,W]: u @ v.mT (exact integers), depatchify, unpad, clamp + truncate."""
+    u = np.asarray(u, dtype=np.float32)
+    v = np.asarray(v, dtype=np.float32)
+    Hp, Wp = H + (8 - H % 8) % 8, W + (8 - W % 8) % 8
+    return to_u8(depatchify_unpad(u @ v.T, 3, Hp, Wp, H, W))

@@ -83,9 +83,12 @@ def test_unsupported_branches_raise():
     with pytest.raises(AssertionError):
         lrf_amd.qmf_encode(img, quality=7, color_space="HSV")
     with pytest.raises(NotImplementedError):
-        lrf_amd.qmf_encode(img, quality=7, color_space="RGB")
+        lrf_amd.qmf_encode(img, quality=7, color_space="RGB", patch_size=(16, 16))
     with pytest.raises(NotImplementedError):
         lrf_amd.qmf_encode(img, quality=7, patch=False)
+    if not torch.cuda.is_available():  # the implemented branches need the GPU: no CPU fallback
+        with pytest.raises(RuntimeError):
+            lrf_amd.qmf_encode(img, quality=7, color_space="RGB")
 
 
 def test_native_packer_matches_reference_streams():

@@ -168,3 +168,53 @@ def gen_sweep():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "sweep":
     gen_sweep()
+
+
+RGBSPACE_CASES = [
+    # qmf_encode(color_space="RGB"): name, image spec, encoder kwargs, store_image
+    ("rgbsp_tiny_q4", dict(kind="randint", seed=11, H=64, W=96), dict(quality=4.0), True),
+    ("rgbsp_tiny_r1", dict(kind="randint", seed=11, H=64, W=96), dict(rank=1), True),
+    ("rgbsp_tiny_r3_it2", dict(kind="randint", seed=11, H=64, W=96), dict(rank=3, num_iters=2), True),
+    ("rgbsp_odd_q6", dict(kind="randint", seed=12, H=173, W=264), dict(quality=6.0), True),
+    ("rgbsp_smooth_q2", dict(kind="smooth", seed=13, H=256, W=384), dict(quality=2.0), True),
+    ("rgbsp_smooth_q10", dict(kind="smooth", seed=13, H=256, W=384), dict(quality=10.0), True),
+    ("rgbsp_nat_q5", dict(kind="natural"), dict(quality=5.0), False),
+]
+
+
+def gen_rgbspace():
+    """Fixtures of the RGB colour-space branch (lrf/compression/qmf.py:164-187): bytes, decoded image, PSNR and the
+    reference's initial factors (u0, v0) so that the BCD can be checked bit for bit from the same start."""
+    torch.set_num_threads(1)
+    ns = ref_loader.load()
+    index = {}
+    for name, spec, kw, store_image in RGBSPACE_CASES:
+        img = make_image(spec)
+        enc = ns.cqmf.qmf_encode(img, color_space="RGB", **kw)
+        dec = ns.cqmf.qmf_decode(enc)
+        mse = torch.mean((img.float() - dec.float()) ** 2, dim=(-3, -2, -1))
+        psnr = (20 * torch.log10(255 / torch.sqrt(mse))).item()
+        meta = json.loads(ns.cutils.separate_bytes(enc, 2)[0].decode())
+        x = ns.cqmf.patchify(ns.cutils.pad_image(img.float(), (8, 8), mode="reflect"), (8, 8))
+        R = meta["rank"]
+        u0, v0, _ = ns.fqmf.SVDInit(rank=R)(x.unsqueeze(0).float())
+        arrays = dict(encoded=np.frombuffer(enc, np.uint8), psnr=np.float64(psnr),
+                      bpp=np.float64(len(enc) * 8 / (img.shape[-2] * img.shape[-1])),
+                      spec=np.array(json.dumps(spec)), kwargs=np.array(json.dumps(kw)),
+                      image_sha256=np.array(hashlib.sha256(img.numpy().tobytes()).hexdigest()),
+                      decoded_sha256=np.array(hashlib.sha256(dec.numpy().tobytes()).hexdigest()),
+                      rank=np.int32(R), sign=wsign(v0[0].numpy()),
+                      u0=np.ascontiguousarray(u0[0].numpy()), v0=np.ascontiguousarray(v0[0].numpy()))
+        if store_image:
+            arrays["image"] = img.numpy()
+            arrays["decoded"] = dec.numpy()
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
+        index[name] = dict(spec=spec, kwargs=kw, bytes=len(enc), psnr=psnr, rank=R,
+                           enc_sha256=hashlib.sha256(enc).hexdigest()[:16])
+        print(name, index[name])
+    with open(os.path.join(OUT, "index_rgbspace.json"), "w") as f:
+        json.dump(index, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "rgbspace":
+    gen_rgbspace()
