@@ -330,3 +330,26 @@ def test_num_iters_zero(oracle):
     assert same / total > 0.99, same / total
     dec = lrf_amd.qmf_decode(enc)
     assert abs(lrf_amd.psnr(case.image, dec).item() - case.psnr) < 0.05
+
+
+@pytest.mark.parametrize("bounds", [(-16, 15), (-128, 127), (-3, 5)])
+def test_every_rank_and_other_bounds_equal_oracle(bounds, oracle):
+    """Each rank 1..16 has its own instantiation of the U phase / Gauss-Seidel (k_bcd_w for R <= 8, k_bcd above), and the
+    int8 rows travel as packed dwords: all of them against the oracle, bit for bit, on a 173x264 image (ragged blocks),
+    with the default bounds, the full int8 range and an asymmetric narrow range (experiments/ablation_bounds)."""
+    import lrf_amd
+    from lrf_amd.codec import split_factors
+    g = torch.Generator().manual_seed(77)
+    img = torch.randint(0, 256, (3, 173, 264), dtype=torch.uint8, generator=g)
+    X = oracle.rgb_to_planes(img.numpy())
+    H, W = img.shape[-2:]
+    rank_sets = [(1, 2, 3), (4, 5, 6), (7, 8, 8), (5, 1, 7), (6, 3, 2)] if bounds == (-16, 15) else [(7, 3, 3), (8, 5, 1)]
+    if bounds == (-16, 15):
+        rank_sets += [(9, 12, 16), (11, 10, 13)]
+    for ranks in rank_sets:
+        U, V = lrf_amd.qmf_factorize_batch(img.cuda().unsqueeze(0), ranks, num_iters=3, bounds=bounds)
+        got = split_factors(U[0].cpu().numpy(), V[0].cpu().numpy(), (H, W), ranks)
+        for c in range(3):
+            u, v = oracle.qmf_decompose(X[c], ranks[c], 3, bounds)
+            assert np.array_equal(got[2 * c], u.astype(np.int8)), f"ranks {ranks} bounds {bounds}: U plane {c}"
+            assert np.array_equal(got[2 * c + 1], v.astype(np.int8)), f"ranks {ranks} bounds {bounds}: V plane {c}"
