@@ -651,8 +651,12 @@ int lrf_qmf_decode_rgb_u8(lrf_ctx* c, const int8_t* U, const int8_t* V, int64_t 
     }
     long n4 = (long)H * ((W + 3) / 4);
     Prof p(c, LRF_K_DECODE);
-    hipLaunchKernelGGL(k_decode, dim3((unsigned)((n4 + 255) / 256), (unsigned)B), dim3(256), 0, c->stream, U, V, (int)H, (int)W,
-                       g, R[0], R[1], R[2], u_img, v_img, rgb);
+    if (R[0] <= 8 && R[1] <= 8 && R[2] <= 8)
+        hipLaunchKernelGGL(k_decode8, dim3((unsigned)((n4 + 255) / 256), (unsigned)B), dim3(256), 0, c->stream, U, V, (int)H, (int)W,
+                           g, R[0], R[1], R[2], u_img, v_img, rgb);
+    else
+        hipLaunchKernelGGL(k_decode, dim3((unsigned)((n4 + 255) / 256), (unsigned)B), dim3(256), 0, c->stream, U, V, (int)H, (int)W,
+                           g, R[0], R[1], R[2], u_img, v_img, rgb);
     LAUNCH_CHECK();
     return LRF_OK;
 }

@@ -1119,6 +1119,81 @@ __device__ __forceinline__ float recon_at(const int8_t* __restrict__ Uc, const i
     return acc;
 }
 
+// Fast path for ranks <= 8 (the default sweeps): the three V tables of the image sit in LDS as floats (zero padded
+// to 8 columns), a thread keeps the u row of the patch it is in and reloads it only when the patch changes (four
+// horizontally adjacent pixels touch at most two luma and two chroma patches), and the four output bytes of a
+// channel leave as one dword.  Same arithmetic and order as k_decode.
+__global__ __launch_bounds__(256) LRF_KALIGN void k_decode8(const int8_t* __restrict__ U, const int8_t* __restrict__ V, int H, int W,
+                                                 ImageGeom g, int R0, int R1, int R2, long u_img, long v_img,
+                                                 uint8_t* __restrict__ rgb)
+{
+    __shared__ float Vs[3][64 * 8];
+    const int8_t* Ui = U + (long)blockIdx.y * u_img;
+    const int8_t* Vi = V + (long)blockIdx.y * v_img;
+    const int8_t* Uc[3] = {Ui, Ui + (long)g.p[0].M * R0, Ui + (long)g.p[0].M * R0 + (long)g.p[1].M * R1};
+    const int8_t* Vc[3] = {Vi, Vi + 64 * R0, Vi + 64 * R0 + 64 * R1};
+    const int Rc[3] = {R0, R1, R2};
+    for (int e = threadIdx.x; e < 3 * 64 * 8; e += 256) {
+        int c = e >> 9, n = (e >> 3) & 63, r = e & 7;
+        Vs[c][n * 8 + r] = (r < Rc[c]) ? (float)Vc[c][n * Rc[c] + r] : 0.f;
+    }
+    __syncthreads();
+    int w4 = (W + 3) >> 2;
+    long o = (long)blockIdx.x * 256 + threadIdx.x;
+    if (o >= (long)H * w4) return;
+    int y = (int)(o / w4), x0 = (int)(o - (long)y * w4) * 4;
+    uint8_t* out = rgb + (long)blockIdx.y * 3 * H * W;
+    const float T[3][3] = {{1.0f, 0.0f, 1.402f}, {1.0f, -0.344136f, -0.714136f}, {1.0f, 1.772f, 0.0f}};
+    float sh = (float)g.p[1].h / (float)H, sw = (float)g.p[1].w / (float)W;
+    int sy = (int)floorf((float)y * sh);
+    if (sy > g.p[1].h - 1) sy = g.p[1].h - 1;
+    float ur[3][8];
+    int mcur[3] = {-1, -1, -1};
+    auto recon = [&](int c, int yy, int xx) { // padded coordinates of plane c
+        const int m = (yy >> 3) * g.p[c].nw + (xx >> 3), n = (yy & 7) * 8 + (xx & 7);
+        if (m != mcur[c]) {
+            mcur[c] = m;
+#pragma unroll
+            for (int r = 0; r < 8; r++) ur[c][r] = (r < Rc[c]) ? (float)Uc[c][(long)m * Rc[c] + r] : 0.f;
+        }
+        float acc = 0.f; // k-ordered fma chain; the padded terms are fma(0, 0, acc) = acc
+#pragma unroll
+        for (int r = 0; r < 8; r++) acc = fmaf(ur[c][r], Vs[c][n * 8 + r], acc);
+        return acc;
+    };
+    uint32_t packed[3] = {0u, 0u, 0u};
+    const int yyl = y + g.p[0].top_crop, yyc = sy + g.p[1].top_crop;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int x = x0 + i;
+        if (x >= W) break;
+        int sx = (int)floorf((float)x * sw);
+        if (sx > g.p[1].w - 1) sx = g.p[1].w - 1;
+        float c[3];
+        c[0] = recon(0, yyl, x + g.p[0].left_crop) + 0.f;
+        c[1] = recon(1, yyc, sx + g.p[1].left_crop) + -128.f;
+        c[2] = recon(2, yyc, sx + g.p[2].left_crop) + -128.f;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            float acc = 0.f;
+            acc = fmaf(T[ch][0], c[0], acc);
+            acc = fmaf(T[ch][1], c[1], acc);
+            acc = fmaf(T[ch][2], c[2], acc);
+            acc = fminf(fmaxf(acc, 0.f), 255.f);
+            packed[ch] |= (uint32_t)(uint8_t)acc << (8 * i); // truncation (to_dtype)
+        }
+    }
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        uint8_t* dst = out + (long)ch * H * W + (long)y * W + x0;
+        if (x0 + 3 < W) {
+            *reinterpret_cast<uint32_t __attribute__((aligned(1)))*>(dst) = packed[ch];
+        } else {
+            for (int i = 0; x0 + i < W; i++) dst[i] = (uint8_t)(packed[ch] >> (8 * i));
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) LRF_KALIGN void k_decode(const int8_t* __restrict__ U, const int8_t* __restrict__ V, int H, int W,
                                                 ImageGeom g, int R0, int R1, int R2, long u_img, long v_img,
                                                 uint8_t* __restrict__ rgb)
