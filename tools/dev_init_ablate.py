@@ -1,3 +1,6 @@
+"""Diagnostic: k_init time for a given build of the library (argv[1] = file name under lrf_amd/), optionally stopped
+after a stage (LRF_DEBUG_INIT_SWEEPS=1 Gram, 2 tridiagonalisation, 3 eigenvalues).  The round-1 Gram ablations
+(loads replaced by constants / MFMAs removed) were throw-away builds timed with this script."""
 import os, sys
 sys.path.insert(0, "/root/repo")
 from lrf_amd import _lib
