@@ -57,6 +57,7 @@ struct lrf_ctx {
     long acc_n[LRF_K_COUNT] = {0};
     int init_sweeps = 0; // developer aid: stop k_init after stage n (0 = run everything)
     std::vector<char> table_key; // bytes of the descriptor tables now resident on the device
+    unsigned attr_done = 0;      // hipFuncSetAttribute call sites already executed for this context's device (bit per site)
 };
 
 static int ensure(lrf_ctx* c, DevBuf& b, size_t bytes)
@@ -247,12 +248,11 @@ static int upload_tables(lrf_ctx* c, const Tables& t)
 
 static int run_init(lrf_ctx* c, const float* X, const Tables& t, const int8_t* sign_dev)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!(c->attr_done & (1u << 0))) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_init<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InitLds<8>)));
         HIP_TRY(hipFuncSetAttribute((const void*)k_init<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InitLds<16>)));
         HIP_TRY(hipFuncSetAttribute((const void*)k_init<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InitLds<64>)));
-        attr_set = true;
+        c->attr_done |= 1u << 0;
     }
     int rmax = table_rmax(t), rp = table_rp(t), nplanes = (int)t.planes.size();
     Prof p(c, LRF_K_INIT);
@@ -307,22 +307,20 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
     int rc = run_bprep(c, np, rp);
     if (rc) return rc;
     {
-        static bool w_attr_set = false;
-        if (!w_attr_set) {
+        if (!(c->attr_done & (1u << 1))) {
             HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_w<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LRF_BCDW_LDS));
             HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_w<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LRF_BCDW_LDS));
             HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_w<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LRF_BCDW_LDS));
-            w_attr_set = true;
+            c->attr_done |= 1u << 1;
         }
     }
     if (rp != 16) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        if (!(c->attr_done & (1u << 2))) {
             HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_big<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BigLds)));
             HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_big<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BigLds)));
             HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_big<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BigLds)));
             HIP_TRY(hipFuncSetAttribute((const void*)k_vupdate_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BigVLds)));
-            attr_set = true;
+            c->attr_done |= 1u << 2;
         }
     }
     // k_bcd_w (one wave per block, no barriers) is the default; LRF_BCD_WG=1 selects the 4-wave workgroup kernel k_bcd
@@ -700,10 +698,9 @@ int lrf_svd_encode_rgb_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_t H, 
     if ((rc = ensure(c, c->swn, (size_t)B * N * R * sizeof(float)))) return rc;
     if ((rc = ensure(c, c->suf, (size_t)B * M * R * sizeof(float)))) return rc;
     if ((rc = ensure(c, c->smm, (size_t)B * 4 * sizeof(float)))) return rc;
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!(c->attr_done & (1u << 3))) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_eig_n, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(EigLds)));
-        attr_set = true;
+        c->attr_done |= 1u << 3;
     }
     float* X = (float*)c->sx.p;
     double* G = (double*)c->sg.p;
@@ -796,13 +793,12 @@ static int run_bcdn(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, 
                     int8_t* U, int8_t* V)
 {
     constexpr int N = 192;
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!(c->attr_done & (1u << 4))) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_bcdn<N, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BcdnLds<N>)));
         HIP_TRY(hipFuncSetAttribute((const void*)k_bcdn<N, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BcdnLds<N>)));
         HIP_TRY(hipFuncSetAttribute((const void*)k_vupdaten<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(VupdnLds<N>)));
         HIP_TRY(hipFuncSetAttribute((const void*)k_bprepn<N>, hipFuncAttributeMaxDynamicSharedMemorySize, N * LRF_RPN * (int)sizeof(float)));
-        attr_set = true;
+        c->attr_done |= 1u << 4;
     }
     const PlaneDesc* pl = (const PlaneDesc*)c->planes.p;
     const BlockDesc* bl = (const BlockDesc*)c->blocks.p;
@@ -861,10 +857,9 @@ int lrf_qmf_rgbspace_encode_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_
         if ((rc = ensure(c, c->svn, (size_t)B * N * R * sizeof(float)))) return rc;
         if ((rc = ensure(c, c->swn, (size_t)B * N * R * sizeof(float)))) return rc;
         if ((rc = ensure(c, c->suf, (size_t)B * M * R * sizeof(float)))) return rc;
-        static bool attr_set = false;
-        if (!attr_set) {
+        if (!(c->attr_done & (1u << 5))) {
             HIP_TRY(hipFuncSetAttribute((const void*)k_eig_n, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(EigLds)));
-            attr_set = true;
+            c->attr_done |= 1u << 5;
         }
         double* G = (double*)c->sg.p;
         float* Vn = (float*)c->svn.p;
