@@ -273,7 +273,7 @@ __global__ __launch_bounds__(64 * LRF_BCDW_WAVES) __attribute__((aligned(4096)))
     tab[4] = gt[(li & 7) * LRF_GT_LD + LRF_GT_DEN];
 
     // prefetch registers: xq[T][q] = X[r0 + 16T + 4q + lq][4li .. +3] (chunk li of the row); upre = old int8 U[r0 + lane][:].
-    // Rows past the end of the block are clamped to its last row (finite data, no branches): their u is forced to 0.
+    // Rows past the end of the block are clamped to its last row (finite data, no per-lane branches): their u is forced to 0.
     f32x4 xq[4][4];
     unsigned upre[2]; // the row's R bytes: bytes 0..3 and bytes R-4..R-1 (R >= 4), or bytes 0..R-1 gathered (R < 4)
     auto issue_x = [&](int t, int T0, int T1) { // rows 16 T0 .. 16 T1 - 1 of sub-tile t: each load is four whole rows (1 KB)
@@ -362,10 +362,13 @@ __global__ __launch_bounds__(64 * LRF_BCDW_WAVES) __attribute__((aligned(4096)))
         }
         // The next sub-tile's 16 KB go out in three bursts (here, after the U phase, after the Gauss-Seidel) rather
         // than as one: at ~10 B/cycle/CU the kernel runs at the memory system's pace and a wave that issues sixteen
-        // loads into full queues just stalls.  Unconditional (the last one re-reads its own tile): exact s_waitcnt counts.
-        const int tn = t + 1 < nsub ? t + 1 : t;
-        issue_x(tn, 0, 2);
-        issue_u(tn);
+        // loads into full queues just stalls.  The last sub-tile of a block prefetches nothing.
+        const int tn = t + 1;
+        const bool more = tn < nsub; // wave-uniform: the last sub-tile prefetches nothing
+        if (more) {
+            issue_x(tn, 0, 2);
+            issue_u(tn);
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -394,7 +397,7 @@ __global__ __launch_bounds__(64 * LRF_BCDW_WAVES) __attribute__((aligned(4096)))
 #ifdef LRF_W_STAMPS
         asm volatile("" ::"v"(a[0]), "v"(a[RMAX - 1]));
 #endif
-        issue_x(tn, 2, 3);
+        if (more) issue_x(tn, 2, 3);
         __builtin_amdgcn_sched_barrier(0);
         WSTAMP(s3);
         WSTAMP_ADD(c_w3, s2, s3); // row reads + packed fma
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(64 * LRF_BCDW_WAVES) __attribute__((aligned(4096)))
 #ifdef LRF_W_STAMPS
         asm volatile("" ::"v"(u[0]), "v"(u[RMAX - 1]));
 #endif
-        issue_x(tn, 3, 4);
+        if (more) issue_x(tn, 3, 4);
         __builtin_amdgcn_sched_barrier(0);
         WSTAMP(s5);
         WSTAMP_ADD(c_w5, s3, s5); // Gauss-Seidel
