@@ -12,6 +12,46 @@
 #define LRF_GTB_DEN 65
 #define LRF_GTB_STRIDE (LRF_RPB * LRF_GTB_LD)
 
+// acc += uu[n] * bb[n] for n = start, start + step, ... (count terms, in that order; uu = the row without column r).
+// Eight terms at a time: the sixteen LDS reads of a chunk are issued together instead of one exposed latency per term.
+__device__ __forceinline__ float gs_chain(const float* u_row, int r, const float* bb, int start, int step, int count, float acc)
+{
+    int i = 0;
+    for (; i + 8 <= count; i += 8) {
+        float p[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int n = start + (i + j) * step;
+            p[j] = u_row[n < r ? n : n + 1] * bb[n];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc = acc + p[j];
+    }
+    for (; i < count; i++) {
+        const int n = start + i * step;
+        acc = acc + u_row[n < r ? n : n + 1] * bb[n];
+    }
+    return acc;
+}
+
+// term2 = uu . bb of column r in the reference's order (qmf.py:115): ATen native chain, or the MKL single-column tree
+// ((fma(u1,b1,u0*b0) + p_lastodd + ... + p3) + (p2 + p4 + ...)), oracle/lrf_oracle.c dot_mkl_n1
+__device__ __forceinline__ float gs_term2_generic(const float* u_row, int r, const float* bb, int K, bool native)
+{
+    if (K <= 0) return 0.f;
+#define UU(n) u_row[(n) < r ? (n) : (n) + 1]
+    if (native) return gs_chain(u_row, r, bb, 0, 1, K, 0.f);
+    if (K == 1) return UU(0) * bb[0];
+    float odd = fmaf(UU(1), bb[1], UU(0) * bb[0]);
+    const int last_odd = ((K - 1) & 1) ? K - 1 : K - 2;
+    if (last_odd >= 3) odd = gs_chain(u_row, r, bb, last_odd, -2, (last_odd - 3) / 2 + 1, odd);
+    if (K < 3) return odd;
+    float even = UU(2) * bb[2];
+    if (K > 4) even = gs_chain(u_row, r, bb, 4, 2, (K - 1 - 4) / 2 + 1, even);
+#undef UU
+    return odd + even;
+}
+
 // One row, all R columns (qmf.py:108-119), u_row updated in place (LDS); gt: table of b = v.mT @ v (layout as in gs_row).
 __device__ __forceinline__ void gs_row_generic(int R, const float* a_row, float* u_row, const float* gt, bool native,
                                                float lo, float hi)
@@ -19,31 +59,7 @@ __device__ __forceinline__ void gs_row_generic(int R, const float* a_row, float*
     const int K = R - 1;
     for (int r = 0; r < R; r++) {
         const float* bb = gt + r * LRF_GTB_LD;
-        float term2 = 0.f;
-#define UU(n) u_row[(n) < r ? (n) : (n) + 1]
-        if (K > 0) {
-            if (native) {
-                float acc = 0.f;
-                for (int n = 0; n < K; n++) {
-                    float p = UU(n) * bb[n];
-                    acc = acc + p;
-                }
-                term2 = acc;
-            } else if (K == 1) {
-                term2 = UU(0) * bb[0];
-            } else { // MKL single-column order (oracle/lrf_oracle.c dot_mkl_n1)
-                float odd = fmaf(UU(1), bb[1], UU(0) * bb[0]);
-                int last_odd = ((K - 1) & 1) ? K - 1 : K - 2;
-                for (int n = last_odd; n >= 3; n -= 2) odd = odd + UU(n) * bb[n];
-                if (K < 3) term2 = odd;
-                else {
-                    float even = UU(2) * bb[2];
-                    for (int n = 4; n < K; n += 2) even = even + UU(n) * bb[n];
-                    term2 = odd + even;
-                }
-            }
-        }
-#undef UU
+        float term2 = gs_term2_generic(u_row, r, bb, K, native);
         float num = (a_row[r] - term2) + LRF_EPS;
         float val = rintf(num / bb[LRF_GTB_DEN]);
         u_row[r] = fminf(fmaxf(val, lo), hi);
@@ -134,6 +150,15 @@ __global__ __launch_bounds__(256) void k_bcd_big(const float* __restrict__ X, co
             d[0] = make_float2(v[0], v[1]);
             d[1] = make_float2(v[2], v[3]);
         }
+        if (MODE != 1) { // old U rows of the sub-tile -> u_s, all threads, coalesced (a lane-by-lane loop in the
+                         // Gauss-Seidel wave paid one exposed global latency per element)
+            const int lim = (nrows - r0 < 64 ? nrows - r0 : 64) * R;
+            for (int e = tid; e < lim; e += 256) {
+                const int row = e / R, r = e - row * R;
+                L.u_s[row * LRF_RPB + r] = (MODE == 0) ? (float)Ub[(long)r0 * R + e]
+                                                       : U0[pd.u0_off + ((long)bd.row0 + r0) * R + e];
+            }
+        }
         __syncthreads();
         { // a^T tiles for rows 16*wave..+15
             f32x4 acc[4], accw[4];
@@ -160,21 +185,20 @@ __global__ __launch_bounds__(256) void k_bcd_big(const float* __restrict__ X, co
             int row = r0 + lane;
             float* ur = &L.u_s[lane * LRF_RPB];
             if (row < nrows) {
-                long grow = (long)bd.row0 + row;
-                if (MODE == 0) {
-                    for (int r = 0; r < R; r++) ur[r] = (float)Ub[(long)row * R + r];
-                } else if (MODE == 2) {
-                    const float* up = U0 + pd.u0_off + grow * R;
-                    for (int r = 0; r < R; r++) ur[r] = up[r];
-                }
                 gs_row_generic(R, &L.a_s[lane * LRF_RPB], ur, L.gt_s, pd.native_t2_u != 0, lo, hi);
-                for (int r = 0; r < R; r++) Ub[(long)row * R + r] = (int8_t)ur[r];
                 for (int r = R; r < LRF_RPB; r++) ur[r] = 0.f;
             } else {
                 for (int r = 0; r < LRF_RPB; r++) ur[r] = 0.f;
             }
         }
         __syncthreads();
+        { // int8 U out, coalesced
+            const int lim = (nrows - r0 < 64 ? nrows - r0 : 64) * R;
+            for (int e = tid; e < lim; e += 256) {
+                const int row = e / R, r = e - row * R;
+                Ub[(long)r0 * R + e] = (int8_t)L.u_s[row * LRF_RPB + r];
+            }
+        }
         { // X^T U for columns 16*wave..+15 (all four rank tiles); U^T U tile row `wave`
             const float* xc = &L.Xs[lq * XS_LD + 16 * wave + li];
             for (int s = 0; s < 16; s++) {

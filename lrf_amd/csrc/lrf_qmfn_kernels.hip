@@ -13,37 +13,14 @@
 #define LRF_GTN_DEN 33
 #define LRF_GTN_STRIDE (LRF_RPN * LRF_GTN_LD)
 
-// One row, all R columns (qmf.py:108-119), u_row updated in place; gt with pitch LRF_GTN_LD (layout as in gs_row).
+// One row, all R columns (qmf.py:108-119), u_row updated in place; gt with pitch LRF_GTN_LD (layout as in gs_row);
+// the dot product in the reference's order is gs_term2_generic (lrf_bigrank_kernels.hip).
 __device__ __forceinline__ void gs_row_n(int R, const float* a_row, float* u_row, const float* gt, bool native, float lo, float hi)
 {
     const int K = R - 1;
     for (int r = 0; r < R; r++) {
         const float* bb = gt + r * LRF_GTN_LD;
-        float term2 = 0.f;
-#define UU(n) u_row[(n) < r ? (n) : (n) + 1]
-        if (K > 0) {
-            if (native) {
-                float acc = 0.f;
-                for (int n = 0; n < K; n++) {
-                    float p = UU(n) * bb[n];
-                    acc = acc + p;
-                }
-                term2 = acc;
-            } else if (K == 1) {
-                term2 = UU(0) * bb[0];
-            } else { // MKL single-column order (oracle/lrf_oracle.c dot_mkl_n1)
-                float odd = fmaf(UU(1), bb[1], UU(0) * bb[0]);
-                int last_odd = ((K - 1) & 1) ? K - 1 : K - 2;
-                for (int n = last_odd; n >= 3; n -= 2) odd = odd + UU(n) * bb[n];
-                if (K < 3) term2 = odd;
-                else {
-                    float even = UU(2) * bb[2];
-                    for (int n = 4; n < K; n += 2) even = even + UU(n) * bb[n];
-                    term2 = odd + even;
-                }
-            }
-        }
-#undef UU
+        float term2 = gs_term2_generic(u_row, r, bb, K, native);
         float num = (a_row[r] - term2) + LRF_EPS;
         float val = rintf(num / bb[LRF_GTN_DEN]);
         u_row[r] = fminf(fmaxf(val, lo), hi);
@@ -139,6 +116,14 @@ __global__ __launch_bounds__(256) void k_bcdn(const float* __restrict__ X, const
             float* d = &L.Xs[row * XLD + 4 * c4];
             d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
         }
+        { // old U rows of the sub-tile -> u_s, all threads, coalesced
+            const int lim = (nrows - r0 < 64 ? nrows - r0 : 64) * R;
+            for (int e = tid; e < lim; e += 256) {
+                const int row = e / R, r = e - row * R;
+                L.u_s[row * LRF_RPN + r] = (MODE == 0) ? (float)Ub[(long)r0 * R + e]
+                                                       : U0[pd.u0_off + ((long)bd.row0 + r0) * R + e];
+            }
+        }
         __syncthreads();
         { // a = x @ v: thread (row = lane, column group = wave) takes the columns r = wave, wave + 4, ...
             float acc[LRF_RPN / 4];
@@ -159,20 +144,20 @@ __global__ __launch_bounds__(256) void k_bcdn(const float* __restrict__ X, const
             const int row = r0 + lane;
             float* ur = &L.u_s[lane * LRF_RPN];
             if (row < nrows) {
-                if (MODE == 0) {
-                    for (int r = 0; r < R; r++) ur[r] = (float)Ub[(long)row * R + r];
-                } else {
-                    const float* up = U0 + pd.u0_off + ((long)bd.row0 + row) * R;
-                    for (int r = 0; r < R; r++) ur[r] = up[r];
-                }
                 gs_row_n(R, &L.a_s[lane * LRF_RPN], ur, L.gt_s, pd.native_t2_u != 0, lo, hi);
-                for (int r = 0; r < R; r++) Ub[(long)row * R + r] = (int8_t)ur[r];
                 for (int r = R; r < LRF_RPN; r++) ur[r] = 0.f;
             } else {
                 for (int r = 0; r < LRF_RPN; r++) ur[r] = 0.f;
             }
         }
         __syncthreads();
+        { // int8 U out, coalesced
+            const int lim = (nrows - r0 < 64 ? nrows - r0 : 64) * R;
+            for (int e = tid; e < lim; e += 256) {
+                const int row = e / R, r = e - row * R;
+                Ub[(long)r0 * R + e] = (int8_t)L.u_s[row * LRF_RPN + r];
+            }
+        }
         if (tid < NN) { // a' += x.mT @ u: thread = column n; rows in order; padded / missing rows have u = 0
             const float* xc = &L.Xs[tid];
             for (int m = 0; m < 64; m++) {
