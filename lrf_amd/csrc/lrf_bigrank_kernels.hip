@@ -185,7 +185,11 @@ __global__ __launch_bounds__(256) void k_bcd_big(const float* __restrict__ X, co
             int row = r0 + lane;
             float* ur = &L.u_s[lane * LRF_RPB];
             if (row < nrows) {
+#ifndef LRF_BIG_NO_GS
                 gs_row_generic(R, &L.a_s[lane * LRF_RPB], ur, L.gt_s, pd.native_t2_u != 0, lo, hi);
+#else
+                for (int r = 0; r < R; r++) ur[r] = fminf(fmaxf(rintf(L.a_s[lane * LRF_RPB + r] * 1e-4f), lo), hi);
+#endif
                 for (int r = R; r < LRF_RPB; r++) ur[r] = 0.f;
             } else {
                 for (int r = 0; r < LRF_RPB; r++) ur[r] = 0.f;
@@ -201,7 +205,11 @@ __global__ __launch_bounds__(256) void k_bcd_big(const float* __restrict__ X, co
         }
         { // X^T U for columns 16*wave..+15 (all four rank tiles); U^T U tile row `wave`
             const float* xc = &L.Xs[lq * XS_LD + 16 * wave + li];
+#ifdef LRF_BIG_NO_P
+            for (int s = 0; s < 0; s++) {
+#else
             for (int s = 0; s < 16; s++) {
+#endif
                 float px = xc[4 * s * XS_LD];
                 const float* urow = &L.u_s[(4 * s + lq) * LRF_RPB];
                 float qa = urow[16 * wave + li];
