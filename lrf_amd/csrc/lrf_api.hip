@@ -316,9 +316,9 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
     }
     if (rp != 16) {
         if (!(c->attr_done & (1u << 2))) {
-            HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_big<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BigLds)));
-            HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_big<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BigLds)));
-            HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_big<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BigLds)));
+            HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_big<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BigLds<0>)));
+            HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_big<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BigLds<1>)));
+            HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_big<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BigLds<2>)));
             HIP_TRY(hipFuncSetAttribute((const void*)k_vupdate_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BigVLds)));
             c->attr_done |= 1u << 2;
         }
@@ -338,7 +338,7 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
             hipLaunchKernelGGL((k_bcd<MODE, RMAX>), dim3(nb), dim3(256), 0, c->stream, X, pl, bl, vf, wf, bf, U0, U, pp, qp, gp); \
     } while (0)
 #define LRF_LAUNCH_BIG(MODE)                                                                                         \
-    hipLaunchKernelGGL((k_bcd_big<MODE>), dim3(nb), dim3(256), sizeof(BigLds), c->stream, X, pl, bl, vf, wf, bf, U0, U, pp, qp, \
+    hipLaunchKernelGGL((k_bcd_big<MODE>), dim3(nb), dim3(256), sizeof(BigLds<MODE>), c->stream, X, pl, bl, vf, wf, bf, U0, U, pp, qp, \
                        gp.lo, gp.hi)
             if (rp != 16) {
                 if (mode == 1) LRF_LAUNCH_BIG(1);

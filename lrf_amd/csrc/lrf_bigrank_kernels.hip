@@ -95,13 +95,15 @@ __global__ __launch_bounds__(256) void k_bprep_big(const PlaneDesc* __restrict__
     make_gtable_big(v_s, 64, planes[blockIdx.x].R, Bf + (long)blockIdx.x * LRF_GTB_STRIDE, threadIdx.x, 256);
 }
 
+// 49 KB (65 KB in the first iteration): three workgroups per CU, i.e. three Gauss-Seidel waves at work per CU.  The b
+// table stays in global memory (only the Gauss-Seidel wave reads it, with wave-uniform addresses: scalar loads) and the
+// V operand of the U phase lives in 64 registers per lane (the W0 operand of the first iteration in LDS).
+template <int MODE>
 struct BigLds {
     float Xs[64 * XS_LD];
     float a_s[64 * LRF_RPB];
     float u_s[64 * LRF_RPB];
-    float va_s[4 * 16 * 64];
-    float wa_s[4 * 16 * 64];
-    float gt_s[LRF_GTB_STRIDE];
+    float wa_s[MODE == 1 ? 4 * 16 * 64 : 4];
 };
 
 // MODE as in k_bcd.  Ppart / Qpart: per block [64][64] fp32.
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(256) void k_bcd_big(const float* __restrict__ X, co
                                                  float* __restrict__ Ppart, float* __restrict__ Qpart, float lo, float hi)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    BigLds& L = *reinterpret_cast<BigLds*>(smem);
+    BigLds<MODE>& L = *reinterpret_cast<BigLds<MODE>*>(smem);
     const BlockDesc bd = blocks[blockIdx.x];
     const PlaneDesc pd = planes[bd.plane];
     const int R = pd.R;
@@ -127,12 +129,18 @@ __global__ __launch_bounds__(256) void k_bcd_big(const float* __restrict__ X, co
     if (nrows > LRF_KC) nrows = LRF_KC;
     const int nsub = (nrows + 63) >> 6;
 
-    for (int i = tid; i < R * LRF_GTB_LD; i += 256) L.gt_s[i] = Bf[(long)bd.plane * LRF_GTB_STRIDE + i];
+    const float* gt = Bf + (long)bd.plane * LRF_GTB_STRIDE;
     // A operand of a^T = V^T X^T for tile nt: lane needs V[4s + lq][16 nt + li] at k-step s
-    for (int e = tid; e < 4 * 16 * 64; e += 256) {
-        int nt = e >> 10, s_ = (e >> 6) & 15, l = e & 63;
-        L.va_s[e] = Vp[(4 * s_ + (l >> 4)) * LRF_RPB + 16 * nt + (l & 15)];
-        if (MODE == 1) L.wa_s[e] = Wf[(long)bd.plane * 64 * LRF_RPB + (4 * s_ + (l >> 4)) * LRF_RPB + 16 * nt + (l & 15)];
+    float va[4][16];
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+        for (int s_ = 0; s_ < 16; s_++) va[nt][s_] = Vp[(4 * s_ + lq) * LRF_RPB + 16 * nt + li];
+    if (MODE == 1) {
+        for (int e = tid; e < 4 * 16 * 64; e += 256) {
+            int nt = e >> 10, s_ = (e >> 6) & 15, l = e & 63;
+            L.wa_s[e] = Wf[(long)bd.plane * 64 * LRF_RPB + (4 * s_ + (l >> 4)) * LRF_RPB + 16 * nt + (l & 15)];
+        }
     }
     f32x4 accP[4], accQ[4];
 #pragma unroll
@@ -165,11 +173,12 @@ __global__ __launch_bounds__(256) void k_bcd_big(const float* __restrict__ X, co
 #pragma unroll
             for (int i = 0; i < 4; i++) { acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; accw[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
             const float* xr = &L.Xs[(16 * wave + li) * XS_LD + lq];
+#pragma unroll
             for (int s = 0; s < 16; s++) {
                 float bx = xr[4 * s];
 #pragma unroll
                 for (int nt = 0; nt < 4; nt++) {
-                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(L.va_s[(nt * 16 + s) * 64 + lane], bx, acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[nt][s], bx, acc[nt], 0, 0, 0);
                     if (MODE == 1)
                         accw[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(L.wa_s[(nt * 16 + s) * 64 + lane], bx, accw[nt], 0, 0, 0);
                 }
@@ -186,7 +195,7 @@ __global__ __launch_bounds__(256) void k_bcd_big(const float* __restrict__ X, co
             float* ur = &L.u_s[lane * LRF_RPB];
             if (row < nrows) {
 #ifndef LRF_BIG_NO_GS
-                gs_row_generic(R, &L.a_s[lane * LRF_RPB], ur, L.gt_s, pd.native_t2_u != 0, lo, hi);
+                gs_row_generic(R, &L.a_s[lane * LRF_RPB], ur, gt, pd.native_t2_u != 0, lo, hi);
 #else
                 for (int r = 0; r < R; r++) ur[r] = fminf(fmaxf(rintf(L.a_s[lane * LRF_RPB + r] * 1e-4f), lo), hi);
 #endif
