@@ -63,12 +63,16 @@ size_t lrf_ctx_workspace_bytes(const lrf_ctx* ctx);
  * of the kernels below is bracketed by events).  kernel ids: LRF_K_*.  lrf_ctx_kernel_time
  * synchronises the stream and returns the accumulated milliseconds and launch count. */
 #define LRF_K_PLANES 0       /* rgb -> patch matrices          */
-#define LRF_K_INIT 1         /* Gram + Jacobi eigen-solve      */
+#define LRF_K_INIT 1         /* SVD initialisation             */
 #define LRF_K_BCD 2          /* U update + X^T U partials      */
 #define LRF_K_VUPDATE 3      /* V update                       */
 #define LRF_K_DECODE 4       /* factors -> rgb                 */
 #define LRF_K_COUNT 5
 int lrf_ctx_profile(lrf_ctx* ctx, int enable);
+/* The same for a subset of the kernels: bit (1 << LRF_K_x) per kernel id, 0 = off.  An event pair costs a few
+ * microseconds of stream time per launch (0.15 ms per 22-launch encode when every kernel is timed); bench.py times
+ * only the dominant kernel inside its timed region. */
+int lrf_ctx_profile_kernels(lrf_ctx* ctx, unsigned mask);
 int lrf_ctx_kernel_time(lrf_ctx* ctx, int kernel_id, double* total_ms, long* launches);
 int lrf_ctx_profile_reset(lrf_ctx* ctx);
 

@@ -45,6 +45,7 @@ def load():
         lib.lrf_ctx_synchronize.argtypes = [c_void_p]
         lib.lrf_ctx_profile.argtypes = [c_void_p, c_int]
         lib.lrf_ctx_profile_reset.argtypes = [c_void_p]
+        lib.lrf_ctx_profile_kernels.argtypes = [c_void_p, ctypes.c_uint]
         lib.lrf_ctx_kernel_time.argtypes = [c_void_p, c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long)]
         lib.lrf_malloc.argtypes = [c_void_p, c_size_t, ctypes.POINTER(c_void_p)]
         lib.lrf_free.argtypes = [c_void_p, c_void_p]
@@ -71,7 +72,7 @@ def load():
 
 
 EXPORTS = ["lrf_last_error", "lrf_device_count", "lrf_version", "lrf_ctx_create", "lrf_ctx_destroy", "lrf_ctx_set_stream", "lrf_ctx_use_own_stream",
-           "lrf_ctx_synchronize", "lrf_ctx_workspace_bytes", "lrf_ctx_profile", "lrf_ctx_kernel_time",
+           "lrf_ctx_synchronize", "lrf_ctx_workspace_bytes", "lrf_ctx_profile", "lrf_ctx_profile_kernels", "lrf_ctx_kernel_time",
            "lrf_ctx_profile_reset", "lrf_malloc", "lrf_free", "lrf_memcpy_h2d", "lrf_memcpy_d2h", "lrf_plane_dims",
            "lrf_qmf_planes_from_rgb_u8", "lrf_qmf_decompose_f32", "lrf_qmf_bcd_f32", "lrf_qmf_svd_init_f32",
            "lrf_qmf_encode_rgb_u8", "lrf_qmf_decode_rgb_u8", "lrf_svd_encode_rgb_u8", "lrf_svd_decode_rgb_u8",
@@ -141,6 +142,13 @@ class Context:
 
     def profile(self, enable=True):
         check(self._lib.lrf_ctx_profile(self._h, int(bool(enable))))
+
+    def profile_kernels(self, kernel_ids):
+        """event-time only these kernel ids (an iterable of LRF_K_* numbers; empty = off)"""
+        mask = 0
+        for k in kernel_ids:
+            mask |= 1 << int(k)
+        check(self._lib.lrf_ctx_profile_kernels(self._h, mask))
 
     def profile_reset(self):
         check(self._lib.lrf_ctx_profile_reset(self._h))

@@ -51,6 +51,7 @@ struct lrf_ctx {
     size_t h_stage_cap = 0;
     // profiling
     bool profile = false;
+    unsigned profile_mask = ~0u; // kernel ids (bit per LRF_K_*) that get event pairs while `profile` is on
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[LRF_K_COUNT];
     std::vector<hipEvent_t> ev_pool;
     double acc_ms[LRF_K_COUNT] = {0};
@@ -100,9 +101,10 @@ struct Prof {
     lrf_ctx* c;
     int id;
     hipEvent_t a = nullptr, b = nullptr;
-    Prof(lrf_ctx* c_, int id_) : c(c_), id(id_)
+    bool on;
+    Prof(lrf_ctx* c_, int id_) : c(c_), id(id_), on(c_->profile && ((c_->profile_mask >> id_) & 1u))
     {
-        if (!c->profile) return;
+        if (!on) return;
         auto get = [&]() {
             hipEvent_t e;
             if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); }
@@ -115,7 +117,7 @@ struct Prof {
     }
     ~Prof()
     {
-        if (!c->profile) return;
+        if (!on) return;
         (void)hipEventRecord(b, c->stream);
         c->ev[id].push_back({a, b});
     }
@@ -463,6 +465,15 @@ int lrf_ctx_profile(lrf_ctx* c, int enable)
 {
     if (!c) return set_err(LRF_EINVAL, "ctx is NULL");
     c->profile = enable != 0;
+    c->profile_mask = ~0u;
+    return LRF_OK;
+}
+
+int lrf_ctx_profile_kernels(lrf_ctx* c, unsigned mask)
+{
+    if (!c) return set_err(LRF_EINVAL, "ctx is NULL");
+    c->profile = mask != 0;
+    c->profile_mask = mask;
     return LRF_OK;
 }
 
