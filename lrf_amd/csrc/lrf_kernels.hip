@@ -213,7 +213,7 @@ struct InitLds {
 };
 
 template <int ZR>
-__global__ __launch_bounds__(256) LRF_KALIGN void k_init(const float* __restrict__ X, const PlaneDesc* __restrict__ planes,
+__global__ __launch_bounds__(256) LRF_KALIGN __attribute__((amdgpu_waves_per_eu(3, 3))) void k_init(const float* __restrict__ X, const PlaneDesc* __restrict__ planes,
                                               const int8_t* __restrict__ sign, float* __restrict__ Vf,
                                               float* __restrict__ Wf, int debug_stop, int rp)
 {
