@@ -108,7 +108,7 @@ struct BigLds {
 
 // MODE as in k_bcd.  Ppart / Qpart: per block [64][64] fp32.
 template <int MODE>
-__global__ __launch_bounds__(256) void k_bcd_big(const float* __restrict__ X, const PlaneDesc* __restrict__ planes,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_bcd_big(const float* __restrict__ X, const PlaneDesc* __restrict__ planes,
                                                  const BlockDesc* __restrict__ blocks, const float* __restrict__ Vf,
                                                  const float* __restrict__ Wf, const float* __restrict__ Bf,
                                                  const float* __restrict__ U0, int8_t* __restrict__ U,
