@@ -548,8 +548,11 @@ int lrf_qmf_planes_from_rgb_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_
     HIP_TRY(hipSetDevice(c->device));
     Prof p(c, LRF_K_PLANES);
     if ((long)H * W * 3 >= (1L << 31)) return set_err(LRF_ENOTSUP, "image too large for 32-bit pixel indexing");
-    hipLaunchKernelGGL(k_planes, dim3((unsigned)(g.p[2].pr0 + g.p[2].nh), (unsigned)B), dim3(256), 0, c->stream, rgb, (int)H,
-                       (int)W, g, X);
+    if (H % 16 == 0 && W % 16 == 0 && (reinterpret_cast<uintptr_t>(rgb) & 7) == 0)
+        hipLaunchKernelGGL(k_planes16, dim3((unsigned)(H / 16), (unsigned)B), dim3(256), 0, c->stream, rgb, (int)H, (int)W, g, X);
+    else
+        hipLaunchKernelGGL(k_planes, dim3((unsigned)(g.p[2].pr0 + g.p[2].nh), (unsigned)B), dim3(256), 0, c->stream, rgb, (int)H,
+                           (int)W, g, X);
     LAUNCH_CHECK();
     return LRF_OK;
 }

@@ -150,6 +150,63 @@ __global__ __launch_bounds__(256) LRF_KALIGN void k_planes(const uint8_t* __rest
     }
 }
 
+// Fast path of K1 for images whose sides are multiples of 16 (no padding anywhere, exact 2x2 chroma windows, 8-byte
+// aligned rows): every RGB byte is read once.  One workgroup per 16-row strip; a thread takes a 2 x 8 pixel block
+// (six 8-byte loads) and produces its sixteen luma samples and its four Cb and four Cr samples with the arithmetic and
+// orders of k_planes (ycc_of; the window sum is row-major: (0,0), (0,1), (1,0), (1,1)).
+__global__ __launch_bounds__(256) LRF_KALIGN void k_planes16(const uint8_t* __restrict__ rgb, int H, int W, ImageGeom g,
+                                                  float* __restrict__ X)
+{
+    const int strip = blockIdx.x;
+    const uint8_t* img = rgb + (long)blockIdx.y * 3 * H * W;
+    float* Xi = X + (long)blockIdx.y * g.img_floats;
+    const int hw = H * W, nwl = g.p[0].nw, nwc = g.p[1].nw;
+    for (int it = threadIdx.x; it < nwl * 8; it += 256) {
+        const int ww = it >> 3, rp = it & 7; // 8-pixel column block, row pair inside the strip
+        const int y = 16 * strip + 2 * rp, x = 8 * ww;
+        uint64_t ch[3][2];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++) ch[k][rr] = *reinterpret_cast<const uint64_t*>(img + k * hw + (y + rr) * W + x);
+        // luma: rows y, y + 1 -> patch row 2 strip + (rp >> 2), rows a = 2 (rp & 3), a + 1 of patch ww
+        float* Yp = Xi + g.p[0].xoff + ((long)(2 * strip + (rp >> 2)) * nwl + ww) * 64 + (2 * (rp & 3)) * 8;
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            f32x4 o0, o1;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                o0[i] = ycc_of((float)((ch[0][rr] >> (8 * i)) & 255u), (float)((ch[1][rr] >> (8 * i)) & 255u),
+                               (float)((ch[2][rr] >> (8 * i)) & 255u), 0);
+                o1[i] = ycc_of((float)((ch[0][rr] >> (8 * (i + 4))) & 255u), (float)((ch[1][rr] >> (8 * (i + 4))) & 255u),
+                               (float)((ch[2][rr] >> (8 * (i + 4))) & 255u), 0);
+            }
+            *reinterpret_cast<f32x4*>(Yp + 8 * rr) = o0;
+            *reinterpret_cast<f32x4*>(Yp + 8 * rr + 4) = o1;
+        }
+        // chroma: samples (8 strip + rp, 4 ww .. 4 ww + 3) -> patch row strip, row a = rp of patch ww >> 1, columns 4 (ww & 1) ..
+#pragma unroll
+        for (int c = 1; c < 3; c++) {
+            f32x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                float sum = 0.f;
+#pragma unroll
+                for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+                    for (int cc = 0; cc < 2; cc++) {
+                        const int sh = 8 * (2 * i + cc);
+                        sum = sum + ycc_of((float)((ch[0][rr] >> sh) & 255u), (float)((ch[1][rr] >> sh) & 255u),
+                                           (float)((ch[2][rr] >> sh) & 255u), c);
+                    }
+                o[i] = sum / 2.f / 2.f;
+            }
+            float* Cp = Xi + g.p[c].xoff + ((long)strip * nwc + (ww >> 1)) * 64 + rp * 8 + 4 * (ww & 1);
+            *reinterpret_cast<f32x4*>(Cp) = o;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2: SVD initialisation = fp64 Gram (MFMA f64) + top-R eigen-pairs of the 64 x 64 Gram matrix
 // (Householder tridiagonalisation, 64-way multisection on Sturm counts, twisted factorisation,
