@@ -20,6 +20,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 #define LRF_EPS 1e-16f
+// Householder columns whose squared norm is at or below this are skipped (oracle: tridiagonalize): cascaded rounding noise of
+// rank-deficient Gram matrices lands in the denormal range, where t = 2 / |v|^2 overflows
+#define LRF_SIGMA_TINY 1e-280
 // Kernel entry points are pinned to 4 KB boundaries: k_bcd_w lost a third of its speed at one unlucky offset
 // (lrf_bcdw_kernel.hip), so no kernel's placement is left to whatever precedes it in the code object.
 #define LRF_KALIGN __attribute__((aligned(4096)))
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(256) LRF_KALIGN __attribute__((amdgpu_waves_per_eu(
             double x = (i > k) ? xk : 0.0;
             double sigma = wave_tree64(x * x);
             double tk = 0.0, ek = 0.0, vi = 0.0;
-            if (sigma != 0.0) {
+            if (sigma > LRF_SIGMA_TINY) {
                 double x0 = __shfl(x, k + 1, 64);
                 double nrm = sqrt(sigma);
                 double alpha = (x0 >= 0.0) ? -nrm : nrm;
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(256) LRF_KALIGN __attribute__((amdgpu_waves_per_eu(
             }
             vbuf[i] = vi;
             if (i > k) G[k * 64 + i] = vi; // row k of the LDS matrix: v_k for the back-transformation
-            if (i == 0) { L.tau[k] = tk; L.e[k] = ek; L.scal[0] = tk; L.flag[k & 1] = (sigma != 0.0); }
+            if (i == 0) { L.tau[k] = tk; L.e[k] = ek; L.scal[0] = tk; L.flag[k & 1] = (sigma > LRF_SIGMA_TINY); }
         }
         __syncthreads();
         if (L.flag[k & 1]) { // flag double-buffered like v: a wave that skips ahead must not overwrite what others still read

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void k_eig_n(double* __restrict__ G, int N, in
     for (int k = 0; k < N - 2; k++) {
         double x = (act && i > k) ? A[(long)k * N + i] : 0.0;
         double sigma = block_sum(x * x, L.part, tid);
-        if (sigma == 0.0) {
+        if (!(sigma > LRF_SIGMA_TINY)) {
             if (tid == 0) { L.tau[k] = 0.0; L.e[k] = 0.0; }
             continue;
         }

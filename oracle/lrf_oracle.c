@@ -358,6 +358,7 @@ static double tree64(double* s)
 
 /* A (EN x EN, symmetric, destroyed) -> d[EN], e[EN-1]; reflectors H_k = I - tau_k v_k v_k^T with
  * v_k stored in Vh[k*EN + i] (zero for i <= k). */
+#define LRF_SIGMA_TINY 1e-280
 static void tridiagonalize(double* A, double* d, double* e, double* Vh, double* tau)
 {
     double s[EN], v[EN], p[EN], w[EN];
@@ -367,7 +368,9 @@ static void tridiagonalize(double* A, double* d, double* e, double* Vh, double* 
         double sigma = tree64(s);
         tau[k] = 0.0;
         e[k] = 0.0;
-        if (sigma == 0.0) continue;
+        /* a column that is zero up to cascaded rounding noise (sigma in the denormal range would overflow t = 2 / vn):
+         * rank-deficient Gram matrices, e.g. constant planes */
+        if (!(sigma > LRF_SIGMA_TINY)) continue;
         double x0 = A[(k + 1) * EN + k];
         double nrm = sqrt(sigma);
         double alpha = (x0 >= 0.0) ? -nrm : nrm;

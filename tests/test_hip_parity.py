@@ -353,3 +353,24 @@ def test_every_rank_and_other_bounds_equal_oracle(bounds, oracle):
             u, v = oracle.qmf_decompose(X[c], ranks[c], 3, bounds)
             assert np.array_equal(got[2 * c], u.astype(np.int8)), f"ranks {ranks} bounds {bounds}: U plane {c}"
             assert np.array_equal(got[2 * c + 1], v.astype(np.int8)), f"ranks {ranks} bounds {bounds}: V plane {c}"
+
+
+@pytest.mark.parametrize("bounds", [(-32, 31), (-128, 127)])
+def test_ablation_bounds_at_full_size(bounds, oracle):
+    """experiments/ablation_bounds/eval.py:51 sweeps bounds up to (-128, 127) on 512x768 images: u.mT @ u is an exact integer
+    per 384-row block and the blocks are added in the reference's order, so nothing restricts the bounds."""
+    import lrf_amd
+    from lrf_amd.codec import split_factors
+    g = torch.Generator().manual_seed(9)
+    base = torch.rand(1, 3, 64, 96, generator=g) * 255
+    img = (torch.nn.functional.interpolate(base, size=(512, 768), mode="bilinear", align_corners=False)[0]
+           + torch.randn(3, 512, 768, generator=g) * 20).clamp(0, 255).to(torch.uint8)
+    ranks = (7, 3, 3)
+    U, V = lrf_amd.qmf_factorize_batch(img.cuda().unsqueeze(0), ranks, num_iters=10, bounds=bounds)
+    got = split_factors(U[0].cpu().numpy(), V[0].cpu().numpy(), (512, 768), ranks)
+    X = oracle.rgb_to_planes(img.numpy())
+    for c in range(3):
+        u, v = oracle.qmf_decompose(X[c], ranks[c], 10, bounds)
+        assert np.array_equal(got[2 * c], u.astype(np.int8)) and np.array_equal(got[2 * c + 1], v.astype(np.int8)), f"plane {c}"
+    enc = lrf_amd.qmf_encode(img, rank=7, bounds=bounds)
+    assert lrf_amd.psnr(img.float(), lrf_amd.qmf_decode(enc).float()).item() > 15  # noisy image: 18.4 dB at rank 7
