@@ -550,7 +550,8 @@ int lrf_qmf_planes_from_rgb_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_
     Prof p(c, LRF_K_PLANES);
     if ((long)H * W * 3 >= (1L << 31)) return set_err(LRF_ENOTSUP, "image too large for 32-bit pixel indexing");
     if (H % 16 == 0 && W % 16 == 0 && (reinterpret_cast<uintptr_t>(rgb) & 7) == 0)
-        hipLaunchKernelGGL(k_planes16, dim3((unsigned)(H / 16), (unsigned)B), dim3(256), 0, c->stream, rgb, (int)H, (int)W, g, X);
+        hipLaunchKernelGGL(k_planes16, dim3((unsigned)((H / 16) * ((g.p[0].nw + 31) / 32)), (unsigned)B), dim3(256), 0, c->stream, rgb, (int)H,
+                           (int)W, g, X);
     else
         hipLaunchKernelGGL(k_planes, dim3((unsigned)(g.p[2].pr0 + g.p[2].nh), (unsigned)B), dim3(256), 0, c->stream, rgb, (int)H,
                            (int)W, g, X);
