@@ -2,16 +2,18 @@
 // one *wave* per (matrix, 384-row block) and no workgroup barrier at all.  Included by lrf_api.hip after lrf_kernels.hip.
 //
 // Per 64-row sub-tile the wave
-//   1. stores the sub-tile (prefetched one sub-tile ahead into registers: 16 coalesced float4 loads) to its private,
-//      XOR-swizzled LDS tile and reads it back with lane = row (16 ds_read_b128, conflict-free);
+//   1. stores the sub-tile (prefetched one sub-tile ahead into registers: 16 float4 loads of four whole rows each, issued
+//      in three bursts) to its private, XOR-swizzled LDS tile and reads it back with lane = row (16 ds_read_b128,
+//      conflict-free);
 //   2. computes a = x V on the VALU: one fma per (k, column), x[k] from the lane's own row and V[k][r] broadcast out of
 //      32 resident VGPRs by the DPP row_newbcast operand modifier (V is wave-uniform and constant for the block).
 //      With R <= 8 the 16-wide f32 MFMA tile would be at most half used, the VALU has the same f32 peak, and the
 //      result is already lane = row — the same k-ordered fma chain as the MFMA, bit for bit;
-//   3. solves the Gauss-Seidel recurrence in registers (gs_row, lrf_kernels.hip);
-//   4. writes the int8 row, parks u in LDS and accumulates a' += X^T u (MFMA, four independent chains over the four
-//      16-column tiles, operand read transposed from the LDS tile) and b' += u^T u (MFMA, two row groups per
-//      instruction in the two diagonal 8 x 8 blocks).
+//   3. solves the Gauss-Seidel recurrence in registers (gs_row_tab below: gs_row of lrf_kernels.hip with the b table
+//      broadcast from VGPRs the same way);
+//   4. writes the int8 row (two overlapping unaligned dword stores), parks u in LDS and accumulates a' += X^T u (MFMA,
+//      four independent chains over four strided 16-column tiles {4i + c}, so that one ds_read_b128 of the LDS tile
+//      feeds all four) and b' += u^T u (MFMA, two row groups per instruction in the two diagonal 8 x 8 blocks).
 // The summation orders are those of k_bcd (and therefore of the reference): k-ordered fma chains, one chain per
 // 384-row block, block partials added in order by k_vupdate.
 // Two waves per SIMD (18 KB LDS per wave): while one wave is in its VALU phases the other feeds the MFMA pipe; the
