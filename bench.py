@@ -106,6 +106,12 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # Set-up, before the W warm-up steps: the first call allocates the workspace and uploads the descriptor tables
+    # (16 ms), and the next two still run 10 % slow (first touch of the workspace, clock ramp): three priming calls,
+    # disclosed as config.priming_steps.
+    PRIMING = 3
+    for _ in range(PRIMING):
+        step()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -173,7 +179,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{B} x 512x768x3 uint8 per GPU, YCbCr 4:2:0, 8x8 patches, ranks (7,3,3), "
                                    f"bounds (-16,15), num_iters 10, int8 factors out (BASELINE configs[1])",
-                       "global_batch": B * world, "parallelism": f"images sharded over {world} GPU(s), no data-path collective"},
+                       "priming_steps": PRIMING, "global_batch": B * world, "parallelism": f"images sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": "k_bcd_w", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(bcd_ms, 5)},
