@@ -38,8 +38,10 @@ extern "C" {
 #define LRF_EHIP (-3)        /* a HIP runtime call failed; see lrf_last_error() */
 #define LRF_ENOMEM (-4)
 
-#define LRF_MAX_RANK 64      /* largest rank (ranks above 16 run on the untuned big-rank kernels) */
-#define LRF_PATCH_ELEMS 64   /* N = p*q handled by the kernels in this build (8x8 patches) */
+#define LRF_MAX_RANK 64      /* largest rank of the 64-column kernels (ranks above 16 run on the untuned big-rank kernels) */
+#define LRF_PATCH_ELEMS 64   /* N = p*q of the tuned kernels (8x8 patches); other N run on the any-shape kernels */
+#define LRF_ANY_MAX_SIDE 2048 /* any-shape path: largest min(M, N) of the SVD initialisation */
+#define LRF_ANY_MAX_RANK 639  /* any-shape path: largest rank */
 
 typedef struct lrf_ctx lrf_ctx;
 
@@ -105,7 +107,9 @@ int lrf_qmf_planes_from_rgb_u8(lrf_ctx* ctx, const uint8_t* rgb, int64_t B, int6
  * one shape: replaces the call sites lrf/compression/qmf.py:190,209,257,281 and the body
  * lrf/factorization/qmf.py:197-214 (SVDInit :42-71, CoordinateDescent.update_u/update_v :93-139,
  * QMF._project :191-195).
- *   X    [B,M,N] fp32, N == LRF_PATCH_ELEMS, 1 <= R <= LRF_MAX_RANK, K >= 1
+ *   X    [B,M,N] fp32, K >= 1.  N == LRF_PATCH_ELEMS with R <= LRF_MAX_RANK runs on the tuned kernels; every other shape
+ *        (the patch sizes of experiments/ablation_patchsize/eval.py:49-55, patch=False) on the any-shape kernels
+ *        (lrf_anyshape_kernels.hip; R <= LRF_ANY_MAX_RANK, min(M,N) <= LRF_ANY_MAX_SIDE for the initialisation)
  *   sign optional [B,R] int8 (NULL = default): sign imposed on sum_j (j+1) v0[j,r] of initial
  *        component r; 0 entries mean default (-1).  The reference's sign is LAPACK's arbitrary
  *        choice (SURVEY.md §7 hard part 1); passing the reference's signs reproduces its factors.
@@ -183,6 +187,27 @@ int lrf_qmf_rgbspace_encode_u8(lrf_ctx* ctx, const uint8_t* rgb, int64_t B, int6
 /* qmf_decode, RGB colour-space branch (lrf/compression/qmf.py:311-323, :351): u @ v.mT, depatchify, unpad_image,
  * to_dtype(uint8).  rgb [B,3,H,W] uint8 (device). */
 int lrf_qmf_rgbspace_decode_u8(lrf_ctx* ctx, const int8_t* U, const int8_t* V, int64_t B, int64_t H, int64_t W, int R, uint8_t* rgb);
+
+/* ---------------------------------------------------------------------------------------------------
+ * YCbCr branch with any patch size, or none: qmf_encode(color_space="YCbCr", patch_size=(p,q)) and patch=False
+ * (lrf/compression/qmf.py:227-262 and :264-286; swept by experiments/ablation_patchsize/eval.py:49-55).
+ * The host forms the matrices of one plane, factorises them with lrf_qmf_decompose_f32 (any M, N, R) and decodes with
+ * lrf_qmf_decode_any_u8.  p = q = 0 means patch=False: the matrix is the plane itself, [h, w].
+ */
+
+/* plane ch (0 = Y, 1 = Cb, 2 = Cr): size after chroma down-sampling, after reflect padding to multiples of (p,q)
+ * (lrf/compression/utils.py:108-132), and the matrix shape [M, N] (N = p*q; p = 0: M = h, N = w) */
+int lrf_plane_dims_any(int64_t H, int64_t W, int p, int q, int ch, int64_t* h, int64_t* w, int64_t* hp, int64_t* wp, int64_t* M,
+                       int64_t* N);
+
+/* rgb [B,3,H,W] uint8 -> X [B,M,N] fp32 for plane ch: rgb_to_ycbcr, chroma_downsampling(area), pad_image(reflect),
+ * patchify (qmf.py:227-242 with patch_size = (p,q); :264-269 when p = 0).  Device pointers. */
+int lrf_qmf_planes_any_u8(lrf_ctx* ctx, const uint8_t* rgb, int64_t B, int64_t H, int64_t W, int p, int q, int ch, float* X);
+
+/* qmf_decode of that branch (qmf.py:325-351): per plane u @ v.mT, depatchify + unpad_image (p > 0), nearest chroma
+ * up-sampling, ycbcr_to_rgb, to_dtype(uint8).  Uc [B,M_c,R_c], Vc [B,N_c,R_c] int8 per plane c; rgb [B,3,H,W] uint8. */
+int lrf_qmf_decode_any_u8(lrf_ctx* ctx, const int8_t* U0, const int8_t* V0, const int8_t* U1, const int8_t* V1, const int8_t* U2,
+                          const int8_t* V2, int64_t B, int64_t H, int64_t W, int p, int q, const int R[3], uint8_t* rgb);
 
 #ifdef __cplusplus
 }

@@ -67,6 +67,10 @@ def load():
         lib.lrf_qmf_rgbspace_encode_u8.argtypes = [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_void_p,
                                                    c_void_p, c_void_p, c_void_p, c_void_p]
         lib.lrf_qmf_rgbspace_decode_u8.argtypes = [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_void_p]
+        lib.lrf_plane_dims_any.argtypes = [c_i64, c_i64, c_int, c_int, c_int] + [ctypes.POINTER(c_i64)] * 6
+        lib.lrf_qmf_planes_any_u8.argtypes = [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_void_p]
+        lib.lrf_qmf_decode_any_u8.argtypes = [c_void_p] + [c_void_p] * 6 + [c_i64, c_i64, c_i64, c_int, c_int,
+                                                                           ctypes.POINTER(c_int), c_void_p]
         _lib = lib
         return lib
 
@@ -76,7 +80,8 @@ EXPORTS = ["lrf_last_error", "lrf_device_count", "lrf_version", "lrf_ctx_create"
            "lrf_ctx_profile_reset", "lrf_malloc", "lrf_free", "lrf_memcpy_h2d", "lrf_memcpy_d2h", "lrf_plane_dims",
            "lrf_qmf_planes_from_rgb_u8", "lrf_qmf_decompose_f32", "lrf_qmf_bcd_f32", "lrf_qmf_svd_init_f32",
            "lrf_qmf_encode_rgb_u8", "lrf_qmf_decode_rgb_u8", "lrf_svd_encode_rgb_u8", "lrf_svd_decode_rgb_u8",
-           "lrf_qmf_rgbspace_encode_u8", "lrf_qmf_rgbspace_decode_u8"]
+           "lrf_qmf_rgbspace_encode_u8", "lrf_qmf_rgbspace_decode_u8",
+           "lrf_plane_dims_any", "lrf_qmf_planes_any_u8", "lrf_qmf_decode_any_u8"]
 
 
 def check(rc):
@@ -98,6 +103,17 @@ def plane_dims(H, W):
     for c in range(3):
         v = [c_i64() for _ in range(5)]
         check(load().lrf_plane_dims(H, W, c, *[ctypes.byref(x) for x in v]))
+        out.append(tuple(int(x.value) for x in v))
+    return out
+
+
+def plane_dims_any(H, W, patch_size):
+    """[(h, w, hp, wp, M, N)] of the Y, Cb, Cr planes for patches (p, q); patch_size None = patch=False (M, N = h, w)."""
+    p, q = (0, 0) if patch_size is None else (int(patch_size[0]), int(patch_size[1]))
+    out = []
+    for c in range(3):
+        v = [c_i64() for _ in range(6)]
+        check(load().lrf_plane_dims_any(H, W, p, q, c, *[ctypes.byref(x) for x in v]))
         out.append(tuple(int(x.value) for x in v))
     return out
 
@@ -226,6 +242,37 @@ class Context:
         R = (c_int * 3)(*[int(r) for r in ranks])
         self.use_torch_stream()
         check(self._lib.lrf_qmf_decode_rgb_u8(self._h, _dptr(U), _dptr(V), B, H, W, R, _dptr(rgb)))
+        return rgb
+
+
+    def planes_any(self, rgb, patch_size, ch):
+        """rgb uint8 [B,3,H,W] (CUDA) -> X fp32 [B, M, N] of plane ch for patches (p, q) (None: the plane itself)"""
+        import torch
+        B, C, H, W = rgb.shape
+        assert C == 3 and rgb.dtype == torch.uint8
+        p, q = (0, 0) if patch_size is None else (int(patch_size[0]), int(patch_size[1]))
+        d = plane_dims_any(H, W, patch_size)[ch]
+        X = torch.empty((B, d[4], d[5]), dtype=torch.float32, device=rgb.device)
+        self.use_torch_stream()
+        check(self._lib.lrf_qmf_planes_any_u8(self._h, _dptr(rgb.contiguous()), B, H, W, p, q, ch, _dptr(X)))
+        return X
+
+    def decode_any(self, Us, Vs, H, W, patch_size):
+        """three (U [B,M_c,R_c], V [B,N_c,R_c]) int8 CUDA pairs -> uint8 [B,3,H,W]"""
+        import torch
+        Us = [u.contiguous() for u in Us]
+        Vs = [v.contiguous() for v in Vs]
+        B = Us[0].shape[0]
+        p, q = (0, 0) if patch_size is None else (int(patch_size[0]), int(patch_size[1]))
+        dims = plane_dims_any(H, W, patch_size)
+        for c in range(3):
+            assert Us[c].shape[1] == dims[c][4] and Vs[c].shape[1] == dims[c][5] and Us[c].shape[2] == Vs[c].shape[2], \
+                "factor shapes do not match the image geometry"
+        rgb = torch.empty((B, 3, H, W), dtype=torch.uint8, device=Us[0].device)
+        R = (c_int * 3)(*[int(u.shape[2]) for u in Us])
+        self.use_torch_stream()
+        check(self._lib.lrf_qmf_decode_any_u8(self._h, _dptr(Us[0]), _dptr(Vs[0]), _dptr(Us[1]), _dptr(Vs[1]), _dptr(Us[2]),
+                                              _dptr(Vs[2]), B, H, W, p, q, R, _dptr(rgb)))
         return rgb
 
 

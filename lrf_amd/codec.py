@@ -29,14 +29,15 @@ def qmf_ranks(image_hw, rank=None, quality=None):
 
 
 def _check_hip_branch(color_space, scale_factor, patch, patch_size, bounds, dtype, kwargs):
-    if not patch or tuple(patch_size) != (8, 8) or (color_space == "YCbCr" and tuple(scale_factor) != (0.5, 0.5)):
-        raise NotImplementedError("HIP path covers patch=True, patch_size=(8,8) and, for color_space='YCbCr', "
-                                  "scale_factor=(0.5,0.5) (the other qmf_encode branches are SURVEY.md §8f N3)")
+    if color_space == "RGB" and (not patch or tuple(patch_size) != (8, 8)):
+        raise NotImplementedError("HIP path covers color_space='RGB' with patch=True, patch_size=(8,8) only")
+    if color_space == "YCbCr" and tuple(scale_factor) != (0.5, 0.5):
+        raise NotImplementedError("HIP path covers scale_factor=(0.5,0.5) only")
     if dtype is not torch.int8:
         raise NotImplementedError("HIP path stores int8 factors only")
     num_iters = kwargs.pop("num_iters", 10)
     init_sign = kwargs.pop("init_sign", None)
-    kwargs.pop("init", None)  # RGB branch only: explicit (u0, v0) fp32 initial factors (tests)
+    kwargs.pop("init", None)  # RGB and any-shape branches: explicit (u0, v0) fp32 initial factors (tests)
     kwargs.pop("verbose", None)
     extra = {k: v for k, v in kwargs.items() if not (k in ("l2", "l1_ratio") and v in (0, (0, 0))) and
              not (k == "eps" and v == 1e-16)}
@@ -196,6 +197,9 @@ def qmf_encode(image: torch.Tensor, rank=None, quality=None, color_space: str = 
     if color_space == "RGB":
         return _qmf_encode_rgbspace(ctx, dev, rank, quality, bounds, (lo, hi), patch_size, num_iters, init_sign,
                                     kwargs.get("init"))
+    if not patch or tuple(patch_size) != (8, 8):
+        return _qmf_encode_anyshape(ctx, dev, rank, quality, bounds, (lo, hi), tuple(patch_size) if patch else None, num_iters,
+                                    init_sign, kwargs.get("init"))
     ranks = qmf_ranks((H, W), rank, quality)
     if num_iters == 0:
         factors = _svd_init_factors(ctx, dev, ranks, init_sign)
@@ -203,6 +207,95 @@ def qmf_encode(image: torch.Tensor, rank=None, quality=None, color_space: str = 
         U, V = qmf_factorize_batch(dev, ranks, num_iters, (lo, hi), init_sign)
         factors = split_factors(U[0].cpu().numpy(), V[0].cpu().numpy(), (H, W), ranks)
     return pack_image(factors, (H, W), ranks, bounds, patch_size, str(image.dtype).split(".")[-1])
+
+
+def anyshape_ranks(image_hw, patch_size, rank=None, quality=None):
+    """Ranks of (Y, Cb, Cr) for patches `patch_size` (lrf/compression/qmf.py:244-250) or, with patch_size None,
+    for patch=False (:268-274): max(round(min(M, N) * quality / 100), 1) on the matrix each plane becomes."""
+    H, W = image_hw
+    if not isinstance(rank, Iterable):
+        rank = (None, None, None) if rank is None else (rank, max(rank // 2, 1), max(rank // 2, 1))
+    if not isinstance(quality, Iterable):
+        quality = (None, None, None) if quality is None else (quality, quality / 2, quality / 2)
+    out = []
+    for i, d in enumerate(_lib.plane_dims_any(H, W, patch_size)):
+        if rank[i] is None:
+            assert quality[i] >= 0 and quality[i] <= 100, "'quality' must be between 0 and 100."
+            out.append(max(round(min(d[4], d[5]) * quality[i] / 100), 1))
+        else:
+            out.append(rank[i])
+    return out
+
+
+def _qmf_encode_anyshape(ctx, dev, rank, quality, bounds, int_bounds, patch_size, num_iters, init_sign, init):
+    """qmf_encode(color_space="YCbCr") with a patch size other than 8x8 (lrf/compression/qmf.py:232-262) or with
+    patch=False (patch_size None, :264-286): per plane one matrix [M, N], factorised on the any-shape kernels.
+    `init`: optional three (u0, v0) fp32 pairs replacing the SVD initialisation (tests)."""
+    H, W = dev.shape[-2:]
+    dims = _lib.plane_dims_any(H, W, patch_size)
+    ranks = anyshape_ranks((H, W), patch_size, rank, quality)
+    factors, soff = [], 0
+    for c in range(3):
+        X = ctx.planes_any(dev, patch_size, c)
+        R = ranks[c]
+        sign = None
+        if init_sign is not None:
+            sign = torch.as_tensor(init_sign, dtype=torch.int8).reshape(-1)[soff:soff + R].reshape(1, R).contiguous().cuda(dev.device)
+        soff += R
+        if init is not None:
+            u0 = torch.as_tensor(init[c][0], dtype=torch.float32).reshape(1, dims[c][4], R).cuda(dev.device)
+            v0 = torch.as_tensor(init[c][1], dtype=torch.float32).reshape(1, dims[c][5], R).cuda(dev.device)
+            u, v = (u0.cpu().to(torch.int8), v0.cpu().to(torch.int8)) if num_iters == 0 else \
+                ctx.bcd(X, u0, v0, num_iters, int_bounds[0], int_bounds[1])
+        elif num_iters == 0:  # the float factors go straight through torch's truncating cast (qmf.py:258-260)
+            u0, v0 = ctx.svd_init(X, R, sign)
+            u, v = u0.cpu().to(torch.int8), v0.cpu().to(torch.int8)
+        else:
+            u, v = ctx.decompose(X, R, num_iters, int_bounds[0], int_bounds[1], sign)
+        u, v = u.cpu().numpy(), v.cpu().numpy()  # [1, M, R], [1, N, R]
+        # patch=False keeps the plane's channel axis: the factors are 3-D there (qmf.py:281-282), 2-D with patches
+        factors += [u, v] if patch_size is None else [u[0], v[0]]
+    return pack_anyshape(factors, (H, W), ranks, bounds, patch_size, str(dev.dtype).split(".")[-1])
+
+
+def pack_anyshape(factors, image_hw, ranks, bounds, patch_size, dtype_name="uint8") -> bytes:
+    """Byte stream of the patch-size / patch=False branches (metadata keys in the reference's order, qmf.py:157-162,
+    233-254, 265-277, 288-290).  factors: [u_y, v_y, u_cb, v_cb, u_cr, v_cr] int8, 2-D with patches, [1, rows, R]
+    without (the reference keeps the plane's channel axis there and encode_tensor stores such tensors whole)."""
+    dims = _lib.plane_dims_any(image_hw[0], image_hw[1], patch_size)
+    metadata = {"dtype": dtype_name, "color space": "YCbCr", "patch": patch_size is not None, "bounds": bounds}
+    if patch_size is not None:
+        metadata["patch size"] = patch_size
+        metadata["original size"] = [[d[0], d[1]] for d in dims]
+        metadata["padded size"] = [[d[2], d[3]] for d in dims]
+    else:
+        metadata["original size"] = [[d[0], d[1]] for d in dims]
+    metadata["rank"] = list(ranks)
+    return combine_bytes([dict_to_bytes(metadata), combine_bytes([encode_tensor(np.ascontiguousarray(f)) for f in factors])])
+
+
+def _qmf_decode_anyshape(encoded_image: bytes, device=None) -> torch.Tensor:
+    """YCbCr branch of qmf_decode for any patch size / patch=False (qmf.py:325-351) -> uint8 CUDA tensor [3,H,W]."""
+    encoded_metadata, encoded_factors = separate_bytes(encoded_image, 2)
+    metadata = bytes_to_dict(encoded_metadata)
+    if metadata["dtype"] != "uint8":
+        raise NotImplementedError("HIP decode writes uint8 images")
+    patch_size = tuple(metadata["patch size"]) if metadata["patch"] else None
+    f = [decode_tensor(x) for x in separate_bytes(encoded_factors, 6)]
+    H, W = metadata["original size"][0]
+    dims = _lib.plane_dims_any(H, W, patch_size)
+    for c in range(3):
+        if list(metadata["original size"][c]) != [dims[c][0], dims[c][1]] or \
+                (patch_size is not None and list(metadata["padded size"][c]) != [dims[c][2], dims[c][3]]):
+            raise NotImplementedError("stream geometry is not the scale_factor=(0.5,0.5) / reflect-padded layout")
+    ctx = _lib.context(device)
+    Us, Vs = [], []
+    for c in range(3):
+        u = np.array(f[2 * c], dtype=np.int8)  # copies: decode_tensor may hand back read-only views
+        v = np.array(f[2 * c + 1], dtype=np.int8)
+        Us.append(torch.from_numpy(u.reshape(1, dims[c][4], -1)).cuda(ctx.device))
+        Vs.append(torch.from_numpy(v.reshape(1, dims[c][5], -1)).cuda(ctx.device))
+    return ctx.decode_any(Us, Vs, H, W, patch_size)[0]
 
 
 def rgbspace_dims(H, W):
@@ -317,4 +410,6 @@ def qmf_decode(encoded_image: bytes) -> torch.Tensor:
     meta = bytes_to_dict(separate_bytes(encoded_image, 2)[0])
     if meta["color space"] == "RGB":
         return _qmf_decode_rgbspace(encoded_image).cpu()
+    if not meta["patch"] or list(meta["patch size"]) != [8, 8]:
+        return _qmf_decode_anyshape(encoded_image).cpu()
     return qmf_decode_batch([encoded_image])[0].cpu()

@@ -1,0 +1,701 @@
+// lrf_anyshape_kernels.hip — QMF for matrices of any shape [M, N] and any rank: the branches of qmf_encode that do not
+// produce 64-column patch matrices (lrf/compression/qmf.py:227-286 with patch_size = (4,4), (16,16), (32,32) — the sweep of
+// experiments/ablation_patchsize/eval.py:49-55 — and patch=False, where X is the whole plane [H, W]).
+//
+// Same arithmetic as the 64-column kernels, restated shape-free (oracle/lrf_oracle.c lrf_oracle_bcd reproduces the
+// reference bit for bit for every shape and rank tried, tools/gen_golden.py `anyshape`):
+//   * every matrix product (x @ v, v.mT @ v, x.mT @ u, u.mT @ u; lrf/factorization/qmf.py:107) is one k-ordered fma chain
+//     per output element over blocks of LRF_KC = 384 of the contraction, the block sums added in block order
+//     (k_any_prod writes the block partials, k_any_fold adds them); ATen's native kernel (rounded product, then sum) when
+//     contraction * rows * cols < 400;
+//   * the Gauss-Seidel sweep over the columns of a factor (qmf.py:108-119) with `uu @ bb` in MKL's single-column order
+//     (k_any_gs), round-half-even and clamp (qmf.py:191-195).
+// The SVD initialisation (qmf.py:42-71) is this project's own: fp64 Gram matrix of the SHORT side (n = min(M, N)),
+// Householder tridiagonalisation, multisection eigenvalues, twisted-factorisation vectors, Gram-Schmidt, back-transformation
+// (k_any_gram, k_any_eig), then the long factor as X (or X^T) times e / sqrt(sigma).
+// Correctness-first, not tuned.  Included by lrf_api.hip after lrf_svd_kernels.hip (wave_sum, block_sum).
+
+// ---- batched products with the reference's summation order ------------------------------------------------------
+// P[b][blk][i][r] = chain over k in block blk of A(i,k) * Bm[k][r];  A(i,k) = A[b*a_batch + i*sai + k*sak].
+// grid (ceil(I/64), ceil(R/32) * nblk, B); each thread keeps 8 rows x 1 column.
+__global__ __launch_bounds__(256) void k_any_prod(const float* __restrict__ A, long a_batch, long sai, long sak,
+                                                  const float* __restrict__ Bm, long b_batch, float* __restrict__ P,
+                                                  int I, int D, int R, int nblk, int native)
+{
+    __shared__ float As[64 * 65];
+    __shared__ float Bs[64 * 32];
+    const int tid = threadIdx.x, tr = tid & 31, ti = tid >> 5;
+    const int rt = blockIdx.y / nblk, blk = blockIdx.y - rt * nblk;
+    const int i0 = blockIdx.x * 64, r0 = rt * 32;
+    const float* Ab = A + (long)blockIdx.z * a_batch;
+    const float* Bb = Bm + (long)blockIdx.z * b_batch;
+    const int kbeg = blk * LRF_KC;
+    const int kend = (kbeg + LRF_KC < D) ? kbeg + LRF_KC : D;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc[j] = 0.f;
+    for (int k0 = kbeg; k0 < kend; k0 += 64) {
+        const int klen = (kend - k0 < 64) ? kend - k0 : 64;
+        __syncthreads();
+        if (sak == 1) { // rows of A contiguous along k
+            for (int e = tid; e < 64 * 64; e += 256) {
+                const int kk = e & 63, ii = e >> 6;
+                float v = 0.f;
+                if (kk < klen && i0 + ii < I) v = Ab[(long)(i0 + ii) * sai + (k0 + kk)];
+                As[kk * 65 + ii] = v;
+            }
+        } else { // contiguous along i (transposed views)
+            for (int e = tid; e < 64 * 64; e += 256) {
+                const int ii = e & 63, kk = e >> 6;
+                float v = 0.f;
+                if (kk < klen && i0 + ii < I) v = Ab[(long)(i0 + ii) * sai + (long)(k0 + kk) * sak];
+                As[kk * 65 + ii] = v;
+            }
+        }
+        for (int e = tid; e < 64 * 32; e += 256) {
+            const int rr = e & 31, kk = e >> 5;
+            float v = 0.f;
+            if (kk < klen && r0 + rr < R) v = Bb[(long)(k0 + kk) * R + r0 + rr];
+            Bs[e] = v;
+        }
+        __syncthreads();
+        if (native) {
+            for (int kk = 0; kk < klen; kk++) {
+                const float b = Bs[kk * 32 + tr];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float p = As[kk * 65 + ti + 8 * j] * b;
+                    acc[j] = acc[j] + p;
+                }
+            }
+        } else {
+            for (int kk = 0; kk < klen; kk++) {
+                const float b = Bs[kk * 32 + tr];
+#pragma unroll
+                for (int j = 0; j < 8; j++) acc[j] = fmaf(As[kk * 65 + ti + 8 * j], b, acc[j]);
+            }
+        }
+    }
+    if (r0 + tr < R) {
+        float* Pp = P + (((long)blockIdx.z * nblk + blk) * I) * R + r0 + tr;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int i = i0 + ti + 8 * j;
+            if (i < I) Pp[(long)i * R] = acc[j];
+        }
+    }
+}
+
+// C[b][e] = ((P[b][0][e] + P[b][1][e]) + P[b][2][e]) + ...   e < IR;  grid (ceil(IR/256), B)
+__global__ __launch_bounds__(256) void k_any_fold(const float* __restrict__ P, float* __restrict__ C, long IR, int nblk)
+{
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= IR) return;
+    const float* Pp = P + (long)blockIdx.y * nblk * IR + e;
+    float acc = Pp[0];
+    for (int b = 1; b < nblk; b++) acc = acc + Pp[(long)b * IR];
+    C[(long)blockIdx.y * IR + e] = acc;
+}
+
+// `uu @ bb` of qmf.py:115 for column r of one row: the K = R - 1 terms j != r, in MKL's single-output-column order
+// (oracle dot_mkl_n1) or ATen's native order.  u: the row (LDS, pitch 1), b: row r of the symmetric b (uniform address).
+__device__ __forceinline__ float any_term2(const float* u, const float* __restrict__ b, int r, int R, bool native)
+{
+    const int K = R - 1;
+    if (K <= 0) return 0.f;
+#define ANY_J(n) ((n) < r ? (n) : (n) + 1)
+    if (native) {
+        float acc = 0.f;
+        for (int n = 0; n < K; n++) {
+            const int j = ANY_J(n);
+            const float p = u[j] * b[j];
+            acc = acc + p;
+        }
+        return acc;
+    }
+    const int j0 = ANY_J(0);
+    if (K == 1) return u[j0] * b[j0];
+    const int j1 = ANY_J(1);
+    float odd = fmaf(u[j1], b[j1], u[j0] * b[j0]);
+    const int last_odd = ((K - 1) & 1) ? K - 1 : K - 2;
+    for (int n = last_odd; n >= 3; n -= 2) {
+        const int j = ANY_J(n);
+        const float p = u[j] * b[j];
+        odd = odd + p;
+    }
+    if (K < 3) return odd;
+    const int j2 = ANY_J(2);
+    float even = u[j2] * b[j2];
+    for (int n = 4; n < K; n += 2) {
+        const int j = ANY_J(n);
+        const float p = u[j] * b[j];
+        even = even + p;
+    }
+    return odd + even;
+#undef ANY_J
+}
+
+// Gauss-Seidel over the R columns of 64 rows (lane = row); the rows sit in LDS with an odd pitch.
+// a [B][I][R], bm [B][R][R] (symmetric), F [B][I][R] updated in place.  grid (ceil(I/64), B), 64 threads,
+// dynamic LDS 64 * (R | 1) floats.
+__global__ __launch_bounds__(64) void k_any_gs(const float* __restrict__ a, const float* __restrict__ bm, float* __restrict__ F,
+                                               int I, int R, int native, float lo, float hi)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* us = reinterpret_cast<float*>(smem);
+    const int RP = R | 1, lane = threadIdx.x;
+    const int row0 = blockIdx.x * 64;
+    const int nrows = (I - row0 < 64) ? I - row0 : 64;
+    float* Fb = F + ((long)blockIdx.y * I + row0) * R;
+    const float* ab = a + ((long)blockIdx.y * I + row0) * R;
+    const float* bb = bm + (long)blockIdx.y * R * R;
+    for (int e = lane; e < nrows * R; e += 64) {
+        const int row = e / R, r = e - row * R;
+        us[row * RP + r] = Fb[e];
+    }
+    __syncthreads();
+    if (lane < nrows) {
+        float* u = us + lane * RP;
+        for (int r = 0; r < R; r++) {
+            const float* brow = bb + (long)r * R;
+            const float term2 = any_term2(u, brow, r, R, native != 0);
+            const float num = (ab[(long)lane * R + r] - term2) + LRF_EPS;
+            const float den = (brow[r] + 0.f) + LRF_EPS;
+            const float val = rintf(num / den);
+            u[r] = fminf(fmaxf(val, lo), hi);
+        }
+    }
+    __syncthreads();
+    for (int e = lane; e < nrows * R; e += 64) {
+        const int row = e / R, r = e - row * R;
+        Fb[e] = us[row * RP + r];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_any_to_i8(const float* __restrict__ F, int8_t* __restrict__ O, long n)
+{
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e < n) O[e] = (int8_t)F[e];
+}
+
+// ---- initialisation -------------------------------------------------------------------------------------------
+// fp64 Gram matrix of the short side: G[i][j] = sum_k A(k,i) A(k,j), A(k,i) = X[k*sgk + i*sgi]; k ascending, one fma
+// chain per element (the products of two fp32 are exact in fp64).  32 x 32 tile per workgroup, upper tiles mirrored.
+// grid (nt, nt, B)
+__global__ __launch_bounds__(256) void k_any_gram(const float* __restrict__ X, long x_batch, long sgk, long sgi, int n, int D,
+                                                  double* __restrict__ G)
+{
+    if (blockIdx.y < blockIdx.x) return;
+    __shared__ float Is[64 * 33], Js[64 * 33];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int i0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+    const float* Xb = X + (long)blockIdx.z * x_batch;
+    double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+    for (int k0 = 0; k0 < D; k0 += 64) {
+        const int klen = (D - k0 < 64) ? D - k0 : 64;
+        __syncthreads();
+        for (int e = tid; e < 64 * 32; e += 256) {
+            int kk, cc;
+            if (sgk == 1) { kk = e & 63; cc = e >> 6; } else { cc = e & 31; kk = e >> 5; }
+            float vi = 0.f, vj = 0.f;
+            if (kk < klen) {
+                if (i0 + cc < n) vi = Xb[(long)(k0 + kk) * sgk + (long)(i0 + cc) * sgi];
+                if (j0 + cc < n) vj = Xb[(long)(k0 + kk) * sgk + (long)(j0 + cc) * sgi];
+            }
+            Is[kk * 33 + cc] = vi;
+            Js[kk * 33 + cc] = vj;
+        }
+        __syncthreads();
+        for (int kk = 0; kk < klen; kk++) {
+            const double a0 = (double)Is[kk * 33 + ty], a1 = (double)Is[kk * 33 + ty + 16];
+            const double b0 = (double)Js[kk * 33 + tx], b1 = (double)Js[kk * 33 + tx + 16];
+            acc[0][0] = fma(a0, b0, acc[0][0]);
+            acc[0][1] = fma(a0, b1, acc[0][1]);
+            acc[1][0] = fma(a1, b0, acc[1][0]);
+            acc[1][1] = fma(a1, b1, acc[1][1]);
+        }
+    }
+    double* Gb = G + (long)blockIdx.z * n * n;
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int i = i0 + ty + 16 * p, j = j0 + tx + 16 * q;
+            if (i < n && j < n) {
+                Gb[(long)i * n + j] = acc[p][q];
+                if (blockIdx.x != blockIdx.y) Gb[(long)j * n + i] = acc[p][q];
+            }
+        }
+}
+
+// the diagonal tiles above compute (i,j) and (j,i) by the same chain of the same commuting products: exactly symmetric.
+
+// Top-R eigen-pairs of the n x n Gram matrix G (global, destroyed): E1 = e sqrt(sigma), E2 = e / sqrt(sigma), fp32 [n][R].
+// One workgroup per matrix; thread t owns the columns t, t + 256, ... (NC = ceil(n/256) <= NCT of them).
+// Workspaces per matrix: Z [R][n] doubles (vectors), Dw [2][n][Rc] doubles (the two pivots sequences of the twisted
+// factorisation).  Dynamic LDS: six n-vectors, lam[R], reduction scratch.
+template <int NCT>
+__global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, int R, const int8_t* __restrict__ sign,
+                                                 float* __restrict__ E1, float* __restrict__ E2, double* __restrict__ Zw,
+                                                 double* __restrict__ Dw)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* Lv = reinterpret_cast<double*>(smem);
+    double* Lw = Lv + n;
+    double* Ld = Lw + n;
+    double* Le = Ld + n;
+    double* Le2 = Le + n;
+    double* Ltau = Le2 + n;
+    double* Llam = Ltau + n;      // [R]
+    double* Lpart = Llam + R;     // [16]
+    double* Lscal = Lpart + 16;   // [8]
+    const int Rc = R < n ? R : n;
+    double* A = G + (long)blockIdx.x * n * n;
+    double* Z = Zw + (long)blockIdx.x * Rc * n;
+    double* Dp = Dw + (long)blockIdx.x * 2 * n * Rc;
+    double* Dm = Dp + (long)n * Rc;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- Householder tridiagonalisation; row k of A keeps the reflector v_k
+    for (int k = 0; k < n - 2; k++) {
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < NCT; c++) {
+            const int i = tid + 256 * c;
+            if (i < n && i > k) { const double x = A[(long)k * n + i]; s = fma(x, x, s); }
+        }
+        const double sigma = block_sum(s, Lpart, tid);
+        if (!(sigma > LRF_SIGMA_TINY)) {
+            if (tid == 0) { Ltau[k] = 0.0; Le[k] = 0.0; }
+            continue;
+        }
+        const double x0 = A[(long)k * n + k + 1];
+        const double nrm = sqrt(sigma);
+        const double alpha = (x0 >= 0.0) ? -nrm : nrm;
+        double vi[NCT];
+        s = 0.0;
+#pragma unroll
+        for (int c = 0; c < NCT; c++) {
+            const int i = tid + 256 * c;
+            double v = 0.0;
+            if (i < n) {
+                if (i > k + 1) v = A[(long)k * n + i];
+                else if (i == k + 1) v = x0 - alpha;
+                Lv[i] = v;
+                if (i > k) A[(long)k * n + i] = v;
+            }
+            vi[c] = v;
+            s = fma(v, v, s);
+        }
+        const double vn = block_sum(s, Lpart, tid); // its barriers publish Lv
+        const double t = 2.0 / vn;
+        if (tid == 0) { Ltau[k] = t; Le[k] = alpha; }
+        double cc[NCT];
+#pragma unroll
+        for (int c = 0; c < NCT; c++) cc[c] = 0.0;
+        for (int j = k + 1; j < n; j++) {
+            const double vj = Lv[j];
+            const double* Aj = A + (long)j * n;
+#pragma unroll
+            for (int c = 0; c < NCT; c++) {
+                const int i = tid + 256 * c;
+                if (i < n && i > k) cc[c] = fma(Aj[i], vj, cc[c]);
+            }
+        }
+        s = 0.0;
+#pragma unroll
+        for (int c = 0; c < NCT; c++) {
+            cc[c] = t * cc[c];
+            s = fma(cc[c], vi[c], s);
+        }
+        const double Kc = (0.5 * t) * block_sum(s, Lpart, tid);
+        double wi[NCT];
+#pragma unroll
+        for (int c = 0; c < NCT; c++) {
+            const int i = tid + 256 * c;
+            wi[c] = fma(-Kc, vi[c], cc[c]);
+            if (i < n) Lw[i] = wi[c];
+        }
+        __syncthreads();
+        for (int r = k + 1; r < n; r++) {
+            const double vr = Lv[r], wr = Lw[r];
+            double* Ar = A + (long)r * n;
+#pragma unroll
+            for (int c = 0; c < NCT; c++) {
+                const int i = tid + 256 * c;
+                if (i < n && i > k) {
+                    const bool rc = r >= i; // canonical (row >= column) operand order: the matrix stays exactly symmetric
+                    const double va = rc ? vr : vi[c], wa = rc ? wr : wi[c], vb = rc ? vi[c] : vr, wb = rc ? wi[c] : wr;
+                    Ar[i] = fma(-wa, vb, fma(-va, wb, Ar[i]));
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int c = 0; c < NCT; c++) {
+        const int i = tid + 256 * c;
+        if (i < n) Ld[i] = A[(long)i * n + i];
+    }
+    if (tid == 0) {
+        if (n >= 2) { Le[n - 2] = A[(long)(n - 1) * n + n - 2]; Ltau[n - 2] = 0.0; }
+        Le[n - 1] = 0.0;
+        Ltau[n - 1] = 0.0;
+    }
+    __syncthreads();
+
+    // ---- Gershgorin hull, pivmin
+    {
+        double a = 1e300, b = -1e300, m2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < NCT; c++) {
+            const int i = tid + 256 * c;
+            if (i < n) {
+                const double ei = (i < n - 1) ? Le[i] : 0.0, eim = (i > 0) ? Le[i - 1] : 0.0;
+                Le2[i] = ei * ei;
+                const double rad = fabs(eim) + fabs(ei);
+                a = fmin(a, Ld[i] - rad);
+                b = fmax(b, Ld[i] + rad);
+                m2 = fmax(m2, ei * ei);
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            a = fmin(a, __shfl_xor(a, off, 64));
+            b = fmax(b, __shfl_xor(b, off, 64));
+            m2 = fmax(m2, __shfl_xor(m2, off, 64));
+        }
+        if (lane == 0) { Lpart[wave] = a; Lpart[4 + wave] = b; Lpart[8 + wave] = m2; }
+        __syncthreads();
+        if (tid == 0) {
+            const double lo = fmin(fmin(Lpart[0], Lpart[1]), fmin(Lpart[2], Lpart[3]));
+            const double hi = fmax(fmax(Lpart[4], Lpart[5]), fmax(Lpart[6], Lpart[7]));
+            const double e2m = fmax(fmax(Lpart[8], Lpart[9]), fmax(Lpart[10], Lpart[11]));
+            const double tn = fabs(lo) > fabs(hi) ? fabs(lo) : fabs(hi);
+            const double pivmin = 2.2250738585072014e-300 * (e2m > 1.0 ? e2m : 1.0);
+            const double slack = 2.0 * tn * 2.220446049250313e-16 * n + 2.0 * pivmin;
+            Lscal[1] = pivmin; Lscal[2] = lo - slack; Lscal[3] = hi + slack;
+        }
+        __syncthreads();
+    }
+    const double pivmin = Lscal[1];
+    // ---- eigenvalues: one wave per eigenvalue, 64 shifts per pass, 10 passes (interval / 65^10)
+    for (int r = wave; r < Rc; r += 4) {
+        const int kk = n - 1 - r;
+        double a = Lscal[2], b = Lscal[3];
+        for (int pass = 0; pass < 10; pass++) {
+            const double h = (b - a) / 65.0;
+            const double x = a + h * (double)(lane + 1);
+            double q = Ld[0] - x;
+            int cnt = q < 0.0;
+            for (int j = 1; j < n; j++) {
+                if (fabs(q) < pivmin) q = -pivmin;
+                q = (Ld[j] - x) - Le2[j - 1] / q;
+                cnt += q < 0.0;
+            }
+            const unsigned long long mask = __ballot(cnt > kk);
+            const int jj = mask ? (int)__builtin_ctzll(mask) : 64;
+            const double xm = __shfl(x, jj > 0 ? jj - 1 : 0, 64), xj = __shfl(x, jj < 64 ? jj : 63, 64);
+            const double na = (jj == 0) ? a : xm, nb = (jj == 64) ? b : xj;
+            a = na;
+            b = nb;
+        }
+        if (lane == 0) Llam[r] = 0.5 * (a + b);
+    }
+    __syncthreads();
+    // ---- twisted factorisation, thread per eigenvalue
+    for (int r = tid; r < Rc; r += 256) {
+        const double lam = Llam[r];
+        double q = Ld[0] - lam;
+        Dp[r] = q;
+        for (int j = 1; j < n; j++) {
+            if (fabs(q) < pivmin) q = -pivmin;
+            q = (Ld[j] - lam) - Le2[j - 1] / q;
+            Dp[(long)j * Rc + r] = q;
+        }
+        q = Ld[n - 1] - lam;
+        Dm[(long)(n - 1) * Rc + r] = q;
+        for (int j = n - 2; j >= 0; j--) {
+            if (fabs(q) < pivmin) q = -pivmin;
+            q = (Ld[j] - lam) - Le2[j] / q;
+            Dm[(long)j * Rc + r] = q;
+        }
+        int kt = 0;
+        double best = 0.0;
+        for (int j = 0; j < n; j++) {
+            const double g = fabs((Dp[(long)j * Rc + r] + Dm[(long)j * Rc + r]) - (Ld[j] - lam));
+            if (j == 0 || g < best) { best = g; kt = j; }
+        }
+        double* x = Z + (long)r * n;
+        double xv = 1.0;
+        x[kt] = 1.0;
+        for (int j = kt - 1; j >= 0; j--) {
+            double qq = Dp[(long)j * Rc + r];
+            if (fabs(qq) < pivmin) qq = -pivmin;
+            xv = -(Le[j] / qq) * xv;
+            x[j] = xv;
+        }
+        xv = 1.0;
+        for (int j = kt; j < n - 1; j++) {
+            double qq = Dm[(long)(j + 1) * Rc + r];
+            if (fabs(qq) < pivmin) qq = -pivmin;
+            xv = -(Le[j] / qq) * xv;
+            x[j + 1] = xv;
+        }
+    }
+    __syncthreads();
+    // ---- orthonormalisation: classical Gram-Schmidt, twice, against the vectors already fixed
+    for (int r = 0; r < Rc; r++) {
+        double* Zr = Z + (long)r * n;
+        double x[NCT];
+        bool fin = true;
+#pragma unroll
+        for (int c = 0; c < NCT; c++) {
+            const int i = tid + 256 * c;
+            x[c] = (i < n) ? Zr[i] : 0.0;
+            fin = fin && isfinite(x[c]);
+        }
+        bool use_twisted = __syncthreads_and(fin) != 0;
+        int uidx = 0;
+        for (;;) {
+            if (use_twisted) {
+                double s = 0.0;
+#pragma unroll
+                for (int c = 0; c < NCT; c++) s = fma(x[c], x[c], s);
+                const double n0 = sqrt(block_sum(s, Lpart, tid));
+#pragma unroll
+                for (int c = 0; c < NCT; c++) x[c] = x[c] / n0;
+            } else {
+                if (uidx >= n) break;
+#pragma unroll
+                for (int c = 0; c < NCT; c++) x[c] = (tid + 256 * c == uidx) ? 1.0 : 0.0;
+                uidx++;
+            }
+            for (int pass = 0; pass < 2 && r > 0; pass++) {
+#pragma unroll
+                for (int c = 0; c < NCT; c++) {
+                    const int i = tid + 256 * c;
+                    if (i < n) Lv[i] = x[c];
+                }
+                __syncthreads();
+                for (int pr = wave; pr < r; pr += 4) {
+                    const double* Zp = Z + (long)pr * n;
+                    double dsum = 0.0;
+                    for (int i = lane; i < n; i += 64) dsum = fma(Zp[i], Lv[i], dsum);
+                    dsum = wave_sum(dsum);
+                    if (lane == 0) Lw[pr] = dsum;
+                }
+                __syncthreads();
+                for (int pr = 0; pr < r; pr++) {
+                    const double cf = Lw[pr];
+                    const double* Zp = Z + (long)pr * n;
+#pragma unroll
+                    for (int c = 0; c < NCT; c++) {
+                        const int i = tid + 256 * c;
+                        if (i < n) x[c] = fma(-cf, Zp[i], x[c]);
+                    }
+                }
+                __syncthreads();
+            }
+            double s = 0.0;
+#pragma unroll
+            for (int c = 0; c < NCT; c++) s = fma(x[c], x[c], s);
+            const double n2 = block_sum(s, Lpart, tid);
+            if (n2 > 1e-6 && n2 < 1e300) {
+                const double nr = sqrt(n2);
+#pragma unroll
+                for (int c = 0; c < NCT; c++) x[c] = x[c] / nr;
+                break;
+            }
+            use_twisted = false;
+        }
+#pragma unroll
+        for (int c = 0; c < NCT; c++) {
+            const int i = tid + 256 * c;
+            if (i < n) Zr[i] = x[c];
+        }
+        __syncthreads();
+    }
+    // ---- back-transformation x <- H_0 H_1 ... H_{n-3} x, CW vectors per wave at a time, lane owns i = lane + 64 e
+    constexpr int NE = 4 * NCT, CW = 32 / NE;
+    float* E1b = E1 + (long)blockIdx.x * n * R;
+    float* E2b = E2 + (long)blockIdx.x * n * R;
+    for (int g0 = wave * CW; g0 < Rc; g0 += 4 * CW) {
+        double x[CW][NE];
+#pragma unroll
+        for (int w = 0; w < CW; w++)
+#pragma unroll
+            for (int e = 0; e < NE; e++) {
+                const int i = lane + 64 * e;
+                x[w][e] = (g0 + w < Rc && i < n) ? Z[(long)(g0 + w) * n + i] : 0.0;
+            }
+        for (int k = n - 3; k >= 0; k--) {
+            const double tk = Ltau[k];
+            if (tk == 0.0) continue;
+            const double* Ak = A + (long)k * n;
+            double v[NE];
+#pragma unroll
+            for (int e = 0; e < NE; e++) {
+                const int i = lane + 64 * e;
+                v[e] = (i < n && i > k) ? Ak[i] : 0.0;
+            }
+#pragma unroll
+            for (int w = 0; w < CW; w++) {
+                double dsum = 0.0;
+#pragma unroll
+                for (int e = 0; e < NE; e++) dsum = fma(v[e], x[w][e], dsum);
+                const double sc = tk * wave_sum(dsum);
+#pragma unroll
+                for (int e = 0; e < NE; e++) x[w][e] = fma(-sc, v[e], x[w][e]);
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < CW; w++) {
+            const int r = g0 + w;
+            if (r >= Rc) continue;
+            double dsum = 0.0;
+#pragma unroll
+            for (int e = 0; e < NE; e++) dsum = fma((double)(lane + 64 * e + 1), x[w][e], dsum);
+            const double dot = wave_sum(dsum);
+            const double lam = Llam[r];
+            const double sr = sqrt(sqrt(lam > 1e-200 ? lam : 0.0));
+            const int sg = sign ? (int)sign[(long)blockIdx.x * R + r] : 0;
+            const double want = sg ? (double)sg : -1.0;
+            const double flip = ((dot < 0.0 ? -1.0 : 1.0) == want) ? 1.0 : -1.0;
+#pragma unroll
+            for (int e = 0; e < NE; e++) {
+                const int i = lane + 64 * e;
+                if (i < n) {
+                    const double ev = flip * x[w][e];
+                    E1b[(long)i * R + r] = (float)(ev * sr);
+                    E2b[(long)i * R + r] = (sr > 0.0) ? (float)(ev / sr) : 0.f;
+                }
+            }
+        }
+    }
+    // columns r >= min(M, N): zero (qmf.py:50-52)
+    for (long e = tid; e < (long)n * (R - Rc); e += 256) {
+        const long i = e / (R - Rc), r = Rc + (e - i * (R - Rc));
+        E1b[i * R + r] = 0.f;
+        E2b[i * R + r] = 0.f;
+    }
+}
+
+// Column signs when the eigenvectors belong to the M side (M < N): the convention of include/lrf_hip.h speaks of v0, so the
+// sign of sum_j (j+1) v0[j,r] is evaluated on the finished factor and both columns are flipped where it differs from the
+// wanted one (sign[r], or -1).  One workgroup per matrix.
+__global__ __launch_bounds__(256) void k_any_signfix(float* __restrict__ Uf, float* __restrict__ Vf, int M, int N, int R,
+                                                     const int8_t* __restrict__ sign)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* flip = reinterpret_cast<float*>(smem); // [R]
+    float* Ub = Uf + (long)blockIdx.x * M * R;
+    float* Vb = Vf + (long)blockIdx.x * N * R;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int r = wave; r < R; r += 4) {
+        double acc = 0.0;
+        for (int j = lane; j < N; j += 64) acc = fma((double)(j + 1), (double)Vb[(long)j * R + r], acc);
+        acc = wave_sum(acc);
+        const int sg = sign ? (int)sign[(long)blockIdx.x * R + r] : 0;
+        const double want = sg ? (double)sg : -1.0;
+        if (lane == 0) flip[r] = ((acc < 0.0 ? -1.0 : 1.0) == want) ? 1.f : -1.f;
+    }
+    __syncthreads();
+    for (long e = tid; e < (long)M * R; e += 256) Ub[e] = flip[e % R] * Ub[e];
+    for (long e = tid; e < (long)N * R; e += 256) Vb[e] = flip[e % R] * Vb[e];
+}
+
+// ---- colour planes for any patch size, and the matching decode ---------------------------------------------------
+// Plane c of B images as matrices: patches of p x q (reflect-padded plane, patchify "c (h p) (w q) -> (h w) (c p q)",
+// qmf.py:43-56) or, with p = 0, the plane itself [h, w].  One thread per matrix element; arithmetic as k_planes.
+__global__ __launch_bounds__(256) void k_any_planes(const uint8_t* __restrict__ rgb, int H, int W, int c, int h, int w, int p, int q,
+                                                    int top, int left, int nw, long mat_elems, float* __restrict__ X)
+{
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= mat_elems) return;
+    int y, x;
+    if (p > 0) {
+        const int N = p * q;
+        const long m = e / N;
+        const int col = (int)(e - m * N);
+        const int ph = (int)(m / nw), pw = (int)(m - (long)ph * nw);
+        y = reflect_idx(ph * p + col / q - top, h);
+        x = reflect_idx(pw * q + col % q - left, w);
+    } else {
+        y = (int)(e / w);
+        x = (int)(e - (long)y * w);
+    }
+    const uint8_t* img = rgb + (long)blockIdx.y * 3 * H * W;
+    const int hw = H * W;
+    float out;
+    if (c == 0) {
+        const uint8_t* p0 = img + (long)y * W + x;
+        out = ycc_of((float)p0[0], (float)p0[hw], (float)p0[2 * hw], 0);
+    } else { // adaptive average pooling window, row-major fp32 sum, then / kh / kw
+        const int h0 = (int)(((long)y * H) / h), h1 = (int)((((long)y + 1) * H + h - 1) / h);
+        const int w0 = (int)(((long)x * W) / w), w1 = (int)((((long)x + 1) * W + w - 1) / w);
+        float sum = 0.f;
+        for (int yy = h0; yy < h1; yy++)
+            for (int xx = w0; xx < w1; xx++) {
+                const uint8_t* p0 = img + (long)yy * W + xx;
+                sum = sum + ycc_of((float)p0[0], (float)p0[hw], (float)p0[2 * hw], c);
+            }
+        out = sum / (float)(h1 - h0) / (float)(w1 - w0);
+    }
+    X[(long)blockIdx.y * mat_elems + e] = out;
+}
+
+struct AnyDecodePlane {
+    const int8_t* U;
+    const int8_t* V;
+    long u_img, v_img; // elements per image
+    int h, w, p, q, top, left, nw, R;
+};
+
+__device__ __forceinline__ float any_recon(const AnyDecodePlane& d, long img, int y, int x)
+{
+    long m;
+    int col;
+    if (d.p > 0) {
+        const int yy = y + d.top, xx = x + d.left;
+        m = (long)(yy / d.p) * d.nw + xx / d.q;
+        col = (yy % d.p) * d.q + xx % d.q;
+    } else {
+        m = y;
+        col = x;
+    }
+    const int8_t* u = d.U + img * d.u_img + m * d.R;
+    const int8_t* v = d.V + img * d.v_img + (long)col * d.R;
+    float acc = 0.f; // u @ v.mT: exact small integers, any order
+    for (int r = 0; r < d.R; r++) acc = fmaf((float)u[r], (float)v[r], acc);
+    return acc;
+}
+
+// qmf_decode of the YCbCr branch for any patch size / no patches (qmf.py:325-351): one thread per pixel
+__global__ __launch_bounds__(256) void k_any_decode(AnyDecodePlane d0, AnyDecodePlane d1, AnyDecodePlane d2, int H, int W,
+                                                    uint8_t* __restrict__ rgb)
+{
+    const long o = (long)blockIdx.x * 256 + threadIdx.x;
+    if (o >= (long)H * W) return;
+    const int y = (int)(o / W), x = (int)(o - (long)y * W);
+    const float T[3][3] = {{1.0f, 0.0f, 1.402f}, {1.0f, -0.344136f, -0.714136f}, {1.0f, 1.772f, 0.0f}};
+    const float sh = (float)d1.h / (float)H, sw = (float)d1.w / (float)W;
+    int sy = (int)floorf((float)y * sh), sx = (int)floorf((float)x * sw);
+    if (sy > d1.h - 1) sy = d1.h - 1;
+    if (sx > d1.w - 1) sx = d1.w - 1;
+    float cv[3];
+    cv[0] = any_recon(d0, blockIdx.y, y, x) + 0.f;
+    cv[1] = any_recon(d1, blockIdx.y, sy, sx) + -128.f;
+    cv[2] = any_recon(d2, blockIdx.y, sy, sx) + -128.f;
+    uint8_t* out = rgb + (long)blockIdx.y * 3 * H * W;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        float acc = 0.f;
+        acc = fmaf(T[ch][0], cv[0], acc);
+        acc = fmaf(T[ch][1], cv[1], acc);
+        acc = fmaf(T[ch][2], cv[2], acc);
+        acc = fminf(fmaxf(acc, 0.f), 255.f);
+        out[(long)ch * H * W + o] = (uint8_t)acc; // truncation (to_dtype)
+    }
+}

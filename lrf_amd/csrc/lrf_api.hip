@@ -16,6 +16,7 @@
 #include "lrf_bigrank_kernels.hip"
 #include "lrf_bcdw_kernel.hip"
 #include "lrf_qmfn_kernels.hip"
+#include "lrf_anyshape_kernels.hip"
 
 static thread_local char g_err[512] = "";
 
@@ -46,6 +47,7 @@ struct lrf_ctx {
     hipStream_t own_stream = nullptr;
     DevBuf planes, blocks, vf, wf, bf, ppart, qpart, x, sign;
     DevBuf sx, sg, svn, swn, suf, smm; // SVD baseline workspace
+    DevBuf any_uf, any_vf, any_a, any_b, any_p, any_e2, any_g, any_x; // any-shape path (lrf_anyshape_host.inc)
     // host staging for descriptor tables (pinned)
     void* h_stage = nullptr;
     size_t h_stage_cap = 0;
@@ -379,6 +381,8 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
 }
 
 // ---- C ABI ------------------------------------------------------------------------------------
+#include "lrf_anyshape_host.inc"
+
 extern "C" {
 
 const char* lrf_last_error(void) { return g_err; }
@@ -421,7 +425,8 @@ void lrf_ctx_destroy(lrf_ctx* c)
     fold_events(c);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     DevBuf* bufs[] = {&c->planes, &c->blocks, &c->vf, &c->wf, &c->bf, &c->ppart, &c->qpart, &c->x, &c->sign,
-                      &c->sx, &c->sg, &c->svn, &c->swn, &c->suf, &c->smm};
+                      &c->sx, &c->sg, &c->svn, &c->swn, &c->suf, &c->smm,
+                      &c->any_uf, &c->any_vf, &c->any_a, &c->any_b, &c->any_p, &c->any_e2, &c->any_g, &c->any_x};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -569,6 +574,7 @@ int lrf_qmf_decompose_f32(lrf_ctx* c, const float* X, int64_t B, int64_t M, int6
                           const int8_t* sign, int8_t* U, int8_t* V)
 {
     if (!c || !X || !U || !V) return set_err(LRF_EINVAL, "NULL argument");
+    if (N != LRF_PATCH_ELEMS || R > LRF_MAX_RANK) return any_decompose(c, X, B, M, N, R, K, lo, hi, sign, U, V);
     int rc = check_params(M, N, R, K, lo, hi);
     if (rc) return rc;
     if (B < 1) return set_err(LRF_EINVAL, "B must be >= 1");
@@ -584,6 +590,7 @@ int lrf_qmf_bcd_f32(lrf_ctx* c, const float* X, int64_t B, int64_t M, int64_t N,
                     const float* U0, const float* V0, int8_t* U, int8_t* V)
 {
     if (!c || !X || !U || !V || !U0 || !V0) return set_err(LRF_EINVAL, "NULL argument");
+    if (N != LRF_PATCH_ELEMS || R > LRF_MAX_RANK) return any_bcd(c, X, B, M, N, R, K, lo, hi, U0, V0, U, V);
     int rc = check_params(M, N, R, K, lo, hi);
     if (rc) return rc;
     if (B < 1) return set_err(LRF_EINVAL, "B must be >= 1");
@@ -601,6 +608,7 @@ int lrf_qmf_svd_init_f32(lrf_ctx* c, const float* X, int64_t B, int64_t M, int64
                          float* U0, float* V0)
 {
     if (!c || !X || !U0 || !V0) return set_err(LRF_EINVAL, "NULL argument");
+    if (N != LRF_PATCH_ELEMS || R > LRF_MAX_RANK) return any_svd_init(c, X, B, M, N, R, sign, U0, V0);
     int rc = check_params(M, N, R, 1, -16, 15);
     if (rc) return rc;
     if (B < 1) return set_err(LRF_EINVAL, "B must be >= 1");
@@ -906,6 +914,59 @@ int lrf_qmf_rgbspace_decode_u8(lrf_ctx* c, const int8_t* U, const int8_t* V, int
     Prof p(c, LRF_K_DECODE);
     hipLaunchKernelGGL(k_qmf_decode_rgbspace, dim3((unsigned)((n + 255) / 256), (unsigned)B), dim3(256), 0, c->stream, U, V, (int)H, (int)W,
                        top, left, nw, M, R, rgb);
+    LAUNCH_CHECK();
+    return LRF_OK;
+}
+
+int lrf_plane_dims_any(int64_t H, int64_t W, int p, int q, int ch, int64_t* h, int64_t* w, int64_t* hp, int64_t* wp, int64_t* M,
+                       int64_t* N)
+{
+    if (!h || !w || !hp || !wp || !M || !N) return set_err(LRF_EINVAL, "NULL argument");
+    AnyGeom g;
+    int rc = any_geom(H, W, p, q, ch, &g);
+    if (rc) return rc;
+    *h = g.h; *w = g.w; *hp = g.hp; *wp = g.wp; *M = g.M; *N = g.N;
+    return LRF_OK;
+}
+
+int lrf_qmf_planes_any_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_t H, int64_t W, int p, int q, int ch, float* X)
+{
+    if (!c || !rgb || !X) return set_err(LRF_EINVAL, "NULL argument");
+    if (B < 1 || B > 65535) return set_err(LRF_EINVAL, "B=%ld out of range [1,65535]", (long)B);
+    AnyGeom g;
+    int rc = any_geom(H, W, p, q, ch, &g);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    const long elems = g.M * g.N;
+    Prof pr(c, LRF_K_PLANES);
+    hipLaunchKernelGGL(k_any_planes, dim3((unsigned)((elems + 255) / 256), (unsigned)B), dim3(256), 0, c->stream, rgb, (int)H, (int)W, ch,
+                       g.h, g.w, p, q, g.top, g.left, g.nw, elems, X);
+    LAUNCH_CHECK();
+    return LRF_OK;
+}
+
+int lrf_qmf_decode_any_u8(lrf_ctx* c, const int8_t* U0, const int8_t* V0, const int8_t* U1, const int8_t* V1, const int8_t* U2,
+                          const int8_t* V2, int64_t B, int64_t H, int64_t W, int p, int q, const int R[3], uint8_t* rgb)
+{
+    if (!c || !U0 || !V0 || !U1 || !V1 || !U2 || !V2 || !R || !rgb) return set_err(LRF_EINVAL, "NULL argument");
+    if (B < 1 || B > 65535) return set_err(LRF_EINVAL, "B=%ld out of range [1,65535]", (long)B);
+    const int8_t* Us[3] = {U0, U1, U2};
+    const int8_t* Vs[3] = {V0, V1, V2};
+    AnyDecodePlane d[3];
+    for (int ch = 0; ch < 3; ch++) {
+        AnyGeom g;
+        int rc = any_geom(H, W, p, q, ch, &g);
+        if (rc) return rc;
+        if (R[ch] < 1 || R[ch] > 16384) return set_err(LRF_EINVAL, "rank %d out of range", R[ch]);
+        d[ch].U = Us[ch]; d[ch].V = Vs[ch];
+        d[ch].u_img = g.M * R[ch]; d[ch].v_img = g.N * R[ch];
+        d[ch].h = g.h; d[ch].w = g.w; d[ch].p = p; d[ch].q = q; d[ch].top = g.top; d[ch].left = g.left; d[ch].nw = g.nw;
+        d[ch].R = R[ch];
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    Prof pr(c, LRF_K_DECODE);
+    hipLaunchKernelGGL(k_any_decode, dim3((unsigned)(((long)H * W + 255) / 256), (unsigned)B), dim3(256), 0, c->stream, d[0], d[1], d[2],
+                       (int)H, (int)W, rgb);
     LAUNCH_CHECK();
     return LRF_OK;
 }

@@ -187,7 +187,8 @@ static void update_factor(const float* X, long sxi, long sxk, long rows, long de
         return;
     }
     int native = aten_uses_native(R - 1, rows, 1);
-    float uu[64], bb[64];
+    float* uu = (float*)malloc(sizeof(float) * 2 * (size_t)R);
+    float* bb = uu + R;
     for (int r = 0; r < R; r++) {
         int n = 0;
         for (int j = 0; j < R; j++)
@@ -202,19 +203,20 @@ static void update_factor(const float* X, long sxi, long sxk, long rows, long de
             Uo[i * R + r] = project((num + LRF_EPS) / den, bounded, lo, hi); /* :118-119 */
         }
     }
+    free(uu);
 }
 
 /* QMF.decompose iterations — lrf/factorization/qmf.py:207-212 / CoordinateDescent.forward :149-164.
  * U [M,R], V [N,R] hold the initial factors on entry and the result on return (fp32, integer valued
- * when num_iters >= 1).  Returns 0, or -1 on allocation failure / R > 64. */
+ * when num_iters >= 1).  Any M, N, R >= 1.  Returns 0, or -1 on allocation failure. */
 int lrf_oracle_bcd(const float* X, long M, long N, int R, int num_iters,
                    int bounded, float lo, float hi, float* U, float* V)
 {
-    if (R > 64 || R < 1) return -1;
+    if (R < 1) return -1;
     long mx = M > N ? M : N;
-    float* a_ws = (float*)malloc(sizeof(float) * (size_t)mx * R);
-    float b_ws[64 * 64];
+    float* a_ws = (float*)malloc(sizeof(float) * ((size_t)mx * R + (size_t)R * R));
     if (!a_ws) return -1;
+    float* b_ws = a_ws + (size_t)mx * R;
     if (bounded) { lo = ceilf(lo); hi = floorf(hi); } /* qmf.py:194 math.ceil / math.floor */
     for (int it = 0; it < num_iters; it++) {
         update_factor(X, N, 1, M, N, R, U, V, bounded, lo, hi, a_ws, b_ws); /* update_u :159 */
@@ -866,6 +868,78 @@ int lrf_oracle_svd_topr(const float* X, long M, long N, int R, const int8_t* sig
     }
     mm_mkl(X, N, 1, w, R, 1, u, R, M, N, R);
     free(G); free(E); free(w); free(order);
+    return 0;
+}
+
+/* The same for any shape: the eigen-problem is solved on the SHORT side (n = min(M, N)); when M < N the roles of the
+ * factors swap (u = e sqrt(sigma), v = X^T e / sqrt(sigma)) and the column sign is imposed on the finished v, as
+ * include/lrf_hip.h states it.  Odd n: the Gram matrix is bordered with a zero row / column (the Jacobi sweep pairs
+ * an even number of indices); the extra eigenvector is e_n with eigenvalue 0 and contributes zero columns at most. */
+int lrf_oracle_svd_topr_any(const float* X, long M, long N, int R, const int8_t* sign, float* u, float* v)
+{
+    const int tall = N <= M;
+    const long n = tall ? N : M, D = tall ? M : N;
+    float* Xt = NULL;
+    const float* A = X; /* D x n, row-major */
+    if (!tall) {
+        Xt = (float*)malloc(sizeof(float) * M * N);
+        for (long i = 0; i < M; i++)
+            for (long j = 0; j < N; j++) Xt[j * M + i] = X[i * N + j];
+        A = Xt;
+    }
+    const int ne = (int)(n + (n & 1));
+    double* G0 = (double*)malloc(sizeof(double) * n * n);
+    double* G = (double*)calloc((size_t)ne * ne, sizeof(double));
+    double* E = (double*)malloc(sizeof(double) * ne * ne);
+    float* e1 = (float*)calloc((size_t)n * R, sizeof(float));
+    float* e2 = (float*)calloc((size_t)n * R, sizeof(float));
+    int* order = (int*)malloc(sizeof(int) * ne);
+    lrf_oracle_gram_f64(A, D, n, G0);
+    for (long i = 0; i < n; i++)
+        for (long j = 0; j < n; j++) G[i * ne + j] = G0[i * n + j];
+    lrf_oracle_jacobi_f64(G, ne, E, 60);
+    for (int i = 0; i < ne; i++) order[i] = i;
+    for (int i = 1; i < ne; i++) {
+        int o = order[i];
+        double key = G[o * ne + o];
+        int j = i - 1;
+        while (j >= 0 && G[order[j] * ne + order[j]] < key) { order[j + 1] = order[j]; j--; }
+        order[j + 1] = o;
+    }
+    for (int r = 0; r < R && r < n; r++) {
+        int c = order[r];
+        double lam = G[c * ne + c];
+        double sr = sqrt(sqrt(lam > 1e-200 ? lam : 0.0));
+        double flip = 1.0;
+        if (tall) {
+            double dot = 0.0;
+            for (long j = 0; j < n; j++) dot = fma((double)(j + 1), E[j * ne + c], dot);
+            double want = (sign && sign[r]) ? (double)sign[r] : -1.0;
+            flip = ((dot < 0.0 ? -1.0 : 1.0) == want) ? 1.0 : -1.0;
+        }
+        for (long j = 0; j < n; j++) {
+            double ev = flip * E[j * ne + c];
+            e1[j * R + r] = (float)(ev * sr);
+            e2[j * R + r] = (sr > 0.0) ? (float)(ev / sr) : 0.f;
+        }
+    }
+    if (tall) {
+        memcpy(v, e1, sizeof(float) * n * R);
+        mm_mkl(X, N, 1, e2, R, 1, u, R, M, N, R);
+    } else {
+        memcpy(u, e1, sizeof(float) * n * R);
+        mm_mkl(X, 1, N, e2, R, 1, v, R, N, M, R);
+        for (int r = 0; r < R; r++) {
+            double dot = 0.0;
+            for (long j = 0; j < N; j++) dot = fma((double)(j + 1), (double)v[j * R + r], dot);
+            double want = (sign && sign[r]) ? (double)sign[r] : -1.0;
+            if ((dot < 0.0 ? -1.0 : 1.0) != want) {
+                for (long j = 0; j < N; j++) v[j * R + r] = -v[j * R + r];
+                for (long i = 0; i < M; i++) u[i * R + r] = -u[i * R + r];
+            }
+        }
+    }
+    free(Xt); free(G0); free(G); free(E); free(e1); free(e2); free(order);
     return 0;
 }
 

@@ -238,3 +238,72 @@ def qmf_rgbspace_decode(u, v, H, W):
     v = np.asarray(v, dtype=np.float32)
     Hp, Wp = H + (8 - H % 8) % 8, W + (8 - W % 8) % 8
     return to_u8(depatchify_unpad(u @ v.T, 3, Hp, Wp, H, W))
+
+
+# ---- qmf_encode / qmf_decode, YCbCr branch with any patch size or patch=False (qmf.py:227-286, 325-351) ----------
+def svd_topr_any(X, R, sign=None):
+    """(u0 [M,R], v0 [N,R]) for any shape: eigen-problem on the short side (lrf_oracle_svd_topr_any)."""
+    X = _f32(X)
+    M, N = X.shape
+    u = np.empty((M, R), np.float32)
+    v = np.empty((N, R), np.float32)
+    keep, sp = _sign_arg(sign, R)
+    lib().lrf_oracle_svd_topr_any.restype = c_int
+    rc = lib().lrf_oracle_svd_topr_any(_ptr(X, _fp), c_long(M), c_long(N), c_int(R), sp, _ptr(u, _fp), _ptr(v, _fp))
+    assert rc == 0
+    return u, v
+
+
+def ycbcr_planes(rgb):
+    """uint8 [3,H,W] -> [Y [H,W], Cb [h,w], Cr [h,w]] fp32: rgb_to_ycbcr + chroma_downsampling(0.5, area)."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    _, H, W = rgb.shape
+    ycc = np.empty((3, H, W), np.float32)
+    lib().lrf_oracle_rgb_to_ycbcr(_ptr(rgb, _u8p), c_long(H), c_long(W), _ptr(ycc, _fp))
+    h, w = H // 2, W // 2
+    out = [ycc[0].copy()]
+    for c in (1, 2):
+        ds = np.empty((h, w), np.float32)
+        lib().lrf_oracle_area_downsample(_ptr(np.ascontiguousarray(ycc[c]), _fp), c_long(H), c_long(W), c_long(h), c_long(w), _ptr(ds, _fp))
+        out.append(ds)
+    return out
+
+
+def anyshape_matrices(rgb, patch_size):
+    """The three matrices qmf_encode factorises: patches (p, q) of the reflect-padded planes, or the planes (None)."""
+    planes = ycbcr_planes(rgb)
+    if patch_size is None:
+        return planes
+    return [pad_patchify(pl[None], patch_size[0], patch_size[1]) for pl in planes]
+
+
+def qmf_anyshape_decompose(rgb, patch_size, ranks, num_iters=10, bounds=(-16, 15), signs=None, inits=None):
+    """-> [(u, v)] * 3 fp32 (integer valued for num_iters >= 1)."""
+    out = []
+    for c, X in enumerate(anyshape_matrices(rgb, patch_size)):
+        u0, v0 = inits[c] if inits is not None else svd_topr_any(X, ranks[c], None if signs is None else signs[c])
+        out.append(bcd(X, u0, v0, num_iters, bounds) if num_iters > 0 else (u0, v0))
+    return out
+
+
+def qmf_anyshape_decode(factors, H, W, patch_size):
+    """[(u, v)] * 3 integer factors -> uint8 [3,H,W]: u @ v.mT, depatchify + unpad, nearest up-sampling, ycbcr_to_rgb, to_dtype."""
+    ycc = np.empty((3, H, W), np.float32)
+    for c, (u, v) in enumerate(factors):
+        h, w = (H, W) if c == 0 else (H // 2, W // 2)
+        X = np.asarray(u, dtype=np.float32) @ np.asarray(v, dtype=np.float32).T  # exact small integers
+        if patch_size is not None:
+            p, q = patch_size
+            hp, wp = h + (p - h % p) % p, w + (q - w % q) % q
+            pl = depatchify_unpad(X, 1, hp, wp, h, w, p, q)[0]
+        else:
+            pl = np.ascontiguousarray(X, dtype=np.float32)
+        if c == 0:
+            ycc[0] = pl
+        else:
+            up = np.empty((H, W), np.float32)
+            lib().lrf_oracle_nearest_upsample(_ptr(np.ascontiguousarray(pl), _fp), c_long(h), c_long(w), c_long(H), c_long(W), _ptr(up, _fp))
+            ycc[c] = up
+    out = np.empty((3, H, W), np.float32)
+    lib().lrf_oracle_ycbcr_to_rgb(_ptr(ycc, _fp), c_long(H), c_long(W), _ptr(out, _fp))
+    return to_u8(out)

@@ -23,11 +23,17 @@ def make_image(spec):
         g = torch.Generator().manual_seed(spec["seed"])
         return torch.randint(0, 256, (3, spec["H"], spec["W"]), dtype=torch.uint8, generator=g)
     if kind == "smooth":
-        g = torch.Generator().manual_seed(spec["seed"])
-        H, W = spec["H"], spec["W"]
-        base = torch.rand(1, 3, H // 8, W // 8, generator=g) * 255
-        sm = torch.nn.functional.interpolate(base, size=(H, W), mode="bilinear", align_corners=False)[0]
-        return (sm + torch.randn(sm.shape, generator=g) * 4).clamp(0, 255).to(torch.uint8)
+        # torch.randn fills large tensors in per-thread chunks: the recipe is pinned at one thread (as the generator ran)
+        nt = torch.get_num_threads()
+        torch.set_num_threads(1)
+        try:
+            g = torch.Generator().manual_seed(spec["seed"])
+            H, W = spec["H"], spec["W"]
+            base = torch.rand(1, 3, H // 8, W // 8, generator=g) * 255
+            sm = torch.nn.functional.interpolate(base, size=(H, W), mode="bilinear", align_corners=False)[0]
+            return (sm + torch.randn(sm.shape, generator=g) * 4).clamp(0, 255).to(torch.uint8)
+        finally:
+            torch.set_num_threads(nt)
     if kind == "const":
         return torch.full((3, spec["H"], spec["W"]), spec["value"], dtype=torch.uint8)
     raise ValueError(kind)

@@ -1,0 +1,266 @@
+"""qmf_encode / qmf_decode, YCbCr branch with patch sizes other than 8x8 and with patch=False
+(lrf/compression/qmf.py:227-286, 325-351; experiments/ablation_patchsize/eval.py:49-55):
+per plane one matrix [M, N] of any shape, any rank.  Fixtures: tools/gen_golden.py anyshape (reference at one thread)."""
+import hashlib
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import Case
+
+SMALL = ["any_p4_q20", "any_p4_odd_q40", "any_p16_q10", "any_p32_q30", "any_p8x4_q15", "any_nopatch_q10",
+         "any_nopatch_odd_q25", "any_nopatch_it1", "any_nopatch_wide_bounds"]
+NO_INIT = ["any_p16_r70"]
+LARGE = ["any_s1_p4_q40", "any_s1_p16_q20", "any_s1_p32_q20", "any_s1_nopatch_q20"]
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _psnr(a, b):
+    mse = np.mean((np.asarray(a, np.float32) - np.asarray(b, np.float32)) ** 2)
+    return 20 * np.log10(255 / np.sqrt(mse))
+
+
+def _params(c):
+    kw = c.kwargs
+    ps = tuple(kw["patch_size"]) if kw.get("patch", True) else None
+    return ps, kw.get("num_iters", 10), tuple(kw.get("bounds", (-16, 15)))
+
+
+def _ref_factors2d(c):
+    return [np.asarray(f).reshape(-1, f.shape[-1]) for f in c.ref_factors()]
+
+
+# ---------------------------------------------------------------- CPU: the oracle and the container against the reference
+@pytest.mark.parametrize("name", SMALL)
+def test_oracle_reproduces_reference_streams_from_its_init(name, oracle):
+    """matrices, K iterations from the reference's (u0, v0), int8 cast, container: the reference's bytes"""
+    from lrf_amd.codec import pack_anyshape
+    c = Case(name)
+    ps, K, bounds = _params(c)
+    inits = [(c.z[f"u0_{i}"], c.z[f"v0_{i}"]) for i in range(3)]
+    fac = oracle.qmf_anyshape_decompose(c.image.numpy(), ps, c.ranks, K, bounds, inits=inits)
+    flat = []
+    for (u, v), (ru, rv) in zip(fac, zip(_ref_factors2d(c)[0::2], _ref_factors2d(c)[1::2])):
+        assert np.array_equal(u, ru.astype(np.float32)) and np.array_equal(v, rv.astype(np.float32))
+        u8, v8 = u.astype(np.int8), v.astype(np.int8)
+        flat += [u8, v8] if ps is not None else [u8[None], v8[None]]
+    H, W = c.image.shape[-2:]
+    kw_bounds = c.kwargs.get("bounds", (-16, 15))
+    stream = pack_anyshape(flat, (H, W), c.ranks, tuple(kw_bounds), ps)
+    assert stream == c.encoded
+
+
+@pytest.mark.parametrize("name", SMALL + NO_INIT + LARGE)
+def test_oracle_decode_matches_reference(name, oracle):
+    c = Case(name)
+    ps, _, _ = _params(c)
+    f = _ref_factors2d(c)
+    H, W = c.image.shape[-2:]
+    dec = oracle.qmf_anyshape_decode(list(zip(f[0::2], f[1::2])), H, W, ps)
+    assert _sha(dec) == c.decoded_sha256
+
+
+@pytest.mark.parametrize("name", SMALL + NO_INIT)
+def test_oracle_own_init_is_close_to_reference(name, oracle):
+    """with its own SVD initialisation (reference's column signs) the oracle lands within 0.25 dB of the reference"""
+    c = Case(name)
+    ps, K, bounds = _params(c)
+    fac = oracle.qmf_anyshape_decompose(c.image.numpy(), ps, c.ranks, K, bounds, signs=c.signs())
+    H, W = c.image.shape[-2:]
+    dec = oracle.qmf_anyshape_decode([(np.trunc(u), np.trunc(v)) for u, v in fac], H, W, ps)
+    assert abs(_psnr(c.image.numpy(), dec) - c.psnr) < 0.25
+
+
+def test_rank_rule_and_geometry():
+    from lrf_amd import _lib
+    from lrf_amd.codec import anyshape_ranks
+    for name in SMALL + NO_INIT + LARGE:
+        c = Case(name)
+        ps, _, _ = _params(c)
+        H, W = c.image.shape[-2:]
+        assert anyshape_ranks((H, W), ps, c.kwargs.get("rank"), c.kwargs.get("quality")) == c.ranks
+        meta = json.loads(__import__("lrf_amd").separate_bytes(c.encoded, 2)[0].decode())
+        dims = _lib.plane_dims_any(H, W, ps)
+        assert [list(d[:2]) for d in dims] == [list(x) for x in meta["original size"]]
+        if ps is not None:
+            assert [list(d[2:4]) for d in dims] == [list(x) for x in meta["padded size"]]
+        f = c.ref_factors()
+        for i in range(3):
+            assert f[2 * i].shape[-2] == dims[i][4] and f[2 * i + 1].shape[-2] == dims[i][5]
+    with pytest.raises(ValueError):
+        _lib.plane_dims_any(8, 8, (16, 16))  # reflect padding larger than the plane: torch raises there too
+
+
+@pytest.mark.parametrize("name", SMALL + NO_INIT)
+def test_repack_is_byte_identical(name):
+    from lrf_amd.codec import pack_anyshape
+    c = Case(name)
+    ps, _, _ = _params(c)
+    H, W = c.image.shape[-2:]
+    assert pack_anyshape(c.ref_factors(), (H, W), c.ranks, tuple(c.kwargs.get("bounds", (-16, 15))), ps) == c.encoded
+
+
+def test_oracle_init_wide_and_tall_agree(oracle):
+    """svd_topr_any on X and on X^T give the same rank-R approximation (short-side eigen-problem either way)"""
+    rng = np.random.default_rng(3)
+    X = rng.normal(size=(37, 120)).astype(np.float32)
+    u, v = oracle.svd_topr_any(X, 5)
+    v2, u2 = oracle.svd_topr_any(np.ascontiguousarray(X.T), 5)
+    assert np.abs(u @ v.T - u2 @ v2.T).max() < 2e-4
+    s = np.linalg.svd(X.astype(np.float64), compute_uv=False)
+    assert np.allclose(np.linalg.norm(u, axis=0) ** 2, s[:5], rtol=1e-5)
+    w = np.arange(1, 121)[:, None]
+    assert ((w * v).sum(0) < 0).all()  # default column sign
+
+
+# ---------------------------------------------------------------- GPU: the HIP path
+def _gpu_image(c):
+    return c.image.cuda()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SMALL + NO_INIT)
+def test_hip_matrices_equal_oracle(name, oracle):
+    from lrf_amd import _lib
+    c = Case(name)
+    ps, _, _ = _params(c)
+    ctx = _lib.context()
+    want = oracle.anyshape_matrices(c.image.numpy(), ps)
+    for ch in range(3):
+        X = ctx.planes_any(_gpu_image(c).unsqueeze(0), ps, ch)[0].cpu().numpy()
+        assert X.shape == want[ch].shape
+        assert np.array_equal(X.view(np.uint32), np.ascontiguousarray(want[ch]).view(np.uint32)), (name, ch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SMALL)
+def test_hip_reproduces_reference_streams_from_its_init(name):
+    import lrf_amd
+    c = Case(name)
+    inits = [(c.z[f"u0_{i}"], c.z[f"v0_{i}"]) for i in range(3)]
+    kw = dict(c.kwargs)
+    if "patch_size" in kw:
+        kw["patch_size"] = tuple(kw["patch_size"])
+    if "bounds" in kw:
+        kw["bounds"] = tuple(kw["bounds"])
+    stream = lrf_amd.qmf_encode(c.image, init=inits, **kw)
+    assert stream == c.encoded
+    assert _sha(lrf_amd.qmf_decode(stream).numpy()) == c.decoded_sha256
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SMALL + NO_INIT + LARGE)
+def test_hip_decode_matches_reference(name):
+    import lrf_amd
+    c = Case(name)
+    assert _sha(lrf_amd.qmf_decode(c.encoded).numpy()) == c.decoded_sha256
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SMALL + NO_INIT + LARGE)
+def test_hip_own_init_is_close_to_reference(name):
+    """default path (this library's SVD initialisation, the reference's column signs): PSNR within 0.25 dB, size within 3 %"""
+    import lrf_amd
+    c = Case(name)
+    kw = dict(c.kwargs)
+    if "patch_size" in kw:
+        kw["patch_size"] = tuple(kw["patch_size"])
+    if "bounds" in kw:
+        kw["bounds"] = tuple(kw["bounds"])
+    stream = lrf_amd.qmf_encode(c.image, init_sign=np.concatenate(c.signs()), **kw)
+    dec = lrf_amd.qmf_decode(stream)
+    assert abs(_psnr(c.image.numpy(), dec.numpy()) - c.psnr) < 0.25
+    assert abs(len(stream) - len(c.encoded)) <= 0.03 * len(c.encoded) + 16
+    meta = json.loads(lrf_amd.separate_bytes(stream, 2)[0].decode())
+    assert meta == json.loads(lrf_amd.separate_bytes(c.encoded, 2)[0].decode())
+
+
+SHAPES = [  # M, N, R, K, bounds — products with 1..64 blocks, both native thresholds, wide and tall, rank above 64, rank > min(M, N)
+    (7, 16, 1, 3, (-16, 15)), (5, 16, 3, 3, (-16, 15)), (24, 16, 4, 2, (-16, 15)), (3, 5, 2, 4, (-16, 15)),
+    (400, 16, 16, 3, (-16, 15)), (1000, 16, 5, 3, (-128, 127)), (96, 1024, 20, 3, (-16, 15)), (35, 256, 4, 10, (-16, 15)),
+    (200, 256, 70, 2, (-16, 15)), (130, 100, 101, 2, (-16, 15)), (64, 96, 6, 10, (-4, 3)), (513, 770, 33, 2, (-16, 15)),
+    (50, 64, 70, 2, (-16, 15)), (1, 40, 1, 2, (-16, 15)), (40, 1, 1, 2, (-16, 15)),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,R,K,bounds", SHAPES)
+def test_hip_bcd_equals_oracle_on_any_shape(M, N, R, K, bounds, oracle):
+    """lrf_qmf_bcd_f32 from given initial factors == the oracle's K iterations, bit for bit (two matrices per call)"""
+    from lrf_amd import _lib
+    rng = np.random.default_rng(M * 131 + N * 7 + R)
+    ctx = _lib.context()
+    X = (rng.random((2, M, N)) * 255).astype(np.float32)
+    X[1] = np.round(X[1])  # integer-valued plane: exact products, ties in the rounding
+    U0 = rng.normal(size=(2, M, R)).astype(np.float32) * 3
+    V0 = rng.normal(size=(2, N, R)).astype(np.float32) * 3
+    if R > min(M, N):
+        U0[:, :, min(M, N):] = 0
+        V0[:, :, min(M, N):] = 0
+    U, V = ctx.bcd(torch.from_numpy(X).cuda(), torch.from_numpy(U0).cuda(), torch.from_numpy(V0).cuda(), K, bounds[0], bounds[1])
+    for b in range(2):
+        u, v = oracle.bcd(X[b], U0[b], V0[b], K, bounds)
+        assert np.array_equal(U[b].cpu().numpy(), u.astype(np.int8)), (M, N, R, "U", b)
+        assert np.array_equal(V[b].cpu().numpy(), v.astype(np.int8)), (M, N, R, "V", b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,R", [(384, 16, 5), (35, 256, 6), (100, 300, 40), (300, 100, 100), (64, 64, 3), (513, 300, 7),
+                                  (20, 1024, 20), (700, 600, 30)])
+def test_hip_init_matches_oracle_init(M, N, R, oracle):
+    """SVD initialisation on any shape: the rank-R product u0 v0^T agrees with the oracle's (Jacobi) to fp32 accuracy, the
+    column norms are the singular values, the default column sign holds"""
+    from lrf_amd import _lib
+    rng = np.random.default_rng(M + N + R)
+    base = rng.normal(size=(M, 12)) @ rng.normal(size=(12, N)) * 20 + rng.normal(size=(M, N)) * 5 + 100
+    X = base.astype(np.float32)
+    ctx = _lib.context()
+    u0, v0 = ctx.svd_init(torch.from_numpy(X[None]).cuda(), R)
+    u0, v0 = u0[0].cpu().numpy().astype(np.float64), v0[0].cpu().numpy().astype(np.float64)
+    s = np.linalg.svd(X.astype(np.float64), compute_uv=False)
+    Rc = min(R, M, N)
+    assert np.allclose((u0 ** 2).sum(0)[:Rc], s[:Rc], rtol=2e-4, atol=1e-3)
+    assert np.allclose((v0 ** 2).sum(0)[:Rc], s[:Rc], rtol=2e-4, atol=1e-3)
+    Uf, sf, Vt = np.linalg.svd(X.astype(np.float64), full_matrices=False)
+    best = (Uf[:, :Rc] * sf[:Rc]) @ Vt[:Rc]
+    assert np.abs(u0 @ v0.T - best).max() < 2e-3 * s[0] ** 0.5 + 1e-2
+    w = np.arange(1, N + 1)[:, None]
+    assert ((w * v0[:, :Rc]).sum(0) < 0).all()
+    if min(M, N) <= 300:
+        uo, vo = oracle.svd_topr_any(X, R)
+        assert np.abs(uo.astype(np.float64) @ vo.T - u0 @ v0.T).max() < 2e-3 * s[0] ** 0.5 + 1e-2
+
+
+@pytest.mark.gpu
+def test_qmf_class_on_any_shape(oracle):
+    """lrf_amd.QMF.decompose on a [B, M, N] batch of non-patch shape: the oracle's result from the same SVD start"""
+    import lrf_amd
+    from lrf_amd import _lib
+    rng = np.random.default_rng(9)
+    X = (rng.random((3, 48, 80)) * 255).astype(np.float32)
+    q = lrf_amd.QMF(rank=5, num_iters=4, bounds=(-16, 15), factor=(0, 1))
+    u, v, w = q.decompose(torch.from_numpy(X))
+    ctx = _lib.context()
+    u0, v0 = ctx.svd_init(torch.from_numpy(X).cuda(), 5)
+    for b in range(3):
+        uo, vo = oracle.bcd(X[b], u0[b].cpu().numpy(), v0[b].cpu().numpy(), 4, (-16, 15))
+        assert np.array_equal(u[b].numpy(), uo) and np.array_equal(v[b].numpy(), vo)
+    assert w.shape == (3, 2, 1)
+
+
+@pytest.mark.gpu
+def test_unsupported_anyshape_arguments_raise():
+    from lrf_amd import _lib
+    ctx = _lib.context()
+    X = torch.zeros((1, 8, 16), device="cuda")
+    with pytest.raises(NotImplementedError):
+        ctx.decompose(X, 700, 1, -16, 15)
+    with pytest.raises(ValueError):
+        ctx.decompose(X, 0, 1, -16, 15)
+    with pytest.raises(ValueError):
+        ctx.decompose(X, 2, 1, -200, 15)

@@ -85,10 +85,13 @@ def test_unsupported_branches_raise():
     with pytest.raises(NotImplementedError):
         lrf_amd.qmf_encode(img, quality=7, color_space="RGB", patch_size=(16, 16))
     with pytest.raises(NotImplementedError):
-        lrf_amd.qmf_encode(img, quality=7, patch=False)
+        lrf_amd.qmf_encode(img, quality=7, color_space="RGB", patch=False)
+    with pytest.raises(NotImplementedError):
+        lrf_amd.qmf_encode(img, quality=7, scale_factor=(0.25, 0.25))
     if not torch.cuda.is_available():  # the implemented branches need the GPU: no CPU fallback
-        with pytest.raises(RuntimeError):
-            lrf_amd.qmf_encode(img, quality=7, color_space="RGB")
+        for kw in (dict(color_space="RGB"), dict(patch=False), dict(patch_size=(4, 4))):
+            with pytest.raises(RuntimeError):
+                lrf_amd.qmf_encode(img, quality=7, **kw)
 
 
 def test_native_packer_matches_reference_streams():

@@ -218,3 +218,71 @@ def gen_rgbspace():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "rgbspace":
     gen_rgbspace()
+
+
+ANYSHAPE_CASES = [
+    # qmf_encode(color_space="YCbCr") with other patch sizes / patch=False (experiments/ablation_patchsize/eval.py:49-55):
+    # name, image spec, encoder kwargs, store_image, store_init
+    ("any_p4_q20", dict(kind="randint", seed=21, H=64, W=96), dict(quality=20, patch_size=(4, 4)), True, True),
+    ("any_p4_odd_q40", dict(kind="smooth", seed=22, H=72, W=104), dict(quality=40, patch_size=(4, 4)), True, True),
+    ("any_p16_q10", dict(kind="smooth", seed=23, H=72, W=104), dict(quality=10, patch_size=(16, 16)), True, True),
+    ("any_p16_r70", dict(kind="randint", seed=24, H=128, W=192), dict(rank=70, patch_size=(16, 16)), True, False),
+    ("any_p32_q30", dict(kind="randint", seed=12, H=173, W=264), dict(quality=30, patch_size=(32, 32)), True, True),
+    ("any_p8x4_q15", dict(kind="smooth", seed=25, H=64, W=96), dict(quality=15, patch_size=(8, 4)), True, True),
+    ("any_nopatch_q10", dict(kind="randint", seed=26, H=64, W=96), dict(quality=10, patch=False), True, True),
+    ("any_nopatch_odd_q25", dict(kind="smooth", seed=27, H=75, W=101), dict(quality=25, patch=False), True, True),
+    ("any_nopatch_it1", dict(kind="smooth", seed=27, H=75, W=101), dict(quality=25, patch=False, num_iters=1), True, True),
+    ("any_nopatch_wide_bounds", dict(kind="smooth", seed=28, H=64, W=96), dict(quality=8, patch=False, bounds=(-128, 127)), True, True),
+    ("any_s1_p4_q40", dict(kind="smooth", seed=5, H=512, W=768), dict(quality=40, patch_size=(4, 4)), False, False),
+    ("any_s1_p16_q20", dict(kind="smooth", seed=5, H=512, W=768), dict(quality=20, patch_size=(16, 16)), False, False),
+    ("any_s1_p32_q20", dict(kind="smooth", seed=5, H=512, W=768), dict(quality=20, patch_size=(32, 32)), False, False),
+    ("any_s1_nopatch_q20", dict(kind="smooth", seed=5, H=512, W=768), dict(quality=20, patch=False), False, False),
+]
+
+
+def gen_anyshape():
+    """Fixtures of the patch-size / patch=False branches: bytes, decoded image, PSNR, the reference's per-plane matrices'
+    initial factors (u0, v0) for the small cases and their column signs for all."""
+    torch.set_num_threads(1)
+    ns = ref_loader.load()
+    index = {}
+    for name, spec, kw, store_image, store_init in ANYSHAPE_CASES:
+        img = make_image(spec)
+        enc = ns.cqmf.qmf_encode(img, **kw)
+        dec = ns.cqmf.qmf_decode(enc)
+        mse = torch.mean((img.float() - dec.float()) ** 2, dim=(-3, -2, -1))
+        psnr = (20 * torch.log10(255 / torch.sqrt(mse))).item()
+        meta = json.loads(ns.cutils.separate_bytes(enc, 2)[0].decode())
+        ycbcr = ns.cutils.rgb_to_ycbcr(img.float())
+        chans = ns.cutils.chroma_downsampling(ycbcr, scale_factor=(0.5, 0.5), mode="area")
+        arrays = dict(encoded=np.frombuffer(enc, np.uint8), psnr=np.float64(psnr),
+                      bpp=np.float64(len(enc) * 8 / (img.shape[-2] * img.shape[-1])),
+                      spec=np.array(json.dumps(spec)), kwargs=np.array(json.dumps(kw)),
+                      image_sha256=np.array(hashlib.sha256(img.numpy().tobytes()).hexdigest()),
+                      decoded_sha256=np.array(hashlib.sha256(dec.numpy().tobytes()).hexdigest()),
+                      ranks=np.array(meta["rank"], np.int32))
+        for c, ch in enumerate(chans):
+            if kw.get("patch", True):
+                ps = kw["patch_size"]
+                x = ns.cqmf.patchify(ns.cutils.pad_image(ch, ps, mode="reflect"), ps)
+            else:
+                x = ch[0]
+            R = meta["rank"][c]
+            u0, v0, _ = ns.fqmf.SVDInit(rank=R)(x.unsqueeze(0).float())
+            arrays[f"sign{c}"] = wsign(v0[0].numpy())
+            if store_init:
+                arrays[f"u0_{c}"] = u0[0].numpy()
+                arrays[f"v0_{c}"] = v0[0].numpy()
+        if store_image:
+            arrays["image"] = img.numpy()
+            arrays["decoded"] = dec.numpy()
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
+        index[name] = dict(spec=spec, kwargs=kw, bytes=len(enc), psnr=psnr, ranks=meta["rank"],
+                           enc_sha256=hashlib.sha256(enc).hexdigest()[:16])
+        print(name, index[name], flush=True)
+    with open(os.path.join(OUT, "index_anyshape.json"), "w") as f:
+        json.dump(index, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "anyshape":
+    gen_anyshape()
