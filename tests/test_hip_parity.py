@@ -130,10 +130,12 @@ def test_qmf_class_api(oracle):
 
 def test_c_abi_argument_errors(ctx):
     x = torch.zeros(1, 10, 64, device="cuda")
+    u, v = ctx.decompose(torch.zeros(1, 10, 32, device="cuda"), 2, 10, -16, 15)  # N != 64: the any-shape kernels
+    assert tuple(u.shape) == (1, 10, 2) and tuple(v.shape) == (1, 32, 2)
     with pytest.raises(NotImplementedError):
-        ctx.decompose(torch.zeros(1, 10, 32, device="cuda"), 2, 10, -16, 15)  # N != 64
+        ctx.decompose(torch.zeros(1, 100, 64, device="cuda"), 640, 10, -16, 15)  # above LRF_ANY_MAX_RANK
     with pytest.raises(NotImplementedError):
-        ctx.decompose(torch.zeros(1, 100, 64, device="cuda"), 65, 10, -16, 15)
+        ctx.decompose(torch.zeros(1, 2100, 2100, device="cuda"), 2, 10, -16, 15)  # min(M, N) above LRF_ANY_MAX_SIDE
     with pytest.raises(ValueError):
         ctx.decompose(x, 0, 10, -16, 15)
     with pytest.raises(ValueError):
