@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void k_any_gram(const float* __restrict__ X, l
 template <int NCT>
 __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, int R, const int8_t* __restrict__ sign,
                                                  float* __restrict__ E1, float* __restrict__ E2, double* __restrict__ Zw,
-                                                 double* __restrict__ Dw)
+                                                 double* __restrict__ Dw, int stop_after /* developer timing aid, 0 = run all */)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* Lv = reinterpret_cast<double*>(smem);
@@ -256,6 +256,7 @@ __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, 
     double* Dm = Dp + (long)n * Rc;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int UB = (NCT <= 2) ? 8 : (NCT == 4 ? 4 : 2); // rows in flight per thread in the two matrix passes
 
     // ---- Householder tridiagonalisation; row k of A keeps the reflector v_k
     for (int k = 0; k < n - 2; k++) {
@@ -294,14 +295,32 @@ __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, 
         double cc[NCT];
 #pragma unroll
         for (int c = 0; c < NCT; c++) cc[c] = 0.0;
-        for (int j = k + 1; j < n; j++) {
-            const double vj = Lv[j];
-            const double* Aj = A + (long)j * n;
+        // rows in batches of UB: all loads of a batch are issued before the first use (a plain loop waits for every load)
+        for (int j0 = k + 1; j0 < n; j0 += UB) {
+            double a[UB][NCT];
 #pragma unroll
-            for (int c = 0; c < NCT; c++) {
-                const int i = tid + 256 * c;
-                if (i < n && i > k) cc[c] = fma(Aj[i], vj, cc[c]);
+            for (int u = 0; u < UB; u++) {
+                const int j = (j0 + u < n) ? j0 + u : n - 1;
+                const double* Aj = A + (long)j * n;
+#pragma unroll
+                for (int c = 0; c < NCT; c++) {
+                    const int i = tid + 256 * c;
+                    a[u][c] = Aj[i < n ? i : n - 1];
+                }
             }
+#pragma unroll
+            for (int u = 0; u < UB; u++) {
+                if (j0 + u < n) {
+                    const double vj = Lv[j0 + u];
+#pragma unroll
+                    for (int c = 0; c < NCT; c++) cc[c] = fma(a[u][c], vj, cc[c]);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NCT; c++) {
+            const int i = tid + 256 * c;
+            if (!(i < n && i > k)) cc[c] = 0.0;
         }
         s = 0.0;
 #pragma unroll
@@ -318,16 +337,33 @@ __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, 
             if (i < n) Lw[i] = wi[c];
         }
         __syncthreads();
-        for (int r = k + 1; r < n; r++) {
-            const double vr = Lv[r], wr = Lw[r];
-            double* Ar = A + (long)r * n;
+        for (int r0 = k + 1; r0 < n; r0 += UB) {
+            double a[UB][NCT];
 #pragma unroll
-            for (int c = 0; c < NCT; c++) {
-                const int i = tid + 256 * c;
-                if (i < n && i > k) {
-                    const bool rc = r >= i; // canonical (row >= column) operand order: the matrix stays exactly symmetric
-                    const double va = rc ? vr : vi[c], wa = rc ? wr : wi[c], vb = rc ? vi[c] : vr, wb = rc ? wi[c] : wr;
-                    Ar[i] = fma(-wa, vb, fma(-va, wb, Ar[i]));
+            for (int u = 0; u < UB; u++) {
+                const int r = (r0 + u < n) ? r0 + u : n - 1;
+                const double* Ar = A + (long)r * n;
+#pragma unroll
+                for (int c = 0; c < NCT; c++) {
+                    const int i = tid + 256 * c;
+                    a[u][c] = Ar[i < n ? i : n - 1];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UB; u++) {
+                const int r = r0 + u;
+                if (r < n) {
+                    const double vr = Lv[r], wr = Lw[r];
+                    double* Ar = A + (long)r * n;
+#pragma unroll
+                    for (int c = 0; c < NCT; c++) {
+                        const int i = tid + 256 * c;
+                        if (i < n && i > k) {
+                            const bool rc = r >= i; // canonical (row >= column) operand order: the matrix stays exactly symmetric
+                            const double va = rc ? vr : vi[c], wa = rc ? wr : wi[c], vb = rc ? vi[c] : vr, wb = rc ? wi[c] : wr;
+                            Ar[i] = fma(-wa, vb, fma(-va, wb, a[u][c]));
+                        }
+                    }
                 }
             }
         }
@@ -345,6 +381,7 @@ __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, 
     }
     __syncthreads();
 
+    if (stop_after == 1) return;
     // ---- Gershgorin hull, pivmin
     {
         double a = 1e300, b = -1e300, m2 = 0.0;
@@ -404,6 +441,7 @@ __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, 
         if (lane == 0) Llam[r] = 0.5 * (a + b);
     }
     __syncthreads();
+    if (stop_after == 2) return;
     // ---- twisted factorisation, thread per eigenvalue
     for (int r = tid; r < Rc; r += 256) {
         const double lam = Llam[r];
@@ -445,6 +483,7 @@ __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, 
         }
     }
     __syncthreads();
+    if (stop_after == 3) return;
     // ---- orthonormalisation: classical Gram-Schmidt, twice, against the vectors already fixed
     for (int r = 0; r < Rc; r++) {
         double* Zr = Z + (long)r * n;
@@ -517,6 +556,7 @@ __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, 
         }
         __syncthreads();
     }
+    if (stop_after == 4) return;
     // ---- back-transformation x <- H_0 H_1 ... H_{n-3} x, CW vectors per wave at a time, lane owns i = lane + 64 e
     constexpr int NE = 4 * NCT, CW = 32 / NE;
     float* E1b = E1 + (long)blockIdx.x * n * R;

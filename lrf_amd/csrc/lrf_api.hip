@@ -330,6 +330,10 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
     }
     // k_bcd_w (one wave per block, no barriers) is the default; LRF_BCD_WG=1 selects the 4-wave workgroup kernel k_bcd
     static const bool wave_variant = !(getenv("LRF_BCD_WG") && getenv("LRF_BCD_WG")[0] == '1');
+    // gs_row_exact (lrf_bigrank_kernels.hip): all terms of `uu @ bb` exact integers in fp32 for the largest rank of the call
+    const long mx_b = abs(lo) > abs(hi) ? abs(lo) : abs(hi);
+    static const bool exact_off = getenv("LRF_BIG_GENERIC_GS") && getenv("LRF_BIG_GENERIC_GS")[0] == '1';
+    const int big_exact = (!exact_off && (long)(rmax - 1) * 64 * mx_b * mx_b * mx_b < (1L << 24)) ? 1 : 0;
     for (int it = 0; it < K; it++) {
         {
             Prof p(c, LRF_K_BCD);
@@ -344,7 +348,7 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
     } while (0)
 #define LRF_LAUNCH_BIG(MODE)                                                                                         \
     hipLaunchKernelGGL((k_bcd_big<MODE>), dim3(nb), dim3(256), sizeof(BigLds<MODE>), c->stream, X, pl, bl, vf, wf, bf, U0, U, pp, qp, \
-                       gp.lo, gp.hi)
+                       gp.lo, gp.hi, big_exact)
             if (rp != 16) {
                 if (mode == 1) LRF_LAUNCH_BIG(1);
                 else if (mode == 2) LRF_LAUNCH_BIG(2);

@@ -66,6 +66,41 @@ __device__ __forceinline__ void gs_row_generic(int R, const float* a_row, float*
     }
 }
 
+// The same row update when every product and partial sum of `uu @ bb` is an exact integer in fp32 (iterations >= 2: v is
+// integer valued, |b| <= 64 mx^2, and the host checks (R - 1) * 64 * mx^3 < 2^24 for mx = max(|lo|, |hi|)): the order of
+// the sum no longer matters, so the R (R - 1) dependent multiply-adds of the reference's chain become R (R - 1) independent
+// fmas on RT accumulators — T[r] starts as the part of the sum over the not yet updated columns j > r (old values) and
+// receives u_r b[r][r'] for every later column r' as soon as u_r is known.  Bit-identical results, a third of the time.
+// gt rows are contiguous and wave-uniform: scalar loads.
+template <int RT>
+__device__ __forceinline__ void gs_row_exact(int R, const float* a_row, float* u_row, const float* __restrict__ gt, float lo, float hi)
+{
+    float T[RT];
+#pragma unroll
+    for (int r = 0; r < RT; r++) T[r] = 0.f;
+#pragma unroll
+    for (int j = 1; j < RT; j++) {
+        if (j < R) {
+            const float uo = u_row[j];
+            const float* bj = gt + j * LRF_GTB_LD; // bj[r] = b[j][r] for r < j
+#pragma unroll
+            for (int r = 0; r < j; r++) T[r] = fmaf(uo, bj[r], T[r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RT; r++) {
+        if (r < R) {
+            const float* br = gt + r * LRF_GTB_LD; // br[r' - 1] = b[r][r'] for r' > r
+            const float num = (a_row[r] - T[r]) + LRF_EPS;
+            float val = rintf(num / br[LRF_GTB_DEN]);
+            val = fminf(fmaxf(val, lo), hi);
+            u_row[r] = val;
+#pragma unroll
+            for (int rn = r + 1; rn < RT; rn++) T[rn] = fmaf(val, br[rn - 1], T[rn]); // columns >= R: never read
+        }
+    }
+}
+
 // gt table (pitch LRF_GTB_LD) of b = v.mT @ v from a [depth][LRF_RPB] factor
 __device__ __forceinline__ void make_gtable_big(const float* Vp, int depth, int R, float* gt, int tid, int nthreads)
 {
@@ -112,7 +147,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                                                  const BlockDesc* __restrict__ blocks, const float* __restrict__ Vf,
                                                  const float* __restrict__ Wf, const float* __restrict__ Bf,
                                                  const float* __restrict__ U0, int8_t* __restrict__ U,
-                                                 float* __restrict__ Ppart, float* __restrict__ Qpart, float lo, float hi)
+                                                 float* __restrict__ Ppart, float* __restrict__ Qpart, float lo, float hi,
+                                                 int gs_exact /* see gs_row_exact; honoured for MODE 0, R <= 32 */)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     BigLds<MODE>& L = *reinterpret_cast<BigLds<MODE>*>(smem);
@@ -130,6 +166,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int nsub = (nrows + 63) >> 6;
 
     const float* gt = Bf + (long)bd.plane * LRF_GTB_STRIDE;
+    const int ntl = (R + 15) >> 4; // 16-wide rank tiles in use: the MFMAs of the others would only move zeros
     // A operand of a^T = V^T X^T for tile nt: lane needs V[4s + lq][16 nt + li] at k-step s
     float va[4][16];
 #pragma unroll
@@ -178,9 +215,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 float bx = xr[4 * s];
 #pragma unroll
                 for (int nt = 0; nt < 4; nt++) {
-                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[nt][s], bx, acc[nt], 0, 0, 0);
-                    if (MODE == 1)
-                        accw[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(L.wa_s[(nt * 16 + s) * 64 + lane], bx, accw[nt], 0, 0, 0);
+                    if (nt < ntl) {
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[nt][s], bx, acc[nt], 0, 0, 0);
+                        if (MODE == 1)
+                            accw[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(L.wa_s[(nt * 16 + s) * 64 + lane], bx, accw[nt], 0, 0, 0);
+                    }
                 }
             }
 #pragma unroll
@@ -195,7 +234,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             float* ur = &L.u_s[lane * LRF_RPB];
             if (row < nrows) {
 #ifndef LRF_BIG_NO_GS
-                gs_row_generic(R, &L.a_s[lane * LRF_RPB], ur, gt, pd.native_t2_u != 0, lo, hi);
+                if (MODE == 0 && gs_exact && R <= 24) gs_row_exact<24>(R, &L.a_s[lane * LRF_RPB], ur, gt, lo, hi);
+                else if (MODE == 0 && gs_exact && R <= 32) gs_row_exact<32>(R, &L.a_s[lane * LRF_RPB], ur, gt, lo, hi);
+                else gs_row_generic(R, &L.a_s[lane * LRF_RPB], ur, gt, pd.native_t2_u != 0, lo, hi);
 #else
                 for (int r = 0; r < R; r++) ur[r] = fminf(fmaxf(rintf(L.a_s[lane * LRF_RPB + r] * 1e-4f), lo), hi);
 #endif
@@ -224,9 +265,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 float qa = urow[16 * wave + li];
 #pragma unroll
                 for (int nt = 0; nt < 4; nt++) {
-                    float ub = urow[16 * nt + li];
-                    accP[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(px, ub, accP[nt], 0, 0, 0);
-                    accQ[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa, ub, accQ[nt], 0, 0, 0);
+                    if (nt < ntl) {
+                        float ub = urow[16 * nt + li];
+                        accP[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(px, ub, accP[nt], 0, 0, 0);
+                        if (wave < ntl) accQ[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa, ub, accQ[nt], 0, 0, 0);
+                    }
                 }
             }
         }
