@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, 
     double* Dm = Dp + (long)n * Rc;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int UB = (NCT <= 2) ? 8 : (NCT == 4 ? 4 : 2); // rows in flight per thread in the two matrix passes
+    constexpr int UB = 16 / NCT; // rows per batch and thread in the two passes over the matrix (two batches in flight)
 
     // ---- Householder tridiagonalisation; row k of A keeps the reflector v_k
     for (int k = 0; k < n - 2; k++) {
@@ -295,19 +295,21 @@ __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, 
         double cc[NCT];
 #pragma unroll
         for (int c = 0; c < NCT; c++) cc[c] = 0.0;
-        // rows in batches of UB: all loads of a batch are issued before the first use (a plain loop waits for every load)
-        for (int j0 = k + 1; j0 < n; j0 += UB) {
-            double a[UB][NCT];
+        // rows in batches of UB, two batches in flight: the loads of the next batch are issued before the current one is
+        // used (a plain loop waits for every single load; the matrix sits in L2 / Infinity Cache, ~1 us away)
+        auto load_rows = [&](int r0, double (&a)[UB][NCT]) __attribute__((always_inline)) {
 #pragma unroll
             for (int u = 0; u < UB; u++) {
-                const int j = (j0 + u < n) ? j0 + u : n - 1;
-                const double* Aj = A + (long)j * n;
+                const int r = (r0 + u < n) ? r0 + u : n - 1;
+                const double* Ar = A + (long)r * n;
 #pragma unroll
                 for (int c = 0; c < NCT; c++) {
                     const int i = tid + 256 * c;
-                    a[u][c] = Aj[i < n ? i : n - 1];
+                    a[u][c] = Ar[i < n ? i : n - 1];
                 }
             }
+        };
+        auto matvec_rows = [&](int j0, const double (&a)[UB][NCT]) __attribute__((always_inline)) {
 #pragma unroll
             for (int u = 0; u < UB; u++) {
                 if (j0 + u < n) {
@@ -315,6 +317,16 @@ __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, 
 #pragma unroll
                     for (int c = 0; c < NCT; c++) cc[c] = fma(a[u][c], vj, cc[c]);
                 }
+            }
+        };
+        {
+            double a0[UB][NCT], a1[UB][NCT];
+            load_rows(k + 1, a0);
+            for (int j0 = k + 1; j0 < n; j0 += 2 * UB) {
+                load_rows(j0 + UB, a1);
+                matvec_rows(j0, a0);
+                load_rows(j0 + 2 * UB, a0);
+                matvec_rows(j0 + UB, a1);
             }
         }
 #pragma unroll
@@ -337,18 +349,7 @@ __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, 
             if (i < n) Lw[i] = wi[c];
         }
         __syncthreads();
-        for (int r0 = k + 1; r0 < n; r0 += UB) {
-            double a[UB][NCT];
-#pragma unroll
-            for (int u = 0; u < UB; u++) {
-                const int r = (r0 + u < n) ? r0 + u : n - 1;
-                const double* Ar = A + (long)r * n;
-#pragma unroll
-                for (int c = 0; c < NCT; c++) {
-                    const int i = tid + 256 * c;
-                    a[u][c] = Ar[i < n ? i : n - 1];
-                }
-            }
+        auto update_rows = [&](int r0, const double (&a)[UB][NCT]) __attribute__((always_inline)) {
 #pragma unroll
             for (int u = 0; u < UB; u++) {
                 const int r = r0 + u;
@@ -365,6 +366,16 @@ __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, 
                         }
                     }
                 }
+            }
+        };
+        { // the loads of the next batch go out before the stores of this one, so a batch waits for one latency, not two
+            double a0[UB][NCT], a1[UB][NCT];
+            load_rows(k + 1, a0);
+            for (int r0 = k + 1; r0 < n; r0 += 2 * UB) {
+                load_rows(r0 + UB, a1);
+                update_rows(r0, a0);
+                load_rows(r0 + 2 * UB, a0);
+                update_rows(r0 + UB, a1);
             }
         }
         __syncthreads();
