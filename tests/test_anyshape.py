@@ -264,3 +264,19 @@ def test_unsupported_anyshape_arguments_raise():
         ctx.decompose(X, 0, 1, -16, 15)
     with pytest.raises(ValueError):
         ctx.decompose(X, 2, 1, -200, 15)
+
+
+@pytest.mark.gpu
+def test_hip_edge_planes():
+    """zero / constant planes, a tiny and a thin image: no NaN, and the error the reference reaches (its values were
+    captured in the build container at one thread; the initial column signs differ, hence the loose bound)"""
+    import lrf_amd
+    cases = [(torch.zeros(3, 24, 40, dtype=torch.uint8), dict(quality=20, patch=False), 4.3333),
+             (torch.full((3, 40, 56), 77, dtype=torch.uint8), dict(quality=10, patch_size=(16, 16)), 4.0),
+             (torch.full((3, 24, 40), 200, dtype=torch.uint8), dict(quality=30, patch=False), 0.0),
+             (torch.arange(3 * 8 * 8, dtype=torch.uint8).reshape(3, 8, 8), dict(quality=50, patch_size=(4, 4)), 36.4375),
+             ((torch.arange(3 * 9 * 200) % 251).to(torch.uint8).reshape(3, 9, 200), dict(quality=40, patch=False), 3847.12)]
+    for img, kw, ref_mse in cases:
+        dec = lrf_amd.qmf_decode(lrf_amd.qmf_encode(img, **kw))
+        mse = float(((img.float() - dec.float()) ** 2).mean())
+        assert mse <= 1.5 * ref_mse + 0.5, (kw, mse, ref_mse)
