@@ -47,7 +47,7 @@ struct lrf_ctx {
     hipStream_t own_stream = nullptr;
     DevBuf planes, blocks, vf, wf, bf, ppart, qpart, x, sign;
     DevBuf sx, sg, svn, swn, suf, smm; // SVD baseline workspace
-    DevBuf any_uf, any_vf, any_a, any_b, any_p, any_e2, any_g, any_x; // any-shape path (lrf_anyshape_host.inc)
+    DevBuf any_uf, any_vf, any_a, any_b, any_p, any_e2, any_g; // any-shape path (lrf_anyshape_host.inc)
     // host staging for descriptor tables (pinned)
     void* h_stage = nullptr;
     size_t h_stage_cap = 0;
@@ -430,7 +430,7 @@ void lrf_ctx_destroy(lrf_ctx* c)
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     DevBuf* bufs[] = {&c->planes, &c->blocks, &c->vf, &c->wf, &c->bf, &c->ppart, &c->qpart, &c->x, &c->sign,
                       &c->sx, &c->sg, &c->svn, &c->swn, &c->suf, &c->smm,
-                      &c->any_uf, &c->any_vf, &c->any_a, &c->any_b, &c->any_p, &c->any_e2, &c->any_g, &c->any_x};
+                      &c->any_uf, &c->any_vf, &c->any_a, &c->any_b, &c->any_p, &c->any_e2, &c->any_g};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -468,7 +468,12 @@ int lrf_ctx_synchronize(lrf_ctx* c)
 size_t lrf_ctx_workspace_bytes(const lrf_ctx* c)
 {
     if (!c) return 0;
-    return c->planes.cap + c->blocks.cap + c->vf.cap + c->wf.cap + c->bf.cap + c->ppart.cap + c->qpart.cap + c->x.cap + c->sign.cap;
+    const DevBuf* bufs[] = {&c->planes, &c->blocks, &c->vf, &c->wf, &c->bf, &c->ppart, &c->qpart, &c->x, &c->sign,
+                            &c->sx, &c->sg, &c->svn, &c->swn, &c->suf, &c->smm,
+                            &c->any_uf, &c->any_vf, &c->any_a, &c->any_b, &c->any_p, &c->any_e2, &c->any_g};
+    size_t total = 0;
+    for (const DevBuf* b : bufs) total += b->cap;
+    return total;
 }
 
 int lrf_ctx_profile(lrf_ctx* c, int enable)
