@@ -286,3 +286,35 @@ def gen_anyshape():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "anyshape":
     gen_anyshape()
+
+
+def gen_loess():
+    """LOESS fixture (lrf/utils/misc.py:276-412): the reference's class is taken out of its module by name (the module
+    itself needs seaborn / pyinstrument, absent here) and run on seeded samples; inputs and predictions are stored."""
+    import ast
+    from itertools import product  # noqa: F401  (names the class body uses)
+    from typing import Optional, Sequence  # noqa: F401
+    from scipy.linalg import lstsq  # noqa: F401
+    path = os.path.join(ref_loader.REF_ROOT, "lrf", "utils", "misc.py")
+    tree = ast.parse(open(path).read())
+    node = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "LOESS"][0]
+    scope = dict(np=np, product=product, Optional=Optional, Sequence=Sequence, lstsq=lstsq)
+    exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), scope)
+    LOESS = scope["LOESS"]
+    rng = np.random.default_rng(7)
+    out = {}
+    for name, n in (("a", 40), ("b", 25)):
+        x = np.sort(rng.uniform(0.05, 1.2, n))
+        y = 20 + 12 * np.log1p(4 * x) + rng.normal(0, 0.4, n)
+        grid = np.linspace(0.0, 1.3, 27)
+        single = LOESS(frac=0.3, degree=1).fit(x, y).predict(grid)
+        model = LOESS(frac=np.arange(0.15, 0.75, 0.1), degree=[1, 2]).fit(x, y)
+        out[name] = dict(x=x.tolist(), y=y.tolist(), grid=grid.tolist(), single=single.tolist(),
+                         searched=model.predict(grid).tolist(), best_frac=float(model.best_frac), best_degree=int(model.best_degree))
+    with open(os.path.join(OUT, "loess.json"), "w") as f:
+        json.dump(out, f)
+    print({k: (v["best_frac"], v["best_degree"]) for k, v in out.items()})
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "loess":
+    gen_loess()
