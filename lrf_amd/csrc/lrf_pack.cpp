@@ -34,21 +34,23 @@ std::string combine(const std::vector<std::string>& parts)
     return acc;
 }
 
-// encode_matrix(mode="col") of a row-major [M,R] int8 matrix
-int encode_matrix(const int8_t* A, int64_t M, int R, std::string& out)
+// one column of a row-major [M,R] int8 matrix, zlib level 9 (encode_matrix, mode "col": utils.py:372-378)
+int compress_column(const int8_t* A, int64_t M, int R, int r, std::string& out)
 {
-    std::vector<std::string> fibers((size_t)R);
     std::vector<unsigned char> col((size_t)M), buf(compressBound((uLong)M));
-    for (int r = 0; r < R; r++) {
-        for (int64_t m = 0; m < M; m++) col[(size_t)m] = (unsigned char)A[m * R + r];
-        uLongf n = (uLongf)buf.size();
-        if (compress2(buf.data(), &n, col.data(), (uLong)M, 9) != Z_OK) return -5;
-        fibers[(size_t)r].assign((const char*)buf.data(), (size_t)n);
-    }
-    char header[96];
-    int hl = snprintf(header, sizeof(header), "{\"num_fibers\": %d, \"mode\": \"col\", \"dtype\": \"int8\"}", R);
-    out = combine({std::string(header, (size_t)hl), combine(fibers)});
+    for (int64_t m = 0; m < M; m++) col[(size_t)m] = (unsigned char)A[m * R + r];
+    uLongf n = (uLongf)buf.size();
+    if (compress2(buf.data(), &n, col.data(), (uLong)M, 9) != Z_OK) return -5;
+    out.assign((const char*)buf.data(), (size_t)n);
     return 0;
+}
+
+// header + fibers of one matrix (utils.py:380-390)
+std::string assemble_matrix(const std::vector<std::string>& fibers)
+{
+    char header[96];
+    int hl = snprintf(header, sizeof(header), "{\"num_fibers\": %d, \"mode\": \"col\", \"dtype\": \"int8\"}", (int)fibers.size());
+    return combine({std::string(header, (size_t)hl), combine(fibers)});
 }
 
 } // namespace
@@ -65,43 +67,62 @@ int lrf_pack_qmf_streams(const int8_t* U, int64_t u_stride, const int8_t* V, int
     if (!U || !V || !M || !R || !metadata || !out || !out_len || B < 1) return -1;
     for (int c = 0; c < 3; c++)
         if (M[c] < 1 || R[c] < 1) return -1;
+    // work item = one column of one factor of one image: a single image spreads over the threads as well as a batch does
+    int64_t cols_per_image = 0;
+    for (int c = 0; c < 3; c++) cols_per_image += 2 * (int64_t)R[c];
+    const int64_t items = B * cols_per_image;
     unsigned hw = std::thread::hardware_concurrency();
     int nt = threads > 0 ? threads : (int)(hw ? (hw > 64 ? 64 : hw) : 1);
-    if (nt > B) nt = (int)B;
+    if (nt > items) nt = (int)items;
+    std::vector<std::string> fibers((size_t)items);
     std::atomic<int64_t> next(0);
     std::atomic<int> status(0);
-    const std::string meta(metadata, (size_t)metadata_len);
     auto work = [&]() {
         for (;;) {
-            int64_t b = next.fetch_add(1);
-            if (b >= B || status.load() != 0) return;
+            int64_t it = next.fetch_add(1);
+            if (it >= items || status.load() != 0) return;
+            const int64_t b = it / cols_per_image;
+            int64_t k = it - b * cols_per_image;
             const int8_t* u = U + b * u_stride;
             const int8_t* v = V + b * v_stride;
-            std::vector<std::string> enc(6);
             int rc = 0;
-            for (int c = 0; c < 3 && rc == 0; c++) {
-                rc = encode_matrix(u, M[c], R[c], enc[2 * c]);
-                if (rc == 0) rc = encode_matrix(v, 64, R[c], enc[2 * c + 1]);
+            for (int c = 0; c < 3; c++) {
+                if (k < R[c]) { rc = compress_column(u, M[c], R[c], (int)k, fibers[(size_t)it]); break; }
+                k -= R[c];
+                if (k < R[c]) { rc = compress_column(v, 64, R[c], (int)k, fibers[(size_t)it]); break; }
+                k -= R[c];
                 u += M[c] * R[c];
                 v += 64 * R[c];
             }
             if (rc) { status.store(rc); return; }
-            std::string stream = combine({meta, combine(enc)});
-            uint8_t* p = (uint8_t*)malloc(stream.size() ? stream.size() : 1);
-            if (!p) { status.store(-4); return; }
-            memcpy(p, stream.data(), stream.size());
-            out[b] = p;
-            out_len[b] = (int64_t)stream.size();
         }
     };
     for (int64_t b = 0; b < B; b++) out[b] = nullptr;
-    std::vector<std::thread> pool;
-    for (int t = 1; t < nt; t++) pool.emplace_back(work);
-    work();
-    for (auto& th : pool) th.join();
-    if (status.load() != 0) {
-        for (int64_t b = 0; b < B; b++) { free(out[b]); out[b] = nullptr; }
-        return status.load();
+    {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; t++) pool.emplace_back(work);
+        work();
+        for (auto& th : pool) th.join();
+    }
+    if (status.load() != 0) return status.load();
+    const std::string meta(metadata, (size_t)metadata_len);
+    for (int64_t b = 0; b < B; b++) {
+        std::vector<std::string> enc;
+        size_t at = (size_t)(b * cols_per_image);
+        for (int c = 0; c < 3; c++)
+            for (int f = 0; f < 2; f++) {
+                enc.push_back(assemble_matrix(std::vector<std::string>(fibers.begin() + at, fibers.begin() + at + R[c])));
+                at += (size_t)R[c];
+            }
+        std::string stream = combine({meta, combine(enc)});
+        uint8_t* p = (uint8_t*)malloc(stream.size() ? stream.size() : 1);
+        if (!p) {
+            for (int64_t j = 0; j < b; j++) { free(out[j]); out[j] = nullptr; }
+            return -4;
+        }
+        memcpy(p, stream.data(), stream.size());
+        out[b] = p;
+        out_len[b] = (int64_t)stream.size();
     }
     return 0;
 }
