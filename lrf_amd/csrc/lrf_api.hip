@@ -280,6 +280,7 @@ static GsParams make_gs(int lo, int hi)
     int mx = abs(lo) > abs(hi) ? abs(lo) : abs(hi);
     gp.flimit = (float)(mx + 2);
     gp.fthr = 0.5f - 8e-7f * (float)(mx + 2); // see gs_row: q~ is within 3 ulp (< 2e-7 |q|) of fl(num/den)
+    gp.exact_int = 0; // set per call by run_bcd (depends on the largest rank)
     return gp;
 }
 
@@ -334,6 +335,7 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
     const long mx_b = abs(lo) > abs(hi) ? abs(lo) : abs(hi);
     static const bool exact_off = getenv("LRF_BIG_GENERIC_GS") && getenv("LRF_BIG_GENERIC_GS")[0] == '1';
     const int big_exact = (!exact_off && (long)(rmax - 1) * 64 * mx_b * mx_b * mx_b < (1L << 24)) ? 1 : 0;
+    gp.exact_int = big_exact; // the same property lets ranks 9..16 of the workgroup kernel drop the ordered chain (gs_row_lds)
     for (int it = 0; it < K; it++) {
         {
             Prof p(c, LRF_K_BCD);

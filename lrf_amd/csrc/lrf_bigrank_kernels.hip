@@ -166,7 +166,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int nsub = (nrows + 63) >> 6;
 
     const float* gt = Bf + (long)bd.plane * LRF_GTB_STRIDE;
-    const int ntl = (R + 15) >> 4; // 16-wide rank tiles in use: the MFMAs of the others would only move zeros
     // A operand of a^T = V^T X^T for tile nt: lane needs V[4s + lq][16 nt + li] at k-step s
     float va[4][16];
 #pragma unroll
@@ -215,11 +214,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 float bx = xr[4 * s];
 #pragma unroll
                 for (int nt = 0; nt < 4; nt++) {
-                    if (nt < ntl) {
-                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[nt][s], bx, acc[nt], 0, 0, 0);
-                        if (MODE == 1)
-                            accw[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(L.wa_s[(nt * 16 + s) * 64 + lane], bx, accw[nt], 0, 0, 0);
-                    }
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[nt][s], bx, acc[nt], 0, 0, 0);
+                    if (MODE == 1)
+                        accw[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(L.wa_s[(nt * 16 + s) * 64 + lane], bx, accw[nt], 0, 0, 0);
                 }
             }
 #pragma unroll
@@ -265,11 +262,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 float qa = urow[16 * wave + li];
 #pragma unroll
                 for (int nt = 0; nt < 4; nt++) {
-                    if (nt < ntl) {
-                        float ub = urow[16 * nt + li];
-                        accP[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(px, ub, accP[nt], 0, 0, 0);
-                        if (wave < ntl) accQ[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa, ub, accQ[nt], 0, 0, 0);
-                    }
+                    float ub = urow[16 * nt + li];
+                    accP[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(px, ub, accP[nt], 0, 0, 0);
+                    accQ[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa, ub, accQ[nt], 0, 0, 0);
                 }
             }
         }

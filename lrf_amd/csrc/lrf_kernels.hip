@@ -633,10 +633,21 @@ __global__ __launch_bounds__(256) LRF_KALIGN __attribute__((amdgpu_waves_per_eu(
 #define LRF_GT_DEN 17
 #define LRF_GT_STRIDE (LRF_RP * LRF_GT_LD)
 
+// acc += b * u with a wave-uniform b (SGPR operand).  Spelled in assembly so that the SLP vectoriser does not pair the
+// independent accumulators of the exact Gauss-Seidel into v_pk_fma_f32 (which costs thousands of register moves there).
+__device__ __forceinline__ void fmac_su(float& acc, float b_uniform, float u)
+{
+    asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "s"(b_uniform), "v"(u));
+}
+// keeps the scalar loads of one table row next to their use (hoisted together they overflow the SGPR file)
+#define LRF_TABLE_ROW_FENCE() asm volatile("" ::: "memory")
+
 struct GsParams {
     float lo, hi;      // clamp
     float flimit;      // |q~| >= flimit: certainly outside [lo,hi] after rounding
     float fthr;        // |q~ - rint(q~)| <= fthr: rint(q~) == rint(fl(num/den))
+    int exact_int;     // iterations >= 2 only: every term and partial sum of `uu @ bb` is an exact integer in fp32 for the
+                       // call's largest rank and bounds ((R-1) 64 mx^3 < 2^24), so the order of that sum is immaterial
 };
 
 // term2 = uu . bb in the reference's order (qmf.py:115): ATen native chain or the MKL single-column tree
@@ -736,12 +747,37 @@ __device__ __forceinline__ void gs_row_lds(const float* a_row, float* u_row, con
     STAMP(gl1);
     GSP_ADD(0, gl0, gl1);
 #endif
-    bool unsafe = native ? gs_row<R, true, false>(a, u, gt, gp) : gs_row<R, false, false>(a, u, gt, gp);
-    if (__any(unsafe)) { // rare (about one wave in a few hundred): redo with the reference's IEEE division
+    if (FROM_I8 && R > 8 && gp.exact_int) {
+        // Ranks 9..16 from the second iteration on: integer u, integer b, sums below 2^24 — the reference's dependent chain
+        // per column (and the R (R-1)-entry register copy of the table it needs) becomes R (R-1) independent fmas on R
+        // accumulators: T[r] starts as the sum over the columns j > r still holding old values and receives u_r b[r][r']
+        // for every later column as soon as u_r is known.  Bit-identical; the b rows are wave-uniform scalar loads.
+        float T[R];
 #pragma unroll
-        for (int r = 0; r < R; r++) u[r] = u0[r];
-        if (native) gs_row<R, true, true>(a, u, gt, gp);
-        else gs_row<R, false, true>(a, u, gt, gp);
+        for (int r = 0; r < R; r++) T[r] = 0.f;
+#pragma unroll
+        for (int j = 1; j < R; j++) {
+            LRF_TABLE_ROW_FENCE();
+#pragma unroll
+            for (int r = 0; r < j; r++) fmac_su(T[r], gt[j * LRF_GT_LD + r], u0[j]);
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            LRF_TABLE_ROW_FENCE();
+            const float num = (a[r] - T[r]) + LRF_EPS;
+            const float val = rintf(num / gt[r * LRF_GT_LD + LRF_GT_DEN]);
+            u[r] = fminf(fmaxf(val, gp.lo), gp.hi);
+#pragma unroll
+            for (int rn = r + 1; rn < R; rn++) fmac_su(T[rn], gt[r * LRF_GT_LD + rn - 1], u[r]);
+        }
+    } else {
+        bool unsafe = native ? gs_row<R, true, false>(a, u, gt, gp) : gs_row<R, false, false>(a, u, gt, gp);
+        if (__any(unsafe)) { // rare (about one wave in a few hundred): redo with the reference's IEEE division
+#pragma unroll
+            for (int r = 0; r < R; r++) u[r] = u0[r];
+            if (native) gs_row<R, true, true>(a, u, gt, gp);
+            else gs_row<R, false, true>(a, u, gt, gp);
+        }
     }
 #ifdef LRF_STAMPS
     STAMP(gl2);

@@ -8,8 +8,9 @@ import torch, lrf_amd
 g = torch.Generator(device="cuda").manual_seed(0)
 imgs = torch.randint(0, 256, (64, 3, 512, 768), dtype=torch.uint8, device="cuda", generator=g)
 ctx = _lib.context(0)
-for _ in range(2): lrf_amd.qmf_factorize_batch(imgs, (20, 10, 10))
+RANKS = tuple(int(v) for v in sys.argv[2].split(",")) if len(sys.argv) > 2 else (20, 10, 10)
+for _ in range(2): lrf_amd.qmf_factorize_batch(imgs, RANKS)
 torch.cuda.synchronize(); ctx.profile(True); ctx.profile_reset()
-for _ in range(3): lrf_amd.qmf_factorize_batch(imgs, (20, 10, 10))
+for _ in range(3): lrf_amd.qmf_factorize_batch(imgs, RANKS)
 torch.cuda.synchronize()
-print(sys.argv[1], {n: round(ctx.kernel_time(k)[0] / max(ctx.kernel_time(k)[1], 1), 4) for k, n in _lib.KERNEL_NAMES.items()})
+print(sys.argv[1], RANKS, {n: round(ctx.kernel_time(k)[0] / max(ctx.kernel_time(k)[1], 1), 4) for k, n in _lib.KERNEL_NAMES.items()})

@@ -7,7 +7,10 @@ from lrf_amd import _lib
 g = torch.Generator(device="cuda").manual_seed(0)
 imgs = torch.randint(0, 256, (64, 3, 512, 768), dtype=torch.uint8, device="cuda", generator=g)
 ctx = _lib.context(0)
-for ranks in ((4, 2, 2), (7, 3, 3), (8, 4, 4), (10, 5, 5), (16, 8, 8), (20, 10, 10), (26, 13, 13), (40, 20, 20)):
+TRIPLES = ((4, 2, 2), (7, 3, 3), (8, 4, 4), (10, 5, 5), (16, 8, 8), (20, 10, 10), (26, 13, 13), (40, 20, 20))
+if len(sys.argv) > 1:  # e.g. "26,13,13": one triple only (for a rocprofv3 --stats run)
+    TRIPLES = (tuple(int(v) for v in sys.argv[1].split(",")),)
+for ranks in TRIPLES:
     for _ in range(2): lrf_amd.qmf_factorize_batch(imgs, ranks)
     torch.cuda.synchronize(); ctx.profile(True); ctx.profile_reset()
     t0 = time.perf_counter()
