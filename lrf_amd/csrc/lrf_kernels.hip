@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <utility>
+
 #include "lrf_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -633,15 +635,6 @@ __global__ __launch_bounds__(256) LRF_KALIGN __attribute__((amdgpu_waves_per_eu(
 #define LRF_GT_DEN 17
 #define LRF_GT_STRIDE (LRF_RP * LRF_GT_LD)
 
-// acc += b * u with a wave-uniform b (SGPR operand).  Spelled in assembly so that the SLP vectoriser does not pair the
-// independent accumulators of the exact Gauss-Seidel into v_pk_fma_f32 (which costs thousands of register moves there).
-__device__ __forceinline__ void fmac_su(float& acc, float b_uniform, float u)
-{
-    asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "s"(b_uniform), "v"(u));
-}
-// keeps the scalar loads of one table row next to their use (hoisted together they overflow the SGPR file)
-#define LRF_TABLE_ROW_FENCE() asm volatile("" ::: "memory")
-
 struct GsParams {
     float lo, hi;      // clamp
     float flimit;      // |q~| >= flimit: certainly outside [lo,hi] after rounding
@@ -649,6 +642,78 @@ struct GsParams {
     int exact_int;     // iterations >= 2 only: every term and partial sum of `uu @ bb` is an exact integer in fp32 for the
                        // call's largest rank and bounds ((R-1) 64 mx^3 < 2^24), so the order of that sum is immaterial
 };
+
+// acc += b * u with a wave-uniform b (SGPR operand).  Spelled in assembly so that the SLP vectoriser does not pair the
+// independent accumulators of the exact Gauss-Seidel into v_pk_fma_f32 (which costs thousands of register moves there).
+__device__ __forceinline__ void fmac_su(float& acc, float b_uniform, float u)
+{
+    asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "s"(b_uniform), "v"(u));
+}
+// acc += tab[lane N of each 16-lane row] * x, and the broadcast alone: a wave-uniform table kept in VGPRs reaches the VALU
+// through DPP row_newbcast with no memory latency at all (the same device k_bcd_w uses for V and its b table)
+template <int N>
+__device__ __forceinline__ void fmac_bc16(float& acc, float tab, float x)
+{
+    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(tab), "v"(x), "n"(N));
+}
+template <int N>
+__device__ __forceinline__ float get_bc16(float tab)
+{
+    float out;
+    asm("v_mov_b32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(out) : "v"(tab), "n"(N));
+    return out;
+}
+// Exact-integer Gauss-Seidel of ranks 9..16 (see gs_row_lds) on a table in seventeen VGPRs: tabv[j], lane l = b[j][l & 15]
+// (symmetric, the diagonal holds den).  T[r] += u0[J] b[J][r] for r < J;  T[r'] += u_R0 b[R0][r'] for r' > R0.
+template <int R, int J, int... Rs>
+__device__ __forceinline__ void gsx_s_row(float (&T)[R], float tab, float u, std::integer_sequence<int, Rs...>)
+{
+    (fmac_bc16<Rs>(T[Rs], tab, u), ...);
+}
+template <int R, int J>
+__device__ __forceinline__ void gsx_s(float (&T)[R], const float (&tabv)[17], const float (&u0)[R])
+{
+    if constexpr (J < R) {
+        gsx_s_row<R, J>(T, tabv[J], u0[J], std::make_integer_sequence<int, J>{});
+        gsx_s<R, J + 1>(T, tabv, u0);
+    }
+}
+template <int R, int R0, int... Is>
+__device__ __forceinline__ void gsx_p_row(float (&T)[R], float tab, float u, std::integer_sequence<int, Is...>)
+{
+    (fmac_bc16<R0 + 1 + Is>(T[R0 + 1 + Is], tab, u), ...);
+}
+// FAST: the quotient as num * (1 / den) with the tie / range test of gs_row (returns "some column was too close to call":
+// the caller then repeats the row with the IEEE division); the division sits on the column-to-column dependency chain,
+// which is what bounds this solve.
+template <int R, int R0, bool FAST>
+__device__ __forceinline__ bool gsx_p(float (&T)[R], const float (&tabv)[17], float rdenv, const float (&a)[R], float (&u)[R],
+                                      const GsParams& gp)
+{
+    if constexpr (R0 < R) {
+        const float num = (a[R0] - T[R0]) + LRF_EPS;
+        float val;
+        bool unsafe = false;
+        if (FAST) {
+            const float q = num * get_bc16<R0>(rdenv);
+            const float nq = rintf(q);
+            const bool inside = fabsf(q) < gp.flimit;
+            unsafe = inside && !(fabsf(q - nq) <= gp.fthr);
+            val = inside ? nq : q;
+        } else {
+            val = rintf(num / get_bc16<R0>(tabv[R0]));
+        }
+        u[R0] = fminf(fmaxf(val, gp.lo), gp.hi);
+        gsx_p_row<R, R0>(T, tabv[R0], u[R0], std::make_integer_sequence<int, R - 1 - R0>{});
+        return gsx_p<R, R0 + 1, FAST>(T, tabv, rdenv, a, u, gp) || unsafe;
+    } else {
+        return false;
+    }
+}
+
+// keeps the scalar loads of one table row next to their use (hoisted together they overflow the SGPR file)
+#define LRF_TABLE_ROW_FENCE() asm volatile("" ::: "memory")
+
 
 // term2 = uu . bb in the reference's order (qmf.py:115): ATen native chain or the MKL single-column tree
 template <int K, bool NATIVE>
@@ -732,7 +797,7 @@ __device__ __forceinline__ bool gs_row(const float* a, float* u, const float* __
 // LDS reads/writes are issued as batches (a runtime-R loop costs one exposed LDS latency per element).
 template <int R, bool FROM_I8>
 __device__ __forceinline__ void gs_row_lds(const float* a_row, float* u_row, const int8_t* uold_row,
-                                           const float* __restrict__ gt, bool native, const GsParams gp)
+                                           const float* __restrict__ gt, bool native, const GsParams gp, const float (&tabv)[17])
 {
     float a[R], u0[R], u[R];
 #pragma unroll
@@ -751,24 +816,20 @@ __device__ __forceinline__ void gs_row_lds(const float* a_row, float* u_row, con
         // Ranks 9..16 from the second iteration on: integer u, integer b, sums below 2^24 — the reference's dependent chain
         // per column (and the R (R-1)-entry register copy of the table it needs) becomes R (R-1) independent fmas on R
         // accumulators: T[r] starts as the sum over the columns j > r still holding old values and receives u_r b[r][r']
-        // for every later column as soon as u_r is known.  Bit-identical; the b rows are wave-uniform scalar loads.
+        // for every later column as soon as u_r is known.  Bit-identical; the table sits in sixteen VGPRs (tabv) and is
+        // broadcast by DPP (scalar loads of it, even fenced row by row, left one exposed scalar-cache latency per row).
         float T[R];
 #pragma unroll
         for (int r = 0; r < R; r++) T[r] = 0.f;
+        gsx_s<R, 1>(T, tabv, u0);
+        float T0[R];
 #pragma unroll
-        for (int j = 1; j < R; j++) {
-            LRF_TABLE_ROW_FENCE();
+        for (int r = 0; r < R; r++) T0[r] = T[r];
+        const float rdenv = tabv[16]; // lane l: 1 / den[l & 15]
+        if (__any(gsx_p<R, 0, true>(T, tabv, rdenv, a, u, gp))) { // rare: repeat with the reference's IEEE division
 #pragma unroll
-            for (int r = 0; r < j; r++) fmac_su(T[r], gt[j * LRF_GT_LD + r], u0[j]);
-        }
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            LRF_TABLE_ROW_FENCE();
-            const float num = (a[r] - T[r]) + LRF_EPS;
-            const float val = rintf(num / gt[r * LRF_GT_LD + LRF_GT_DEN]);
-            u[r] = fminf(fmaxf(val, gp.lo), gp.hi);
-#pragma unroll
-            for (int rn = r + 1; rn < R; rn++) fmac_su(T[rn], gt[r * LRF_GT_LD + rn - 1], u[r]);
+            for (int r = 0; r < R; r++) T[r] = T0[r];
+            gsx_p<R, 0, false>(T, tabv, rdenv, a, u, gp);
         }
     } else {
         bool unsafe = native ? gs_row<R, true, false>(a, u, gt, gp) : gs_row<R, false, false>(a, u, gt, gp);
@@ -792,12 +853,12 @@ __device__ __forceinline__ void gs_row_lds(const float* a_row, float* u_row, con
 
 template <int RMAX, bool FROM_I8>
 __device__ __forceinline__ void gs_dispatch(int R, const float* a_row, float* u_row, const int8_t* uold_rows, int lane,
-                                            const float* __restrict__ gt, bool native, const GsParams gp)
+                                            const float* __restrict__ gt, bool native, const GsParams gp, const float (&tabv)[17])
 {
     switch (R) {
 #define LRF_CASE(r)                                                                                              \
     case r:                                                                                                      \
-        if (r <= RMAX) gs_row_lds<(r <= RMAX ? r : 1), FROM_I8>(a_row, u_row, uold_rows + lane * r, gt, native, gp); \
+        if (r <= RMAX) gs_row_lds<(r <= RMAX ? r : 1), FROM_I8>(a_row, u_row, uold_rows + lane * r, gt, native, gp, tabv); \
         break;
         LRF_CASE(1) LRF_CASE(2) LRF_CASE(3) LRF_CASE(4) LRF_CASE(5) LRF_CASE(6) LRF_CASE(7) LRF_CASE(8)
         LRF_CASE(9) LRF_CASE(10) LRF_CASE(11) LRF_CASE(12) LRF_CASE(13) LRF_CASE(14) LRF_CASE(15) LRF_CASE(16)
@@ -897,6 +958,16 @@ __global__ __launch_bounds__(256) LRF_KALIGN void k_bcd(const float* __restrict_
     if (nrows > LRF_KC) nrows = LRF_KC;
     const int nsub = (nrows + 63) >> 6;
     const int invR = (65536 + R - 1) / R; // (i * invR) >> 16 == i / R for i < 64 * R
+    // the symmetric b table of the exact Gauss-Seidel (ranks 9..16, iterations >= 2): tabv[j], lane l = b[j][l & 15]
+    float tabv[17]; // [16]: lane l = 1 / den[l & 15]
+#pragma unroll
+    for (int j = 0; j < 17; j++) tabv[j] = 0.f;
+    if (RMAX > 8 && MODE == 0 && gp.exact_int && R > 8) {
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            if (j < R && li < R) tabv[j] = (j == li) ? gt[li * LRF_GT_LD + LRF_GT_DEN] : gt[li * LRF_GT_LD + (j < li ? j : j - 1)];
+        if (li < R) tabv[16] = gt[li * LRF_GT_LD + LRF_GT_RDEN];
+    }
 
     // A operand of a^T = V^T X^T : A[i = r][k]; lane needs V[4s + lq][li] at k-step s.  Kept in LDS in
     // [step][lane] order (conflict-free, one ds_read per MFMA) rather than in 16 VGPRs per wave.
@@ -1014,7 +1085,10 @@ __global__ __launch_bounds__(256) LRF_KALIGN void k_bcd(const float* __restrict_
             STAMP(g0);
             int row = r0 + lane;
             float* ur = &u_s[lane * LRF_RP];
-            if (row < nrows) {
+            // the DPP broadcasts of the exact solve read lanes of the table registers: every lane of the wave must be active,
+            // so rows past the end are solved too (their inputs are zeros / stale bytes, finite) and zeroed afterwards
+            const bool all_lanes = (MODE == 0) && RMAX > 8 && gp.exact_int && R > 8;
+            if (row < nrows || all_lanes) {
                 if (MODE == 2) {
                     const float* up = U0 + pd.u0_off + ((long)bd.row0 + row) * R;
                     for (int r = 0; r < R; r++) ur[r] = up[r];
@@ -1034,14 +1108,15 @@ __global__ __launch_bounds__(256) LRF_KALIGN void k_bcd(const float* __restrict_
                     *reinterpret_cast<f32x4*>(ur + 12) = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
 #else
-                gs_dispatch<RMAX, MODE == 0>(R, &a_s[lane * LRF_RP], ur, uold_s, lane, gt, pd.native_t2_u != 0, gp);
+                gs_dispatch<RMAX, MODE == 0>(R, &a_s[lane * LRF_RP], ur, uold_s, lane, gt, pd.native_t2_u != 0, gp, tabv);
 #endif
                 STAMP(g2);
 #ifdef LRF_STAMPS
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 STAMP(g3);
 #endif
-            } else {
+            }
+            if (!(row < nrows)) {
 #pragma unroll
                 for (int r = 0; r < LRF_RP; r += 4) *reinterpret_cast<f32x4*>(ur + r) = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
@@ -1174,7 +1249,8 @@ __global__ __launch_bounds__(256) LRF_KALIGN void k_vupdate(const PlaneDesc* __r
     __syncthreads();
     if (tid < 64) {
         bool native = (long)(R - 1) * 64 < 400;
-        gs_dispatch<RMAX, false>(R, &a_s[tid * LRF_RP], &v_s[tid * LRF_RP], nullptr, 0, gt_s, native, gp);
+        const float no_tab[17] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; // FROM_I8 = false: unused
+        gs_dispatch<RMAX, false>(R, &a_s[tid * LRF_RP], &v_s[tid * LRF_RP], nullptr, 0, gt_s, native, gp, no_tab);
         float* Vp = Vf + (long)blockIdx.x * 64 * LRF_RP + tid * LRF_RP;
         for (int r = 0; r < R; r++) Vp[r] = v_s[tid * LRF_RP + r];
         if (write_i8) {
