@@ -25,9 +25,6 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 // Householder columns whose squared norm is at or below this are skipped (oracle: tridiagonalize): cascaded rounding noise of
 // rank-deficient Gram matrices lands in the denormal range, where t = 2 / |v|^2 overflows
 #define LRF_SIGMA_TINY 1e-280
-// Kernel entry points are pinned to 4 KB boundaries: k_bcd_w lost a third of its speed at one unlucky offset
-// (lrf_bcdw_kernel.hip), so no kernel's placement is left to whatever precedes it in the code object.
-#define LRF_KALIGN __attribute__((aligned(4096)))
 
 // Diagnostic build only (-DLRF_STAMPS, never shipped): per-phase cycle sums of k_bcd, wave 0 of each workgroup.
 #ifdef LRF_STAMPS
@@ -80,7 +77,7 @@ __device__ __forceinline__ float ycc_of(float r, float g, float b, int c)
 // One workgroup per (patch row of one plane, image): it consumes 8 (luma) or 16 (chroma) full image rows and
 // writes nw complete 256-byte patches.  Thread item = one float4 of a patch (16 consecutive items = one patch,
 // so stores are fully coalesced); int32 arithmetic only, word loads on the aligned interior fast paths.
-__global__ __launch_bounds__(256) LRF_KALIGN void k_planes(const uint8_t* __restrict__ rgb, int H, int W, ImageGeom g,
+__global__ __launch_bounds__(256) void k_planes(const uint8_t* __restrict__ rgb, int H, int W, ImageGeom g,
                                                 float* __restrict__ X)
 {
     const int pr = blockIdx.x;
@@ -159,7 +156,7 @@ __global__ __launch_bounds__(256) LRF_KALIGN void k_planes(const uint8_t* __rest
 // aligned rows): every RGB byte is read once.  One workgroup per 16-row strip; a thread takes a 2 x 8 pixel block
 // (six 8-byte loads) and produces its sixteen luma samples and its four Cb and four Cr samples with the arithmetic and
 // orders of k_planes (ycc_of; the window sum is row-major: (0,0), (0,1), (1,0), (1,1)).
-__global__ __launch_bounds__(256) LRF_KALIGN void k_planes16(const uint8_t* __restrict__ rgb, int H, int W, ImageGeom g,
+__global__ __launch_bounds__(256) void k_planes16(const uint8_t* __restrict__ rgb, int H, int W, ImageGeom g,
                                                   float* __restrict__ X)
 {
     // luma staging: [h = patch row 0/1 of the strip][patch 0..31][16 float4], float4 slot q stored at q ^ swz(h, q)
@@ -296,7 +293,7 @@ struct InitLds {
 };
 
 template <int ZR>
-__global__ __launch_bounds__(256) LRF_KALIGN __attribute__((amdgpu_waves_per_eu(3, 3))) void k_init(const float* __restrict__ X, const PlaneDesc* __restrict__ planes,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_init(const float* __restrict__ X, const PlaneDesc* __restrict__ planes,
                                               const int8_t* __restrict__ sign, float* __restrict__ Vf,
                                               float* __restrict__ Wf, int debug_stop, int rp)
 {
@@ -929,7 +926,7 @@ __device__ __forceinline__ void rows_transpose4(f32x4& c)
 }
 
 template <int MODE, int RMAX>
-__global__ __launch_bounds__(256) LRF_KALIGN void k_bcd(const float* __restrict__ X, const PlaneDesc* __restrict__ planes,
+__global__ __launch_bounds__(256) void k_bcd(const float* __restrict__ X, const PlaneDesc* __restrict__ planes,
                                              const BlockDesc* __restrict__ blocks, const float* __restrict__ Vf,
                                              const float* __restrict__ Wf, const float* __restrict__ Bf,
                                              const float* __restrict__ U0, int8_t* __restrict__ U,
@@ -1190,7 +1187,7 @@ __global__ __launch_bounds__(256) LRF_KALIGN void k_bcd(const float* __restrict_
 // then the b table (v.mT @ v) of the new V for the next U update.
 // ------------------------------------------------------------------------------------------------
 template <int RMAX>
-__global__ __launch_bounds__(256) LRF_KALIGN void k_vupdate(const PlaneDesc* __restrict__ planes, const float* __restrict__ Ppart,
+__global__ __launch_bounds__(256) void k_vupdate(const PlaneDesc* __restrict__ planes, const float* __restrict__ Ppart,
                                                  const float* __restrict__ Qpart, float* __restrict__ Vf,
                                                  float* __restrict__ Bf, int8_t* __restrict__ V8, GsParams gp,
                                                  int write_i8)
@@ -1316,7 +1313,7 @@ __device__ __forceinline__ float recon_at(const int8_t* __restrict__ Uc, const i
 // to 8 columns), a thread keeps the u row of the patch it is in and reloads it only when the patch changes (four
 // horizontally adjacent pixels touch at most two luma and two chroma patches), and the four output bytes of a
 // channel leave as one dword.  Same arithmetic and order as k_decode.
-__global__ __launch_bounds__(256) LRF_KALIGN void k_decode8(const int8_t* __restrict__ U, const int8_t* __restrict__ V, int H, int W,
+__global__ __launch_bounds__(256) void k_decode8(const int8_t* __restrict__ U, const int8_t* __restrict__ V, int H, int W,
                                                  ImageGeom g, int R0, int R1, int R2, long u_img, long v_img,
                                                  uint8_t* __restrict__ rgb)
 {
@@ -1387,7 +1384,7 @@ __global__ __launch_bounds__(256) LRF_KALIGN void k_decode8(const int8_t* __rest
     }
 }
 
-__global__ __launch_bounds__(256) LRF_KALIGN void k_decode(const int8_t* __restrict__ U, const int8_t* __restrict__ V, int H, int W,
+__global__ __launch_bounds__(256) void k_decode(const int8_t* __restrict__ U, const int8_t* __restrict__ V, int H, int W,
                                                 ImageGeom g, int R0, int R1, int R2, long u_img, long v_img,
                                                 uint8_t* __restrict__ rgb)
 {
