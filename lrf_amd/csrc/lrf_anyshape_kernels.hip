@@ -237,7 +237,8 @@ __global__ __launch_bounds__(256) void k_any_gram(const float* __restrict__ X, l
 template <int NCT>
 __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, int R, const int8_t* __restrict__ sign,
                                                  float* __restrict__ E1, float* __restrict__ E2, double* __restrict__ Zw,
-                                                 double* __restrict__ Dw, int stop_after /* developer timing aid, 0 = run all */)
+                                                 double* __restrict__ Dw, int stop_after /* developer timing aid, 0 = run all */,
+                                                 int rcap /* rank of the matrix at most this: columns beyond are zero */)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* Lv = reinterpret_cast<double*>(smem);
@@ -249,7 +250,8 @@ __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, 
     double* Llam = Ltau + n;      // [R]
     double* Lpart = Llam + R;     // [16]
     double* Lscal = Lpart + 16;   // [8]
-    const int Rc = R < n ? R : n;
+    const int Rn = R < n ? R : n;
+    const int Rc = Rn < rcap ? Rn : rcap;
     double* A = G + (long)blockIdx.x * n * n;
     double* Z = Zw + (long)blockIdx.x * Rc * n;
     double* Dp = Dw + (long)blockIdx.x * 2 * n * Rc;

@@ -721,7 +721,7 @@ int lrf_svd_encode_rgb_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_t H, 
     if (!c || !rgb || !U || !V || !qparams) return set_err(LRF_EINVAL, "NULL argument");
     if (B < 1 || B > 65535) return set_err(LRF_EINVAL, "B=%ld out of range [1,65535]", (long)B);
     if (R < 1) return set_err(LRF_EINVAL, "rank must be >= 1 (got %d)", R);
-    if (R > EIG_ZR) return set_err(LRF_ENOTSUP, "svd_encode: rank %d > %d not implemented (k_eig_n keeps %d eigenvectors in LDS)", R, EIG_ZR, EIG_ZR);
+    if (R > 192) return set_err(LRF_EINVAL, "svd_encode: rank %d > 192 columns", R);
     int hp, wp, top, left, nw, M, rc;
     if ((rc = svd_geom(H, W, &hp, &wp, &top, &left, &nw, &M))) return rc;
     const int N = 192, nc = 3;
@@ -733,10 +733,6 @@ int lrf_svd_encode_rgb_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_t H, 
     if ((rc = ensure(c, c->swn, (size_t)B * N * R * sizeof(float)))) return rc;
     if ((rc = ensure(c, c->suf, (size_t)B * M * R * sizeof(float)))) return rc;
     if ((rc = ensure(c, c->smm, (size_t)B * 4 * sizeof(float)))) return rc;
-    if (!(c->attr_done & (1u << 3))) {
-        HIP_TRY(hipFuncSetAttribute((const void*)k_eig_n, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(EigLds)));
-        c->attr_done |= 1u << 3;
-    }
     float* X = (float*)c->sx.p;
     double* G = (double*)c->sg.p;
     float* Vn = (float*)c->svn.p;
@@ -747,11 +743,7 @@ int lrf_svd_encode_rgb_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_t H, 
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_gram_blk, dim3(nc * (nc + 1) / 2, (unsigned)B), dim3(256), 0, c->stream, (const float*)X, xs, M, N, nc, G);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_eig_n, dim3((unsigned)B), dim3(256), sizeof(EigLds), c->stream, G, N, M, R, sign, Vn, Wn);
-    LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_xw_n, dim3((unsigned)(((long)M * R + 255) / 256), (unsigned)B), dim3(256), 0, c->stream, (const float*)X, xs, M,
-                       N, R, (const float*)Wn, Uf);
-    LAUNCH_CHECK();
+    if ((rc = any_factors_from_gram(c, X, G, (int)B, M, N, R, sign, Vn, Wn, Uf))) return rc;
     hipLaunchKernelGGL(k_minmax, dim3((unsigned)B), dim3(256), 0, c->stream, (const float*)Uf, (long)M * R, (long)M * R, mm);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_minmax, dim3((unsigned)B), dim3(256), 0, c->stream, (const float*)Vn, (long)N * R, (long)N * R, mm + 2 * B);
@@ -814,7 +806,7 @@ static int rgbspace_check(int64_t B, int64_t H, int64_t W, int R, int K, int lo,
 {
     if (B < 1 || B > 65535) return set_err(LRF_EINVAL, "B=%ld out of range [1,65535]", (long)B);
     if (R < 1) return set_err(LRF_EINVAL, "rank must be >= 1 (got %d)", R);
-    if (R > EIG_ZR) return set_err(LRF_ENOTSUP, "RGB colour space: rank %d > %d not implemented", R, EIG_ZR);
+    if (R > LRF_RPN) return set_err(LRF_ENOTSUP, "RGB colour space: rank %d > %d not implemented", R, LRF_RPN);
     if (K < 1) return set_err(LRF_ENOTSUP, "RGB colour space: num_iters=%d not implemented (K >= 1)", K);
     if (lo > hi || lo < -128 || hi > 127) return set_err(LRF_EINVAL, "bounds (%d,%d) outside int8", lo, hi);
     (void)M; // u.mT @ u stays the reference's for any int8 bounds: see check_params
@@ -891,10 +883,6 @@ int lrf_qmf_rgbspace_encode_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_
         if ((rc = ensure(c, c->svn, (size_t)B * N * R * sizeof(float)))) return rc;
         if ((rc = ensure(c, c->swn, (size_t)B * N * R * sizeof(float)))) return rc;
         if ((rc = ensure(c, c->suf, (size_t)B * M * R * sizeof(float)))) return rc;
-        if (!(c->attr_done & (1u << 5))) {
-            HIP_TRY(hipFuncSetAttribute((const void*)k_eig_n, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(EigLds)));
-            c->attr_done |= 1u << 5;
-        }
         double* G = (double*)c->sg.p;
         float* Vn = (float*)c->svn.p;
         float* Wn = (float*)c->swn.p;
@@ -902,11 +890,7 @@ int lrf_qmf_rgbspace_encode_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_
         Prof p(c, LRF_K_INIT);
         hipLaunchKernelGGL(k_gram_blk, dim3(nc * (nc + 1) / 2, (unsigned)B), dim3(256), 0, c->stream, (const float*)X, xs, M, N, nc, G);
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_eig_n, dim3((unsigned)B), dim3(256), sizeof(EigLds), c->stream, G, N, M, R, sign, Vn, Wn);
-        LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_xw_n, dim3((unsigned)(((long)M * R + 255) / 256), (unsigned)B), dim3(256), 0, c->stream, (const float*)X, xs,
-                           M, N, R, (const float*)Wn, Uf);
-        LAUNCH_CHECK();
+        if ((rc = any_factors_from_gram(c, X, G, (int)B, M, N, R, sign, Vn, Wn, Uf))) return rc;
         u0 = Uf;
         v0 = Vn;
     }

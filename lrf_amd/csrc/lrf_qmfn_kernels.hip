@@ -47,7 +47,7 @@ __device__ __forceinline__ void make_gtable_n(const float* Vp, int depth, int R,
     }
 }
 
-// V0 [plane][NN][R] fp32 (k_eig_n output) -> padded Vf [plane][NN][LRF_RPN], and the first b table
+// V0 [plane][NN][R] fp32 (k_any_eig output) -> padded Vf [plane][NN][LRF_RPN], and the first b table
 template <int NN>
 __global__ __launch_bounds__(256) void k_bprepn(const PlaneDesc* __restrict__ planes, const float* __restrict__ V0,
                                                 float* __restrict__ Vf, float* __restrict__ Bf)
@@ -74,7 +74,7 @@ struct BcdnLds {
     float gt_s[LRF_GTN_STRIDE];
 };
 
-// MODE 0: old U from int8 (iterations >= 2); MODE 2: first iteration, old U = fp32 U0 (u0 = X w0 from k_xw_n).
+// MODE 0: old U from int8 (iterations >= 2); MODE 2: first iteration, old U = fp32 U0 (u0 = X w0 from k_any_prod).
 // Ppart: per block [NN][LRF_RPN]; Qpart: per block [LRF_RPN][LRF_RPN].
 template <int NN, int MODE>
 __global__ __launch_bounds__(256) void k_bcdn(const float* __restrict__ X, const PlaneDesc* __restrict__ planes,

@@ -2,10 +2,10 @@
 //
 // Reference: lrf/compression/svd.py:156-193 (encode), :310-326 (decode), lrf/compression/utils.py:185-243
 // (quantize / dequantize).  X is [M, 192] (three 8x8 colour patches per row), so the 64-wide kernels of the QMF
-// path do not apply; the top-R singular pairs come from the fp64 Gram matrix (192 x 192, kept in global memory)
-// by the same algorithm as k_init (Householder tridiagonalisation, multisection, twisted factorisation,
-// Gram-Schmidt, back-transformation), written for a general N = 64 * NC.  Parity for this path is by tolerance
-// (SURVEY.md §8d config 5), so reductions use plain block sums.
+// path do not apply; the top-R singular pairs come from the fp64 Gram matrix (192 x 192, k_gram_blk below) through the
+// eigen-solver of the any-shape path (k_any_eig<1>, lrf_anyshape_kernels.hip: Householder tridiagonalisation, multisection,
+// twisted factorisation, Gram-Schmidt, back-transformation) and its ordered product (k_any_prod) for u = X w.  Parity for
+// this path is by tolerance.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -85,15 +85,7 @@ __global__ __launch_bounds__(256) void k_gram_blk(const float* __restrict__ X, l
     }
 }
 
-// ---- top-R eigen-pairs of the N x N Gram matrix in global memory -> v = e sqrt(sigma), w = e / sqrt(sigma) ----
-#define EIG_MAXN 192
-#define EIG_ZR 24 // eigenvectors kept in LDS: ranks up to 24 (svd_encode sweeps reach 10, the RGB branch of qmf_encode 19)
-struct EigLds {
-    double v[EIG_MAXN], w[EIG_MAXN], d[EIG_MAXN], e[EIG_MAXN], e2[EIG_MAXN], tau[EIG_MAXN];
-    double D1[EIG_MAXN * EIG_ZR], D2[EIG_MAXN * EIG_ZR], Z[EIG_ZR * EIG_MAXN];
-    double part[4 * EIG_ZR], lam[EIG_ZR], scal[8];
-};
-
+// ---- reductions shared with the eigen-solver of the any-shape path (k_any_eig, lrf_anyshape_kernels.hip) ----
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll
@@ -109,251 +101,6 @@ __device__ __forceinline__ double block_sum(double v, double* part, int tid)
     double r = ((part[0] + part[1]) + part[2]) + part[3];
     __syncthreads();
     return r;
-}
-
-__global__ __launch_bounds__(256) void k_eig_n(double* __restrict__ G, int N, int M, int R, const int8_t* __restrict__ sign,
-                                               float* __restrict__ Vout, float* __restrict__ Wout)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    EigLds& L = *reinterpret_cast<EigLds*>(smem);
-    double* A = G + (long)blockIdx.x * N * N;
-    const int tid = threadIdx.x, i = tid, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool act = i < N;
-
-    // ---- Householder tridiagonalisation; row k of A keeps v_k
-    for (int k = 0; k < N - 2; k++) {
-        double x = (act && i > k) ? A[(long)k * N + i] : 0.0;
-        double sigma = block_sum(x * x, L.part, tid);
-        if (!(sigma > LRF_SIGMA_TINY)) {
-            if (tid == 0) { L.tau[k] = 0.0; L.e[k] = 0.0; }
-            continue;
-        }
-        double x0 = A[(long)k * N + k + 1];
-        double nrm = sqrt(sigma);
-        double alpha = (x0 >= 0.0) ? -nrm : nrm;
-        double vi = (act && i > k + 1) ? x : 0.0;
-        if (i == k + 1) vi = x0 - alpha;
-        double vn = block_sum(vi * vi, L.part, tid);
-        double t = 2.0 / vn;
-        if (act) {
-            L.v[i] = vi;
-            if (i > k) A[(long)k * N + i] = vi;
-        }
-        if (tid == 0) { L.tau[k] = t; L.e[k] = alpha; }
-        __syncthreads();
-        double c = 0.0;
-        if (act && i > k) {
-#pragma unroll 8
-            for (int j = k + 1; j < N; j++) c = fma(A[(long)j * N + i], L.v[j], c);
-        }
-        double p = t * c;
-        double K = (0.5 * t) * block_sum(p * vi, L.part, tid);
-        double wi = fma(-K, vi, p);
-        if (act) L.w[i] = wi;
-        __syncthreads();
-        if (act && i > k) {
-            const double vc = vi, wc = wi;
-#pragma unroll 4
-            for (int r = k + 1; r < N; r++) {
-                const double vr = L.v[r], wr = L.w[r];
-                const bool rc = r >= i;
-                const double va = rc ? vr : vc, wa = rc ? wr : wc, vb = rc ? vc : vr, wb = rc ? wc : wr;
-                A[(long)r * N + i] = fma(-wa, vb, fma(-va, wb, A[(long)r * N + i]));
-            }
-        }
-        __syncthreads();
-    }
-    if (act) L.d[i] = A[(long)i * N + i];
-    if (tid == 0) {
-        L.e[N - 2] = A[(long)(N - 1) * N + N - 2];
-        L.e[N - 1] = 0.0;
-        L.tau[N - 2] = 0.0;
-        L.tau[N - 1] = 0.0;
-    }
-    __syncthreads();
-
-    // ---- Gershgorin hull, pivmin
-    {
-        double ei = (act && i < N - 1) ? L.e[i] : 0.0, eim = (act && i > 0) ? L.e[i - 1] : 0.0;
-        if (act) L.e2[i] = ei * ei;
-        double rad = fabs(eim) + fabs(ei);
-        double a = act ? L.d[i] - rad : 1e300, b = act ? L.d[i] + rad : -1e300, m2 = ei * ei;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            a = fmin(a, __shfl_xor(a, off, 64));
-            b = fmax(b, __shfl_xor(b, off, 64));
-            m2 = fmax(m2, __shfl_xor(m2, off, 64));
-        }
-        if (lane == 0) { L.part[wave] = a; L.part[4 + wave] = b; L.part[8 + wave] = m2; }
-        __syncthreads();
-        if (tid == 0) {
-            double lo = fmin(fmin(L.part[0], L.part[1]), fmin(L.part[2], L.part[3]));
-            double hi = fmax(fmax(L.part[4], L.part[5]), fmax(L.part[6], L.part[7]));
-            double e2m = fmax(fmax(L.part[8], L.part[9]), fmax(L.part[10], L.part[11]));
-            double tn = fabs(lo) > fabs(hi) ? fabs(lo) : fabs(hi);
-            double pivmin = 2.2250738585072014e-300 * (e2m > 1.0 ? e2m : 1.0);
-            double slack = 2.0 * tn * 2.220446049250313e-16 * N + 2.0 * pivmin;
-            L.scal[1] = pivmin; L.scal[2] = lo - slack; L.scal[3] = hi + slack;
-        }
-        __syncthreads();
-    }
-    const int rmax = M < N ? M : N;
-    const int Rc = R < rmax ? R : rmax;
-    {
-        const double pivmin = L.scal[1];
-        for (int r = wave; r < Rc; r += 4) { // one wave per eigenvalue, 64 shifts per pass
-            const int kk = N - 1 - r;
-            double a = L.scal[2], b = L.scal[3];
-            for (int pass = 0; pass < 10; pass++) {
-                double h = (b - a) / 65.0;
-                double x = a + h * (double)(lane + 1);
-                double q = L.d[0] - x;
-                int cnt = q < 0.0;
-                for (int j = 1; j < N; j++) {
-                    if (fabs(q) < pivmin) q = -pivmin;
-                    q = (L.d[j] - x) - L.e2[j - 1] / q;
-                    cnt += q < 0.0;
-                }
-                unsigned long long mask = __ballot(cnt > kk);
-                int jj = mask ? (int)__builtin_ctzll(mask) : 64;
-                double xm = __shfl(x, jj > 0 ? jj - 1 : 0, 64), xj = __shfl(x, jj < 64 ? jj : 63, 64);
-                double na = (jj == 0) ? a : xm, nb = (jj == 64) ? b : xj;
-                a = na;
-                b = nb;
-            }
-            if (lane == 0) L.lam[r] = 0.5 * (a + b);
-        }
-    }
-    __syncthreads();
-    // ---- twisted factorisation, thread r
-    if (tid < Rc) {
-        const int r = tid;
-        const double lam = L.lam[r], pivmin = L.scal[1];
-        double* Dp = L.D1 + r;
-        double* Dm = L.D2 + r;
-        double q = L.d[0] - lam;
-        Dp[0] = q;
-        for (int j = 1; j < N; j++) {
-            if (fabs(q) < pivmin) q = -pivmin;
-            q = (L.d[j] - lam) - L.e2[j - 1] / q;
-            Dp[j * EIG_ZR] = q;
-        }
-        q = L.d[N - 1] - lam;
-        Dm[(N - 1) * EIG_ZR] = q;
-        for (int j = N - 2; j >= 0; j--) {
-            if (fabs(q) < pivmin) q = -pivmin;
-            q = (L.d[j] - lam) - L.e2[j] / q;
-            Dm[j * EIG_ZR] = q;
-        }
-        int kt = 0;
-        double best = 0.0;
-        for (int j = 0; j < N; j++) {
-            double g = fabs((Dp[j * EIG_ZR] + Dm[j * EIG_ZR]) - (L.d[j] - lam));
-            if (j == 0 || g < best) { best = g; kt = j; }
-        }
-        double* x = L.Z + r * EIG_MAXN;
-        double xv = 1.0;
-        x[kt] = 1.0;
-        for (int j = kt - 1; j >= 0; j--) {
-            double qq = Dp[j * EIG_ZR];
-            if (fabs(qq) < pivmin) qq = -pivmin;
-            xv = -(L.e[j] / qq) * xv;
-            x[j] = xv;
-        }
-        xv = 1.0;
-        for (int j = kt; j < N - 1; j++) {
-            double qq = Dm[(j + 1) * EIG_ZR];
-            if (fabs(qq) < pivmin) qq = -pivmin;
-            xv = -(L.e[j] / qq) * xv;
-            x[j + 1] = xv;
-        }
-    }
-    __syncthreads();
-    // ---- scale, modified Gram-Schmidt, normalise (sequential over r; thread = element)
-    for (int r = 0; r < Rc; r++) {
-        double x = act ? L.Z[r * EIG_MAXN + i] : 0.0;
-        bool use_twisted = __syncthreads_and(isfinite(x)) != 0;
-        int uidx = 0;
-        for (;;) {
-            if (use_twisted) {
-                double n0 = sqrt(block_sum(x * x, L.part, tid));
-                x = x / n0;
-            } else {
-                if (uidx >= N) break;
-                x = (i == uidx) ? 1.0 : 0.0;
-                uidx++;
-            }
-            for (int pr = 0; pr < r; pr++) {
-                double pv = act ? L.Z[pr * EIG_MAXN + i] : 0.0;
-                double c = block_sum(pv * x, L.part, tid);
-                x = fma(-c, pv, x);
-            }
-            double n2 = block_sum(x * x, L.part, tid);
-            if (n2 > 1e-6 && n2 < 1e300) {
-                x = x / sqrt(n2);
-                break;
-            }
-            use_twisted = false;
-        }
-        if (act) L.Z[r * EIG_MAXN + i] = x;
-        __syncthreads();
-    }
-    // ---- back-transformation of all vectors at once, then sign / scaling / output
-    double xr[EIG_ZR];
-#pragma unroll
-    for (int r = 0; r < EIG_ZR; r++) xr[r] = (act && r < Rc) ? L.Z[r * EIG_MAXN + i] : 0.0;
-    for (int k = N - 3; k >= 0; k--) {
-        double tk = L.tau[k];
-        if (tk == 0.0) continue;
-        double v = (act && i > k) ? A[(long)k * N + i] : 0.0;
-        double pr[EIG_ZR];
-#pragma unroll
-        for (int r = 0; r < EIG_ZR; r++) pr[r] = wave_sum(v * xr[r]);
-        if (lane == 0) {
-#pragma unroll
-            for (int r = 0; r < EIG_ZR; r++) L.part[wave * EIG_ZR + r] = pr[r];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < EIG_ZR; r++) {
-            double sc = tk * (((L.part[r] + L.part[EIG_ZR + r]) + L.part[2 * EIG_ZR + r]) + L.part[3 * EIG_ZR + r]);
-            xr[r] = fma(-sc, v, xr[r]);
-        }
-        __syncthreads();
-    }
-    float* Vp = Vout + (long)blockIdx.x * N * R;
-    float* Wp = Wout + (long)blockIdx.x * N * R;
-    for (int r = 0; r < R; r++) {
-        double x = (r < EIG_ZR) ? xr[r < EIG_ZR ? r : 0] : 0.0;
-        double dot = block_sum((double)(i + 1) * x, L.part, tid);
-        float vo = 0.f, wo = 0.f;
-        if (r < Rc) {
-            double lam = L.lam[r];
-            double sr = sqrt(sqrt(lam > 1e-200 ? lam : 0.0));
-            int sg = sign ? (int)sign[(long)blockIdx.x * R + r] : 0;
-            double want = sg ? (double)sg : -1.0;
-            double flip = ((dot < 0.0 ? -1.0 : 1.0) == want) ? 1.0 : -1.0;
-            double ev = flip * x;
-            vo = (float)(ev * sr);
-            wo = (sr > 0.0) ? (float)(ev / sr) : 0.f;
-        }
-        if (act) { Vp[(long)i * R + r] = vo; Wp[(long)i * R + r] = wo; }
-    }
-}
-
-// ---- u = X @ w: k-ordered fma chain per element; grid (ceil(M*R/256), matrix) ----
-__global__ __launch_bounds__(256) void k_xw_n(const float* __restrict__ X, long x_stride, int M, int N, int R,
-                                              const float* __restrict__ Wn, float* __restrict__ Uf)
-{
-    long e = (long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (long)M * R) return;
-    int m = (int)(e / R), r = (int)(e - (long)m * R);
-    const float* x = X + (long)blockIdx.y * x_stride + (long)m * N;
-    const float* w = Wn + (long)blockIdx.y * N * R + r;
-    float acc = 0.f;
-    for (int k = 0; k < N; k++) acc = fmaf(x[k], w[(long)k * R], acc);
-    Uf[(long)blockIdx.y * M * R + e] = acc;
 }
 
 // ---- quantize(tensor, uint8): lrf/compression/utils.py:185-220.  One workgroup per tensor finds min / max ----

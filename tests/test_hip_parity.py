@@ -376,3 +376,20 @@ def test_ablation_bounds_at_full_size(bounds, oracle):
         assert np.array_equal(got[2 * c], u.astype(np.int8)) and np.array_equal(got[2 * c + 1], v.astype(np.int8)), f"plane {c}"
     enc = lrf_amd.qmf_encode(img, rank=7, bounds=bounds)
     assert lrf_amd.psnr(img.float(), lrf_amd.qmf_decode(enc).float()).item() > 15  # noisy image: 18.4 dB at rank 7
+
+
+def test_svd_baseline_rank_40_against_oracle(oracle):
+    """svd_encode beyond the reference's sweep (rank 40 of 192; the eigen-solver of the any-shape path has no 24-vector
+    cap): PSNR within 0.05 dB of the oracle's pipeline (Jacobi SVD, quantize, decode) and above the rank-5 result."""
+    import lrf_amd
+    from conftest import make_image
+    img = make_image(dict(kind="smooth", seed=31, H=96, W=128))
+    X = oracle.pad_patchify(img.numpy().astype(np.float32))
+    u, v = oracle.svd_topr(X, 40)
+    qu, su, mu = oracle.quantize_u8(u)
+    qv, sv, mv = oracle.quantize_u8(v)
+    want = oracle.svd_decode_rgb(qu, qv, (su, mu), (sv, mv), 96, 128)
+    p_want = lrf_amd.psnr(img, torch.from_numpy(want)).item()
+    p40 = lrf_amd.psnr(img, lrf_amd.svd_decode(lrf_amd.svd_encode(img, rank=40))).item()
+    p5 = lrf_amd.psnr(img, lrf_amd.svd_decode(lrf_amd.svd_encode(img, rank=5))).item()
+    assert abs(p40 - p_want) < 0.05 and p40 > p5 + 1.0

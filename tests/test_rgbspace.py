@@ -131,8 +131,25 @@ def test_hip_rgbspace_rejects_what_is_not_implemented():
     import lrf_amd
     img = torch.randint(0, 256, (3, 64, 96), dtype=torch.uint8)
     with pytest.raises(NotImplementedError):
-        lrf_amd.qmf_encode(img, color_space="RGB", rank=25)
+        lrf_amd.qmf_encode(img, color_space="RGB", rank=33)  # above the 32 columns the [M,192] kernels pad the rank to
     with pytest.raises(NotImplementedError):
         lrf_amd.qmf_encode(img, color_space="RGB", rank=4, num_iters=0)
     with pytest.raises(NotImplementedError):
         lrf_amd.qmf_encode(img, color_space="RGB", rank=4, patch=False)
+
+
+@pytest.mark.gpu
+def test_hip_bcd_rank_30_equals_oracle(oracle):
+    """ranks 25..32 of the RGB colour-space kernels (beyond the reference's sweep): BCD from given factors, bit for bit"""
+    from lrf_amd import _lib
+    rng = np.random.default_rng(30)
+    img = rng.integers(0, 256, (3, 72, 104), dtype=np.uint8)
+    X = oracle.pad_patchify(img.astype(np.float32))
+    R = 30
+    u0 = (rng.normal(size=(X.shape[0], R)) * 3).astype(np.float32)
+    v0 = (rng.normal(size=(192, R)) * 3).astype(np.float32)
+    ctx = _lib.context()
+    U, V = ctx.qmf_rgbspace_encode(torch.from_numpy(img).cuda().unsqueeze(0), R, 3, (-16, 15), None,
+                                   (torch.from_numpy(u0[None]), torch.from_numpy(v0[None])))
+    u, v = oracle.bcd(X, u0, v0, 3, (-16, 15))
+    assert np.array_equal(U[0].cpu().numpy(), u.astype(np.int8)) and np.array_equal(V[0].cpu().numpy(), v.astype(np.int8))
