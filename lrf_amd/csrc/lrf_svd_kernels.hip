@@ -48,13 +48,25 @@ __global__ __launch_bounds__(256) void k_gram_blk(const float* __restrict__ X, l
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[i] = (f64x4){0.0, 0.0, 0.0, 0.0};
     const int nsteps = (M + 3) >> 2;
-    for (int s = wave; s < nsteps; s += 4) {
-        int row = 4 * s + lq;
-        f32x4 xa = (f32x4){0.f, 0.f, 0.f, 0.f}, xb = xa;
-        if (row < M) {
+    auto load_step = [&](int s, f32x4& xa, f32x4& xb) __attribute__((always_inline)) {
+        const int row = 4 * s + lq;
+        xa = (f32x4){0.f, 0.f, 0.f, 0.f};
+        xb = xa;
+        if (s < nsteps && row < M) {
             xa = *reinterpret_cast<const f32x4*>(Xp + (long)row * N + 64 * cg + 4 * li);
             xb = *reinterpret_cast<const f32x4*>(Xp + (long)row * N + 64 * cgp + 4 * li);
         }
+    };
+    // two steps in flight: the loads of the next two steps are issued before the sixteen MFMAs of the current one (a step
+    // that waits for its own loads runs at a third of the fp64 MFMA rate)
+    f32x4 xa0, xb0, xa1, xb1;
+    load_step(wave, xa0, xb0);
+    load_step(wave + 4, xa1, xb1);
+    for (int s = wave; s < nsteps; s += 4) {
+        const f32x4 xa = xa0, xb = xb0;
+        xa0 = xa1;
+        xb0 = xb1;
+        load_step(s + 8, xa1, xb1);
 #pragma unroll
         for (int t = 0; t < 4; t++)
 #pragma unroll
