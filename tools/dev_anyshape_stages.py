@@ -14,7 +14,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     ctx.svd_init(X, R); torch.cuda.synchronize()
     print(f"{ctx.kernel_time(_lib.LRF_K_INIT)[0]:.2f}")
 else:
-    for shape in ((32, 512, 768, 102), (32, 1536, 256, 51), (32, 384, 1024, 77), (256, 512, 768, 102)):
+    shapes = ((32, 512, 768, 102), (32, 1536, 256, 51), (32, 384, 1024, 77), (256, 512, 768, 102))
+    if len(sys.argv) > 1:  # e.g. "256,6144,192,5"
+        shapes = (tuple(int(v) for v in sys.argv[1].split(",")),)
+    for shape in shapes:
         row = []
         for s in (1, 2, 3, 4, 0):
             env = dict(os.environ, LRF_DEBUG_INIT_SWEEPS=str(s))
