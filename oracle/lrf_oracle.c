@@ -21,7 +21,9 @@
  *   - MKL with a single output column (the Gauss-Seidel `uu @ bb` product of
  *     lrf/factorization/qmf.py:115 when it is large enough for MKL): for K <= 6 the
  *     tree (((fma(a1,b1,a0*b0) + p5) + p3) + (p2 + p4)) with absent terms dropped;
- *     K >= 7 is NOT pinned (pattern continued).                           (dot_mkl_n1)
+ *     the same pattern continued for K >= 7 (descending odd terms, ascending even ones)
+ *     reproduces the reference for every K up to 204 (tools/pin_oracle_anyshape.py:
+ *     ranks 1..205 on all patch sizes and on whole planes).               (dot_mkl_n1)
  * With more than one BLAS thread the reference itself changes the order of the long
  * X^T U reduction, so "the reference" is pinned at one thread.
  *
