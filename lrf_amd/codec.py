@@ -154,14 +154,21 @@ def _pack_pool(workers):
 
 
 def qmf_encode_batch(images: torch.Tensor, rank=None, quality=None, bounds=(-16, 15), num_iters: int = 10,
-                     init_sign=None, pack_workers: Optional[int] = None) -> list:
-    """Batched qmf_encode (default branch) -> list of byte streams, one per image.  The factorisation of the whole batch
-    runs on the GPU; the byte containers are packed by liblrf_pack.so on native host threads (`pack_workers` = 0: one per
-    hardware thread), or, with pack_workers="python", by the Python container code on a thread pool."""
+                     init_sign=None, pack_workers: Optional[int] = None, patch: bool = True, patch_size=(8, 8)) -> list:
+    """Batched qmf_encode (YCbCr branch) -> list of byte streams, one per image.  The factorisation of the whole batch
+    runs on the GPU; for the default 8x8 patches the byte containers are packed by liblrf_pack.so on native host threads
+    (`pack_workers` = 0: one per hardware thread), or, with pack_workers="python", by the Python container code on a
+    thread pool.  Other patch sizes and patch=False go through the any-shape kernels (container packed in Python)."""
     assert (rank, quality) != (None, None), "Either 'rank' or 'quality' must be specified."
     ctx = _lib.context(images.device.index if images.is_cuda else None)
     dev = images if images.is_cuda else images.cuda(ctx.device)
     H, W = images.shape[-2:]
+    if not patch or tuple(patch_size) != (8, 8):
+        if images.dtype != torch.uint8:
+            raise NotImplementedError("HIP path takes uint8 images")
+        lo, hi = math.ceil(bounds[0]), math.floor(bounds[1])
+        return _qmf_encode_anyshape(ctx, dev, rank, quality, bounds, (lo, hi), tuple(patch_size) if patch else None, num_iters,
+                                    init_sign, None)
     ranks = qmf_ranks((H, W), rank, quality)
     U, V = qmf_factorize_batch(dev, ranks, num_iters, bounds, init_sign)
     Uh, Vh = U.cpu().numpy(), V.cpu().numpy()
@@ -199,7 +206,7 @@ def qmf_encode(image: torch.Tensor, rank=None, quality=None, color_space: str = 
                                     kwargs.get("init"))
     if not patch or tuple(patch_size) != (8, 8):
         return _qmf_encode_anyshape(ctx, dev, rank, quality, bounds, (lo, hi), tuple(patch_size) if patch else None, num_iters,
-                                    init_sign, kwargs.get("init"))
+                                    init_sign, kwargs.get("init"))[0]
     ranks = qmf_ranks((H, W), rank, quality)
     if num_iters == 0:
         factors = _svd_init_factors(ctx, dev, ranks, init_sign)
@@ -233,22 +240,26 @@ def anyshape_ranks(image_hw, patch_size, rank=None, quality=None):
 
 def _qmf_encode_anyshape(ctx, dev, rank, quality, bounds, int_bounds, patch_size, num_iters, init_sign, init):
     """qmf_encode(color_space="YCbCr") with a patch size other than 8x8 (lrf/compression/qmf.py:232-262) or with
-    patch=False (patch_size None, :264-286): per plane one matrix [M, N], factorised on the any-shape kernels.
-    `init`: optional three (u0, v0) fp32 pairs replacing the SVD initialisation (tests)."""
+    patch=False (patch_size None, :264-286) for a batch dev [B,3,H,W]: per plane one matrix [M, N] per image, all images
+    of a plane factorised in one call of the any-shape kernels.  Returns one byte stream per image.
+    `init`: optional three (u0, v0) fp32 pairs ([M,R] / [N,R], or with a leading batch axis) replacing the SVD
+    initialisation (tests); `init_sign`: [R0+R1+R2] or [B, R0+R1+R2]."""
+    B = dev.shape[0]
     H, W = dev.shape[-2:]
     dims = _lib.plane_dims_any(H, W, patch_size)
     ranks = anyshape_ranks((H, W), patch_size, rank, quality)
-    factors, soff = [], 0
+    per_plane, soff = [], 0
     for c in range(3):
         X = ctx.planes_any(dev, patch_size, c)
         R = ranks[c]
         sign = None
         if init_sign is not None:
-            sign = torch.as_tensor(init_sign, dtype=torch.int8).reshape(-1)[soff:soff + R].reshape(1, R).contiguous().cuda(dev.device)
+            sg = torch.as_tensor(init_sign, dtype=torch.int8).reshape(-1, sum(ranks))[:, soff:soff + R]
+            sign = sg.expand(B, R).contiguous().cuda(dev.device)
         soff += R
         if init is not None:
-            u0 = torch.as_tensor(init[c][0], dtype=torch.float32).reshape(1, dims[c][4], R).cuda(dev.device)
-            v0 = torch.as_tensor(init[c][1], dtype=torch.float32).reshape(1, dims[c][5], R).cuda(dev.device)
+            u0 = torch.as_tensor(init[c][0], dtype=torch.float32).reshape(-1, dims[c][4], R).expand(B, -1, -1).contiguous().cuda(dev.device)
+            v0 = torch.as_tensor(init[c][1], dtype=torch.float32).reshape(-1, dims[c][5], R).expand(B, -1, -1).contiguous().cuda(dev.device)
             u, v = (u0.cpu().to(torch.int8), v0.cpu().to(torch.int8)) if num_iters == 0 else \
                 ctx.bcd(X, u0, v0, num_iters, int_bounds[0], int_bounds[1])
         elif num_iters == 0:  # the float factors go straight through torch's truncating cast (qmf.py:258-260)
@@ -256,10 +267,15 @@ def _qmf_encode_anyshape(ctx, dev, rank, quality, bounds, int_bounds, patch_size
             u, v = u0.cpu().to(torch.int8), v0.cpu().to(torch.int8)
         else:
             u, v = ctx.decompose(X, R, num_iters, int_bounds[0], int_bounds[1], sign)
-        u, v = u.cpu().numpy(), v.cpu().numpy()  # [1, M, R], [1, N, R]
-        # patch=False keeps the plane's channel axis: the factors are 3-D there (qmf.py:281-282), 2-D with patches
-        factors += [u, v] if patch_size is None else [u[0], v[0]]
-    return pack_anyshape(factors, (H, W), ranks, bounds, patch_size, str(dev.dtype).split(".")[-1])
+        per_plane.append((u.cpu().numpy(), v.cpu().numpy()))  # [B, M, R], [B, N, R]
+    streams = []
+    for b in range(B):
+        factors = []
+        for u, v in per_plane:
+            # patch=False keeps the plane's channel axis: the factors are 3-D there (qmf.py:281-282), 2-D with patches
+            factors += [u[b:b + 1], v[b:b + 1]] if patch_size is None else [u[b], v[b]]
+        streams.append(pack_anyshape(factors, (H, W), ranks, bounds, patch_size, str(dev.dtype).split(".")[-1]))
+    return streams
 
 
 def pack_anyshape(factors, image_hw, ranks, bounds, patch_size, dtype_name="uint8") -> bytes:

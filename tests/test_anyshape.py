@@ -280,3 +280,14 @@ def test_hip_edge_planes():
         dec = lrf_amd.qmf_decode(lrf_amd.qmf_encode(img, **kw))
         mse = float(((img.float() - dec.float()) ** 2).mean())
         assert mse <= 1.5 * ref_mse + 0.5, (kw, mse, ref_mse)
+
+
+@pytest.mark.gpu
+def test_hip_batch_encode_equals_single_calls():
+    """qmf_encode_batch with a patch size / patch=False: the streams of the images encoded one by one"""
+    import lrf_amd
+    g = torch.Generator().manual_seed(41)
+    imgs = torch.randint(0, 256, (3, 3, 72, 104), dtype=torch.uint8, generator=g)
+    for kw in (dict(patch_size=(16, 16)), dict(patch=False), dict(patch_size=(4, 4))):
+        got = lrf_amd.qmf_encode_batch(imgs, quality=12, **kw)
+        assert got == [lrf_amd.qmf_encode(im, quality=12, **kw) for im in imgs]
