@@ -34,25 +34,29 @@ __global__ __launch_bounds__(256) void k_any_prod(const float* __restrict__ A, l
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) acc[j] = 0.f;
+    // staging width along k: the next power of two >= the contraction (64 at most), so that a short contraction (N = 16 for
+    // 4x4 patches) does not walk 64-wide tiles of mostly absent entries
+    int kw = 64, kws = 6;
+    while (kw > 1 && (kw >> 1) >= D) { kw >>= 1; kws--; }
     for (int k0 = kbeg; k0 < kend; k0 += 64) {
         const int klen = (kend - k0 < 64) ? kend - k0 : 64;
         __syncthreads();
         if (sak == 1) { // rows of A contiguous along k
-            for (int e = tid; e < 64 * 64; e += 256) {
-                const int kk = e & 63, ii = e >> 6;
+            for (int e = tid; e < 64 * kw; e += 256) {
+                const int kk = e & (kw - 1), ii = e >> kws;
                 float v = 0.f;
                 if (kk < klen && i0 + ii < I) v = Ab[(long)(i0 + ii) * sai + (k0 + kk)];
                 As[kk * 65 + ii] = v;
             }
         } else { // contiguous along i (transposed views)
-            for (int e = tid; e < 64 * 64; e += 256) {
+            for (int e = tid; e < 64 * kw; e += 256) {
                 const int ii = e & 63, kk = e >> 6;
                 float v = 0.f;
                 if (kk < klen && i0 + ii < I) v = Ab[(long)(i0 + ii) * sai + (long)(k0 + kk) * sak];
                 As[kk * 65 + ii] = v;
             }
         }
-        for (int e = tid; e < 64 * 32; e += 256) {
+        for (int e = tid; e < kw * 32; e += 256) {
             const int rr = e & 31, kk = e >> 5;
             float v = 0.f;
             if (kk < klen && r0 + rr < R) v = Bb[(long)(k0 + kk) * R + r0 + rr];
