@@ -178,8 +178,8 @@ int lrf_svd_decode_rgb_u8(lrf_ctx* ctx, const uint8_t* U, const uint8_t* V, int6
  * the host, QMF(rank=R, bounds, factor=(0,1)).decompose, int8 factors U [B,M,R], V [B,192,R] (device memory).
  *   U0 [B,M,R] / V0 [B,192,R] fp32 (device), both or neither: the initial factors (lrf/factorization/qmf.py:42-71);
  *   NULL = this library's SVD initialisation (sign optional [B,R] as in lrf_qmf_decompose_f32).
- * Ranks up to 32 (the reference's colour-space ablation sweeps quality 0..10 -> R <= 19), K >= 1.
- * Not tuned (correctness-first kernels, lrf_qmfn_kernels.hip).
+ * Ranks up to 192 (the reference's colour-space ablation sweeps quality 0..10 -> R <= 19), K >= 1.
+ * The factorisation runs on the any-shape kernels (lrf_anyshape_kernels.hip).
  */
 int lrf_qmf_rgbspace_encode_u8(lrf_ctx* ctx, const uint8_t* rgb, int64_t B, int64_t H, int64_t W, int R, int K, int lo, int hi,
                                const int8_t* sign, const float* U0, const float* V0, int8_t* U, int8_t* V);

@@ -774,85 +774,15 @@ int lrf_svd_decode_rgb_u8(lrf_ctx* c, const uint8_t* U, const uint8_t* V, int64_
 }
 
 /* ---- QMF, RGB colour-space branch (qmf_encode(color_space="RGB", patch=True): qmf.py:164-187; decode :311-323) ---- */
-static int rgbspace_tables(lrf_ctx* c, int64_t B, int M, int R, Tables& t)
-{
-    const int N = 192;
-    for (int64_t b = 0; b < B; b++) {
-        add_plane(t, b * (long)M * N, b * (long)M * R, b * (long)N * R, b * (long)M * R, b * (long)N * R, M, R, -1);
-        t.planes.back().native_t2_u = ((long)(R - 1) * M < 400) ? 1 : 0;
-    }
-    // descriptor upload, cached like upload_tables (the key carries a tag so that it never matches a 64-column table)
-    size_t pb = t.planes.size() * sizeof(PlaneDesc), bb = t.blocks.size() * sizeof(BlockDesc);
-    std::vector<char> key(pb + bb + 1);
-    memcpy(key.data(), t.planes.data(), pb);
-    memcpy(key.data() + pb, t.blocks.data(), bb);
-    key[pb + bb] = (char)N;
-    int rc;
-    if (key != c->table_key) {
-        c->table_key.clear();
-        if ((rc = upload(c, c->planes, t.planes.data(), pb))) return rc;
-        if ((rc = upload(c, c->blocks, t.blocks.data(), bb))) return rc;
-        c->table_key.swap(key);
-    }
-    size_t np = t.planes.size(), nb = t.blocks.size();
-    if ((rc = ensure(c, c->vf, np * N * LRF_RPN * sizeof(float)))) return rc;
-    if ((rc = ensure(c, c->bf, np * LRF_GTN_STRIDE * sizeof(float)))) return rc;
-    if ((rc = ensure(c, c->ppart, nb * N * LRF_RPN * sizeof(float)))) return rc;
-    if ((rc = ensure(c, c->qpart, nb * LRF_RPN * LRF_RPN * sizeof(float)))) return rc;
-    return LRF_OK;
-}
-
 static int rgbspace_check(int64_t B, int64_t H, int64_t W, int R, int K, int lo, int hi, int M)
 {
     if (B < 1 || B > 65535) return set_err(LRF_EINVAL, "B=%ld out of range [1,65535]", (long)B);
     if (R < 1) return set_err(LRF_EINVAL, "rank must be >= 1 (got %d)", R);
-    if (R > LRF_RPN) return set_err(LRF_ENOTSUP, "RGB colour space: rank %d > %d not implemented", R, LRF_RPN);
+    if (R > 192) return set_err(LRF_ENOTSUP, "RGB colour space: rank %d > 192 columns not implemented", R);
     if (K < 1) return set_err(LRF_ENOTSUP, "RGB colour space: num_iters=%d not implemented (K >= 1)", K);
     if (lo > hi || lo < -128 || hi > 127) return set_err(LRF_EINVAL, "bounds (%d,%d) outside int8", lo, hi);
     (void)M; // u.mT @ u stays the reference's for any int8 bounds: see check_params
     (void)H; (void)W;
-    return LRF_OK;
-}
-
-// K BCD iterations on X [B][M][192] from fp32 (U0 [B][M][R], V0 [B][192][R]) on the device
-static int run_bcdn(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, int hi, const float* U0, const float* V0,
-                    int8_t* U, int8_t* V)
-{
-    constexpr int N = 192;
-    if (!(c->attr_done & (1u << 4))) {
-        HIP_TRY(hipFuncSetAttribute((const void*)k_bcdn<N, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BcdnLds<N>)));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_bcdn<N, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BcdnLds<N>)));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_vupdaten<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(VupdnLds<N>)));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_bprepn<N>, hipFuncAttributeMaxDynamicSharedMemorySize, N * LRF_RPN * (int)sizeof(float)));
-        c->attr_done |= 1u << 4;
-    }
-    const PlaneDesc* pl = (const PlaneDesc*)c->planes.p;
-    const BlockDesc* bl = (const BlockDesc*)c->blocks.p;
-    float* vf = (float*)c->vf.p;
-    float* bf = (float*)c->bf.p;
-    float* pp = (float*)c->ppart.p;
-    float* qp = (float*)c->qpart.p;
-    const int nb = (int)t.blocks.size(), np = (int)t.planes.size();
-    hipLaunchKernelGGL((k_bprepn<N>), dim3(np), dim3(256), N * LRF_RPN * sizeof(float), c->stream, pl, V0, vf, bf);
-    LAUNCH_CHECK();
-    for (int it = 0; it < K; it++) {
-        {
-            Prof p(c, LRF_K_BCD);
-            if (it == 0)
-                hipLaunchKernelGGL((k_bcdn<N, 2>), dim3(nb), dim3(256), sizeof(BcdnLds<N>), c->stream, X, pl, bl, (const float*)vf,
-                                   (const float*)bf, U0, U, pp, qp, (float)lo, (float)hi);
-            else
-                hipLaunchKernelGGL((k_bcdn<N, 0>), dim3(nb), dim3(256), sizeof(BcdnLds<N>), c->stream, X, pl, bl, (const float*)vf,
-                                   (const float*)bf, U0, U, pp, qp, (float)lo, (float)hi);
-            LAUNCH_CHECK();
-        }
-        {
-            Prof p(c, LRF_K_VUPDATE);
-            hipLaunchKernelGGL((k_vupdaten<N>), dim3(np), dim3(256), sizeof(VupdnLds<N>), c->stream, pl, (const float*)pp,
-                               (const float*)qp, vf, bf, V, (float)lo, (float)hi, it == K - 1 ? 1 : 0);
-            LAUNCH_CHECK();
-        }
-    }
     return LRF_OK;
 }
 
@@ -869,32 +799,30 @@ int lrf_qmf_rgbspace_encode_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_
     const long xs = (long)M * N;
     if ((rc = ensure(c, c->sx, (size_t)B * xs * sizeof(float)))) return rc;
     float* X = (float*)c->sx.p;
-    Tables t;
-    if ((rc = rgbspace_tables(c, B, M, R, t))) return rc;
     {
         Prof p(c, LRF_K_PLANES);
         hipLaunchKernelGGL(k_patchify_rgb, dim3(hp / 8, (unsigned)B), dim3(256), 0, c->stream, rgb, (int)H, (int)W, top, left, nw, xs, X);
         LAUNCH_CHECK();
     }
-    const float* u0 = U0;
-    const float* v0 = V0;
-    if (!U0) { // SVD initialisation: u0 = U sqrt(s), v0 = V sqrt(s) (qmf.py:42-71) by the general-N eigen-solver of the SVD baseline
+    // The factorisation itself runs on the any-shape kernels (lrf_anyshape_kernels.hip): measured against a dedicated
+    // [M,192] kernel set with plain VALU chains they took half the time, so that set is gone.
+    if ((rc = any_workspace(c, (int)B, M, N, R))) return rc;
+    float* Uf = (float*)c->any_uf.p;
+    float* Vf = (float*)c->any_vf.p;
+    if (U0) {
+        HIP_TRY(hipMemcpyAsync(Uf, U0, (size_t)B * M * R * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(Vf, V0, (size_t)B * N * R * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    } else { // SVD initialisation: u0 = U sqrt(s), v0 = V sqrt(s) (qmf.py:42-71): fp64 MFMA Gram, then the any-shape eigen-solver
         if ((rc = ensure(c, c->sg, (size_t)B * N * N * sizeof(double)))) return rc;
-        if ((rc = ensure(c, c->svn, (size_t)B * N * R * sizeof(float)))) return rc;
         if ((rc = ensure(c, c->swn, (size_t)B * N * R * sizeof(float)))) return rc;
-        if ((rc = ensure(c, c->suf, (size_t)B * M * R * sizeof(float)))) return rc;
         double* G = (double*)c->sg.p;
-        float* Vn = (float*)c->svn.p;
         float* Wn = (float*)c->swn.p;
-        float* Uf = (float*)c->suf.p;
         Prof p(c, LRF_K_INIT);
         hipLaunchKernelGGL(k_gram_blk, dim3(nc * (nc + 1) / 2, (unsigned)B), dim3(256), 0, c->stream, (const float*)X, xs, M, N, nc, G);
         LAUNCH_CHECK();
-        if ((rc = any_factors_from_gram(c, X, G, (int)B, M, N, R, sign, Vn, Wn, Uf))) return rc;
-        u0 = Uf;
-        v0 = Vn;
+        if ((rc = any_factors_from_gram(c, X, G, (int)B, M, N, R, sign, Vf, Wn, Uf))) return rc;
     }
-    return run_bcdn(c, X, t, K, lo, hi, u0, v0, U, V);
+    return any_run_bcd(c, X, (int)B, M, N, R, K, lo, hi, U, V);
 }
 
 int lrf_qmf_rgbspace_decode_u8(lrf_ctx* c, const int8_t* U, const int8_t* V, int64_t B, int64_t H, int64_t W, int R, uint8_t* rgb)

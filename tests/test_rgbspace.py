@@ -131,7 +131,7 @@ def test_hip_rgbspace_rejects_what_is_not_implemented():
     import lrf_amd
     img = torch.randint(0, 256, (3, 64, 96), dtype=torch.uint8)
     with pytest.raises(NotImplementedError):
-        lrf_amd.qmf_encode(img, color_space="RGB", rank=33)  # above the 32 columns the [M,192] kernels pad the rank to
+        lrf_amd.qmf_encode(img, color_space="RGB", rank=193)  # more columns than the matrix has
     with pytest.raises(NotImplementedError):
         lrf_amd.qmf_encode(img, color_space="RGB", rank=4, num_iters=0)
     with pytest.raises(NotImplementedError):

@@ -22,4 +22,4 @@ ctx.profile(False)
 k = {nm: round(ctx.kernel_time(i)[0] / n, 3) for i, nm in _lib.KERNEL_NAMES.items() if ctx.kernel_time(i)[1]}
 x_bytes = B * 6144 * 192 * 4
 print(f"B={B} R={R}: {dt*1e3:.2f} ms per batch, {B*512*768/dt/1e6:.0f} Mpix/s; ms per batch by class {k}; "
-      f"X = {x_bytes/1e6:.0f} MB read per BCD iteration -> {x_bytes/ (k.get('k_bcd',1e9)/10*1e-3)/1e9:.0f} GB/s in k_bcdn")
+      f"X = {x_bytes/1e6:.0f} MB read per BCD iteration -> {x_bytes/ (k.get('k_bcd',1e9)/10*1e-3)/1e9:.0f} GB/s in the BCD kernels")
