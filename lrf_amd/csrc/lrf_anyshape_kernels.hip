@@ -176,10 +176,11 @@ __global__ __launch_bounds__(64) void k_any_gs(const float* __restrict__ a, cons
     }
 }
 
-__global__ __launch_bounds__(256) void k_any_to_i8(const float* __restrict__ F, int8_t* __restrict__ O, long n)
+// fp32 factors [B][per] -> int8, matrix b at O + b * o_batch (the fused encode interleaves the planes of an image)
+__global__ __launch_bounds__(256) void k_any_to_i8(const float* __restrict__ F, int8_t* __restrict__ O, long per, long o_batch)
 {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    if (e < n) O[e] = (int8_t)F[e];
+    if (e < per) O[(long)blockIdx.y * o_batch + e] = (int8_t)F[(long)blockIdx.y * per + e];
 }
 
 // ---- initialisation -------------------------------------------------------------------------------------------

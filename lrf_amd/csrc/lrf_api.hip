@@ -581,11 +581,44 @@ static void uniform_tables(Tables& t, int64_t B, int64_t M, int R, bool with_sig
         add_plane(t, b * M * 64, b * M * R, b * 64 * R, b * M * R, b * 64 * R, (int)M, R, with_sign ? (int)(b * R) : -1);
 }
 
+// Ranks 33..64 of the 64-column path: k_bcd_big solves them with the ordered Gauss-Seidel chain on one wave of four and is
+// 2x slower there than the any-shape kernels, which spread the same chain over all waves (tools/dev_big_vs_any.py: ranks
+// (40,20): 20.8 against 11.4 ms per 64 images, (64,32): 45.6 against 20.6).  The initialisation stays with k_init, which mirrors
+// the oracle operation for operation: k_emit_init writes its factors out as fp32 and the any-shape iteration takes over.
+#define LRF_BIG_TO_ANY_RANK 32
+
+// one class of B equal-shaped 64-column matrices whose initial factors sit contiguously at U0c / V0c
+static int any_bcd_from_init(lrf_ctx* c, const float* X, long x_batch, int B, int M, int R, int K, int lo, int hi, const float* U0c,
+                             const float* V0c, int8_t* U, long u_batch, int8_t* V, long v_batch)
+{
+    int rc = any_workspace(c, B, M, 64, R);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(c->any_uf.p, U0c, (size_t)B * M * R * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->any_vf.p, V0c, (size_t)B * 64 * R * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    return any_run_bcd_ex(c, X, x_batch, B, M, 64, R, K, lo, hi, U, u_batch, V, v_batch);
+}
+
+// k_init on the uploaded table, then its factors as fp32 into c->any_e2 (U0 at [0], V0 behind it): offsets from the table
+static int init_to_fp32(lrf_ctx* c, const float* X, const Tables& t, const int8_t* sign, size_t u0_floats, size_t v0_floats, float** U0,
+                        float** V0)
+{
+    int rc = run_init(c, X, t, sign);
+    if (rc) return rc;
+    if ((rc = ensure(c, c->any_e2, (u0_floats + v0_floats) * sizeof(float)))) return rc;
+    *U0 = (float*)c->any_e2.p;
+    *V0 = *U0 + u0_floats;
+    hipLaunchKernelGGL(k_emit_init, dim3((unsigned)t.blocks.size()), dim3(256), 0, c->stream, X, (const PlaneDesc*)c->planes.p,
+                       (const BlockDesc*)c->blocks.p, (const float*)c->vf.p, (const float*)c->wf.p, *U0, *V0, table_rp(t));
+    LAUNCH_CHECK();
+    return LRF_OK;
+}
+
 int lrf_qmf_decompose_f32(lrf_ctx* c, const float* X, int64_t B, int64_t M, int64_t N, int R, int K, int lo, int hi,
                           const int8_t* sign, int8_t* U, int8_t* V)
 {
     if (!c || !X || !U || !V) return set_err(LRF_EINVAL, "NULL argument");
-    if (N != LRF_PATCH_ELEMS || R > LRF_MAX_RANK) return any_decompose(c, X, B, M, N, R, K, lo, hi, sign, U, V);
+    static const bool force_any = getenv("LRF_FORCE_ANY") && getenv("LRF_FORCE_ANY")[0] == '1'; // developer comparison aid
+    if (N != LRF_PATCH_ELEMS || R > LRF_MAX_RANK || force_any) return any_decompose(c, X, B, M, N, R, K, lo, hi, sign, U, V);
     int rc = check_params(M, N, R, K, lo, hi);
     if (rc) return rc;
     if (B < 1) return set_err(LRF_EINVAL, "B must be >= 1");
@@ -593,6 +626,11 @@ int lrf_qmf_decompose_f32(lrf_ctx* c, const float* X, int64_t B, int64_t M, int6
     Tables t;
     uniform_tables(t, B, M, R, sign != nullptr);
     if ((rc = upload_tables(c, t))) return rc;
+    if (R > LRF_BIG_TO_ANY_RANK) {
+        float *U0, *V0;
+        if ((rc = init_to_fp32(c, X, t, sign, (size_t)B * M * R, (size_t)B * 64 * R, &U0, &V0))) return rc;
+        return any_bcd_from_init(c, X, M * 64, (int)B, (int)M, R, K, lo, hi, U0, V0, U, M * R, V, 64L * R);
+    }
     if ((rc = run_init(c, X, t, sign))) return rc;
     return run_bcd(c, X, t, K, lo, hi, 1, nullptr, U, V);
 }
@@ -601,7 +639,7 @@ int lrf_qmf_bcd_f32(lrf_ctx* c, const float* X, int64_t B, int64_t M, int64_t N,
                     const float* U0, const float* V0, int8_t* U, int8_t* V)
 {
     if (!c || !X || !U || !V || !U0 || !V0) return set_err(LRF_EINVAL, "NULL argument");
-    if (N != LRF_PATCH_ELEMS || R > LRF_MAX_RANK) return any_bcd(c, X, B, M, N, R, K, lo, hi, U0, V0, U, V);
+    if (N != LRF_PATCH_ELEMS || R > LRF_BIG_TO_ANY_RANK) return any_bcd(c, X, B, M, N, R, K, lo, hi, U0, V0, U, V);
     int rc = check_params(M, N, R, K, lo, hi);
     if (rc) return rc;
     if (B < 1) return set_err(LRF_EINVAL, "B must be >= 1");
@@ -656,12 +694,28 @@ int lrf_qmf_encode_rgb_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_t H, 
         u_img += (long)g.p[ch].M * R[ch];
         v_img += 64L * R[ch];
     }
+    // fp32 initial factors, if they are wanted (ranks above LRF_BIG_TO_ANY_RANK): per plane class contiguous [B][M][R] / [B][64][R]
+    long u0c[4] = {0, 0, 0, 0}, v0c[4] = {0, 0, 0, 0};
+    for (int ch = 0; ch < 3; ch++) {
+        u0c[ch + 1] = u0c[ch] + B * (long)g.p[ch].M * R[ch];
+        v0c[ch + 1] = v0c[ch] + B * 64L * R[ch];
+    }
     Tables t;
     for (int ch = 0; ch < 3; ch++)
         for (int64_t b = 0; b < B; b++)
-            add_plane(t, b * g.img_floats + g.p[ch].xoff, b * u_img + uoff[ch], b * v_img + voff[ch], 0, 0, g.p[ch].M, R[ch],
+            add_plane(t, b * g.img_floats + g.p[ch].xoff, b * u_img + uoff[ch], b * v_img + voff[ch],
+                      u0c[ch] + b * (long)g.p[ch].M * R[ch], v0c[ch] + b * 64L * R[ch], g.p[ch].M, R[ch],
                       sign ? (int)(b * s_img + soff[ch]) : -1);
     if ((rc = upload_tables(c, t))) return rc;
+    if (table_rmax(t) > LRF_BIG_TO_ANY_RANK) {
+        float *U0, *V0;
+        if ((rc = init_to_fp32(c, X, t, sign, (size_t)u0c[3], (size_t)v0c[3], &U0, &V0))) return rc;
+        for (int ch = 0; ch < 3; ch++)
+            if ((rc = any_bcd_from_init(c, X + g.p[ch].xoff, g.img_floats, (int)B, g.p[ch].M, R[ch], K, lo, hi, U0 + u0c[ch],
+                                        V0 + v0c[ch], U + uoff[ch], u_img, V + voff[ch], v_img)))
+                return rc;
+        return LRF_OK;
+    }
     if ((rc = run_init(c, X, t, sign))) return rc;
     return run_bcd(c, X, t, K, lo, hi, 1, nullptr, U, V);
 }

@@ -393,3 +393,21 @@ def test_svd_baseline_rank_40_against_oracle(oracle):
     p40 = lrf_amd.psnr(img, lrf_amd.svd_decode(lrf_amd.svd_encode(img, rank=40))).item()
     p5 = lrf_amd.psnr(img, lrf_amd.svd_decode(lrf_amd.svd_encode(img, rank=5))).item()
     assert abs(p40 - p_want) < 0.05 and p40 > p5 + 1.0
+
+
+def test_ranks_above_32_equal_oracle(oracle):
+    """Ranks 33..64 of the 64-column path: k_init's factors handed to the any-shape iteration (lrf_api.hip
+    LRF_BIG_TO_ANY_RANK), mixed with planes below the switch — bit for bit against the oracle, ragged blocks, two images."""
+    import lrf_amd
+    from lrf_amd.codec import split_factors
+    g = torch.Generator().manual_seed(5)
+    H, W = 173, 264
+    img = torch.randint(0, 256, (2, 3, H, W), dtype=torch.uint8, generator=g)
+    for ranks in ((40, 20, 20), (64, 32, 33), (33, 5, 48)):
+        U, V = lrf_amd.qmf_factorize_batch(img.cuda(), ranks, num_iters=3)
+        for b in range(2):
+            X = oracle.rgb_to_planes(img[b].numpy())
+            got = split_factors(U[b].cpu().numpy(), V[b].cpu().numpy(), (H, W), ranks)
+            for c in range(3):
+                u, v = oracle.qmf_decompose(X[c], ranks[c], 3, (-16, 15))
+                assert np.array_equal(got[2 * c], u.astype(np.int8)) and np.array_equal(got[2 * c + 1], v.astype(np.int8)), (ranks, b, c)
