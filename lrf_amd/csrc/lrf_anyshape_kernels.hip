@@ -17,7 +17,8 @@
 
 // ---- batched products with the reference's summation order ------------------------------------------------------
 // P[b][blk][i][r] = chain over k in block blk of A(i,k) * Bm[k][r];  A(i,k) = A[b*a_batch + i*sai + k*sak].
-// grid (ceil(I/64), ceil(R/32) * nblk, B); each thread keeps 8 rows x 1 column.
+// grid (ceil(I/64), ceil(R/32) * nblk, B).  MKL order: f32 MFMA tiles (a k-ordered fma chain per element); ATen's native
+// order (tiny products): scalar loop, each thread 8 rows x 1 column.
 __global__ __launch_bounds__(256) void k_any_prod(const float* __restrict__ A, long a_batch, long sai, long sak,
                                                   const float* __restrict__ Bm, long b_batch, float* __restrict__ P,
                                                   int I, int D, int R, int nblk, int native)
@@ -25,9 +26,12 @@ __global__ __launch_bounds__(256) void k_any_prod(const float* __restrict__ A, l
     __shared__ float As[64 * 65];
     __shared__ float Bs[64 * 32];
     const int tid = threadIdx.x, tr = tid & 31, ti = tid >> 5;
+    const int lane = tid & 63, li = lane & 15, lq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rt = blockIdx.y / nblk, blk = blockIdx.y - rt * nblk;
     const int i0 = blockIdx.x * 64, r0 = rt * 32;
     const float* Ab = A + (long)blockIdx.z * a_batch;
+    f32x4 macc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     const float* Bb = Bm + (long)blockIdx.z * b_batch;
     const int kbeg = blk * LRF_KC;
     const int kend = (kbeg + LRF_KC < D) ? kbeg + LRF_KC : D;
@@ -37,7 +41,7 @@ __global__ __launch_bounds__(256) void k_any_prod(const float* __restrict__ A, l
     // staging width along k: the next power of two >= the contraction (64 at most), so that a short contraction (N = 16 for
     // 4x4 patches) does not walk 64-wide tiles of mostly absent entries
     int kw = 64, kws = 6;
-    while (kw > 1 && (kw >> 1) >= D) { kw >>= 1; kws--; }
+    while (kw > 4 && (kw >> 1) >= D) { kw >>= 1; kws--; } // at least 4: one MFMA step reads four k
     for (int k0 = kbeg; k0 < kend; k0 += 64) {
         const int klen = (kend - k0 < 64) ? kend - k0 : 64;
         __syncthreads();
@@ -73,19 +77,35 @@ __global__ __launch_bounds__(256) void k_any_prod(const float* __restrict__ A, l
                 }
             }
         } else {
-            for (int kk = 0; kk < klen; kk++) {
-                const float b = Bs[kk * 32 + tr];
-#pragma unroll
-                for (int j = 0; j < 8; j++) acc[j] = fmaf(As[kk * 65 + ti + 8 * j], b, acc[j]);
+            // wave w: rows 16w .. 16w+15 of the tile, both 16-wide column tiles.  v_mfma_f32_16x16x4_f32 adds its four
+            // products to the accumulator one after the other in k order — the same chain of fmas as the scalar loop — and
+            // entries past klen are zeros staged above (fma(0, 0, acc) = acc).
+            const int steps = (klen + 3) >> 2;
+            for (int s4 = 0; s4 < steps; s4++) {
+                const float av = As[(4 * s4 + lq) * 65 + 16 * wave + li];
+                macc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Bs[(4 * s4 + lq) * 32 + li], macc[0], 0, 0, 0);
+                macc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Bs[(4 * s4 + lq) * 32 + 16 + li], macc[1], 0, 0, 0);
             }
         }
     }
-    if (r0 + tr < R) {
-        float* Pp = P + (((long)blockIdx.z * nblk + blk) * I) * R + r0 + tr;
+    float* Pb = P + (((long)blockIdx.z * nblk + blk) * I) * R;
+    if (native) {
+        if (r0 + tr < R) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int i = i0 + ti + 8 * j;
-            if (i < I) Pp[(long)i * R] = acc[j];
+            for (int j = 0; j < 8; j++) {
+                const int i = i0 + ti + 8 * j;
+                if (i < I) Pb[(long)i * R + r0 + tr] = acc[j];
+            }
+        }
+    } else { // C/D layout of the 16x16 tile: column = lane & 15, rows 4 (lane >> 4) + reg
+#pragma unroll
+        for (int ct = 0; ct < 2; ct++) {
+            const int r = r0 + 16 * ct + li;
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int i = i0 + 16 * wave + 4 * lq + reg;
+                if (i < I && r < R) Pb[(long)i * R + r] = macc[ct][reg];
+            }
         }
     }
 }
