@@ -209,6 +209,44 @@ int lrf_qmf_planes_any_u8(lrf_ctx* ctx, const uint8_t* rgb, int64_t B, int64_t H
 int lrf_qmf_decode_any_u8(lrf_ctx* ctx, const int8_t* U0, const int8_t* V0, const int8_t* U1, const int8_t* V1, const int8_t* U2,
                           const int8_t* V2, int64_t B, int64_t H, int64_t W, int p, int q, const int R[3], uint8_t* rgb);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Host -> host pipelined encoder.  This is the protocol a caller of the reference experiences — a host tensor goes in,
+ * the encoded factors come back on the host (lrf/utils/misc.py:90-100 times exactly that around `encoder(image)`;
+ * experiments/comparison/eval.py:105-110 loops it over a dataset) — and the metric SURVEY.md section 8(d) defines.
+ * A pipe owns `slots` encoder contexts (stream + scratch + device staging each).  A batch is cut into sub-batches of
+ * `sub_batch` images (0 = chosen by the library: ~48 MB of input); sub-batch i runs on slot i % slots as
+ *     H2D(rgb) -> lrf_qmf_encode_rgb_u8 -> D2H(U, V)
+ * on that slot's stream, so uploads, kernels and downloads of different sub-batches overlap.
+ *   rgb_host [B,3,H,W] uint8, U_host / V_host as lrf_qmf_encode_rgb_u8 lays them out, sign_host optional
+ *   [B, R[0]+R[1]+R[2]] int8: HOST pointers.  Page-locked memory (lrf_host_alloc, lrf_host_register, or torch's
+ *   pin_memory) is what lets the copies run asynchronously at link speed; pageable memory works, slowly.
+ * The results equal lrf_qmf_encode_rgb_u8's on the same images bit for bit (images are independent).
+ * A pipe is not thread-safe: one per (host thread, device), which is also the multi-GPU model (one process per GPU).
+ */
+typedef struct lrf_pipe lrf_pipe;
+int lrf_pipe_create(int device, int slots /* 1..8 */, int64_t sub_batch /* images, 0 = auto */, lrf_pipe** out);
+void lrf_pipe_destroy(lrf_pipe* pipe);
+int lrf_pipe_slots(const lrf_pipe* pipe);
+/* the encoder context of one slot (owned by the pipe): for lrf_ctx_profile* / lrf_ctx_kernel_time */
+lrf_ctx* lrf_pipe_slot_ctx(lrf_pipe* pipe, int slot);
+size_t lrf_pipe_workspace_bytes(const lrf_pipe* pipe);
+/* whole batch, returns when every factor is in U_host / V_host */
+int lrf_pipe_qmf_encode_rgb_u8_host(lrf_pipe* pipe, const uint8_t* rgb_host, int64_t B, int64_t H, int64_t W, const int R[3],
+                                    int K, int lo, int hi, const int8_t* sign_host, int8_t* U_host, int8_t* V_host);
+/* the same in two steps, so that the host can pack the container of finished sub-batches (lrf/compression/utils.py:354-455)
+ * while the GPU works on the next ones: submit enqueues everything and returns the number of sub-batches; each
+ * lrf_pipe_wait_next blocks until the next sub-batch (in order) is on the host and reports its image range
+ * (n_images = 0: nothing left).  The host buffers must stay valid until the last wait returns. */
+int lrf_pipe_qmf_encode_submit(lrf_pipe* pipe, const uint8_t* rgb_host, int64_t B, int64_t H, int64_t W, const int R[3], int K,
+                               int lo, int hi, const int8_t* sign_host, int8_t* U_host, int8_t* V_host, int* n_sub);
+int lrf_pipe_wait_next(lrf_pipe* pipe, int64_t* first_image, int64_t* n_images);
+
+/* page-locked host memory for the pipe's callers (hosts without a GPU runtime of their own) */
+int lrf_host_alloc(size_t bytes, void** out_host);
+int lrf_host_free(void* host);
+int lrf_host_register(void* host, size_t bytes);   /* page-locks memory the caller already owns */
+int lrf_host_unregister(void* host);
+
 #ifdef __cplusplus
 }
 #endif

@@ -71,6 +71,23 @@ def load():
         lib.lrf_qmf_planes_any_u8.argtypes = [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_void_p]
         lib.lrf_qmf_decode_any_u8.argtypes = [c_void_p] + [c_void_p] * 6 + [c_i64, c_i64, c_i64, c_int, c_int,
                                                                            ctypes.POINTER(c_int), c_void_p]
+        lib.lrf_pipe_create.argtypes = [c_int, c_int, c_i64, ctypes.POINTER(c_void_p)]
+        lib.lrf_pipe_destroy.argtypes = [c_void_p]
+        lib.lrf_pipe_destroy.restype = None
+        lib.lrf_pipe_slots.argtypes = [c_void_p]
+        lib.lrf_pipe_slot_ctx.argtypes = [c_void_p, c_int]
+        lib.lrf_pipe_slot_ctx.restype = c_void_p
+        lib.lrf_pipe_workspace_bytes.argtypes = [c_void_p]
+        lib.lrf_pipe_workspace_bytes.restype = c_size_t
+        lib.lrf_pipe_qmf_encode_rgb_u8_host.argtypes = [c_void_p, c_void_p, c_i64, c_i64, c_i64, ctypes.POINTER(c_int), c_int,
+                                                        c_int, c_int, c_void_p, c_void_p, c_void_p]
+        lib.lrf_pipe_qmf_encode_submit.argtypes = [c_void_p, c_void_p, c_i64, c_i64, c_i64, ctypes.POINTER(c_int), c_int, c_int,
+                                                   c_int, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_int)]
+        lib.lrf_pipe_wait_next.argtypes = [c_void_p, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]
+        lib.lrf_host_alloc.argtypes = [c_size_t, ctypes.POINTER(c_void_p)]
+        lib.lrf_host_free.argtypes = [c_void_p]
+        lib.lrf_host_register.argtypes = [c_void_p, c_size_t]
+        lib.lrf_host_unregister.argtypes = [c_void_p]
         _lib = lib
         return lib
 
@@ -81,7 +98,10 @@ EXPORTS = ["lrf_last_error", "lrf_device_count", "lrf_version", "lrf_ctx_create"
            "lrf_qmf_planes_from_rgb_u8", "lrf_qmf_decompose_f32", "lrf_qmf_bcd_f32", "lrf_qmf_svd_init_f32",
            "lrf_qmf_encode_rgb_u8", "lrf_qmf_decode_rgb_u8", "lrf_svd_encode_rgb_u8", "lrf_svd_decode_rgb_u8",
            "lrf_qmf_rgbspace_encode_u8", "lrf_qmf_rgbspace_decode_u8",
-           "lrf_plane_dims_any", "lrf_qmf_planes_any_u8", "lrf_qmf_decode_any_u8"]
+           "lrf_plane_dims_any", "lrf_qmf_planes_any_u8", "lrf_qmf_decode_any_u8",
+           "lrf_pipe_create", "lrf_pipe_destroy", "lrf_pipe_slots", "lrf_pipe_slot_ctx", "lrf_pipe_workspace_bytes",
+           "lrf_pipe_qmf_encode_rgb_u8_host", "lrf_pipe_qmf_encode_submit", "lrf_pipe_wait_next",
+           "lrf_host_alloc", "lrf_host_free", "lrf_host_register", "lrf_host_unregister"]
 
 
 def check(rc):
@@ -227,8 +247,12 @@ class Context:
         if out is None:
             U = torch.empty((B, nu), dtype=torch.int8, device=rgb.device)
             V = torch.empty((B, nv), dtype=torch.int8, device=rgb.device)
-        else:
+        else:  # the kernels write B * nu / B * nv bytes: anything else would be an out-of-bounds device write
             U, V = out
+            for t, n, name in ((U, nu, "U"), (V, nv, "V")):
+                if not (t.is_cuda and t.device == rgb.device and t.dtype == torch.int8 and t.is_contiguous()
+                        and tuple(t.shape) == (B, n)):
+                    raise ValueError(f"out {name} must be a contiguous int8 tensor of shape {(B, n)} on {rgb.device}")
         R = (c_int * 3)(*[int(r) for r in ranks])
         self.use_torch_stream()
         check(self._lib.lrf_qmf_encode_rgb_u8(self._h, _dptr(rgb), B, H, W, R, K, lo, hi, _dptr(sign), _dptr(U), _dptr(V)))
@@ -238,6 +262,13 @@ class Context:
         import torch
         U, V = U.contiguous(), V.contiguous()
         B = U.shape[0]
+        # the kernel indexes the factors from (H, W) and the ranks alone: sizes that disagree would be out-of-bounds reads
+        dims = plane_dims(H, W)
+        nu, nv = sum(d[4] * int(r) for d, r in zip(dims, ranks)), 64 * sum(int(r) for r in ranks)
+        if len(ranks) != 3 or U.dtype != torch.int8 or V.dtype != torch.int8 or tuple(U.shape) != (B, nu) or \
+                tuple(V.shape) != (B, nv) or V.device != U.device:
+            raise ValueError(f"factor buffers do not match the geometry: expected int8 U {(B, nu)} and V {(B, nv)}, "
+                             f"got {U.dtype} {tuple(U.shape)} and {V.dtype} {tuple(V.shape)}")
         rgb = torch.empty((B, 3, H, W), dtype=torch.uint8, device=U.device)
         R = (c_int * 3)(*[int(r) for r in ranks])
         self.use_torch_stream()
@@ -337,7 +368,136 @@ def _svd_methods():
 
 
 _svd_methods()
+
+
+class _BorrowedContext(Context):
+    """A Context view of an lrf_ctx owned by something else (a pipe's slot): profiling calls only, never destroyed here."""
+
+    def __init__(self, handle, device):
+        self._lib = load()
+        self._h = c_void_p(handle)
+        self.device = int(device)
+
+    def close(self):
+        self._h = c_void_p()
+
+
+def _hptr(t):
+    """host pointer of a contiguous torch CPU tensor / numpy array, or None"""
+    if t is None:
+        return None
+    if isinstance(t, np.ndarray):
+        assert t.flags["C_CONTIGUOUS"], "expected a C-contiguous array"
+        return c_void_p(t.ctypes.data)
+    assert (not t.is_cuda) and t.is_contiguous(), "expected a contiguous CPU tensor"
+    return c_void_p(t.data_ptr())
+
+
+class Pipe:
+    """lrf_pipe: the host -> host pipelined encoder (include/lrf_hip.h).  Host tensors in, int8 factors back on the
+    host; sub-batches stream through `slots` independent encoder contexts so that uploads, kernels and downloads
+    overlap.  Not thread-safe; one per (host thread, device)."""
+
+    def __init__(self, device=0, slots=3, sub_batch=0):
+        import torch
+        if not torch.cuda.is_available():
+            raise LrfError("lrf_amd needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+        self._lib = load()
+        self._h = c_void_p()
+        self.device = int(device)
+        check(self._lib.lrf_pipe_create(self.device, int(slots), int(sub_batch), ctypes.byref(self._h)))
+        self.slots = int(self._lib.lrf_pipe_slots(self._h))
+
+    def close(self):
+        if self._h:
+            self._lib.lrf_pipe_destroy(self._h)
+            self._h = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def slot_context(self, slot):
+        return _BorrowedContext(self._lib.lrf_pipe_slot_ctx(self._h, int(slot)), self.device)
+
+    def workspace_bytes(self):
+        return int(self._lib.lrf_pipe_workspace_bytes(self._h))
+
+    def _prepare(self, rgb, ranks, sign, out):
+        import torch
+        assert (not rgb.is_cuda) and rgb.dtype == torch.uint8 and rgb.dim() == 4 and rgb.shape[1] == 3, \
+            "expected a uint8 CPU tensor [B,3,H,W]"
+        rgb = rgb.contiguous()
+        B, _, H, W = rgb.shape
+        dims = plane_dims(H, W)
+        nu, nv = sum(d[4] * int(r) for d, r in zip(dims, ranks)), 64 * sum(int(r) for r in ranks)
+        if out is None:
+            pin = rgb.is_pinned()
+            U = torch.empty((B, nu), dtype=torch.int8, pin_memory=pin)
+            V = torch.empty((B, nv), dtype=torch.int8, pin_memory=pin)
+        else:
+            U, V = out
+            for t, n, name in ((U, nu, "U"), (V, nv, "V")):
+                if t.is_cuda or t.dtype != torch.int8 or not t.is_contiguous() or tuple(t.shape) != (B, n):
+                    raise ValueError(f"out {name} must be a contiguous int8 CPU tensor of shape {(B, n)}")
+        if sign is not None:
+            sign = torch.as_tensor(sign, dtype=torch.int8).reshape(-1, sum(int(r) for r in ranks))
+            sign = sign.expand(B, -1).contiguous()
+        R = (c_int * 3)(*[int(r) for r in ranks])
+        return rgb, B, H, W, R, sign, U, V
+
+    def encode_rgb_host(self, rgb, ranks, K, lo, hi, sign=None, out=None):
+        """rgb uint8 CPU tensor [B,3,H,W] (pinned for full speed) -> (U int8 [B, sum M_c R_c], V int8 [B, 64 sum R_c])
+        CPU tensors; returns when they are complete."""
+        rgb, B, H, W, R, sign, U, V = self._prepare(rgb, ranks, sign, out)
+        check(self._lib.lrf_pipe_qmf_encode_rgb_u8_host(self._h, _hptr(rgb), B, H, W, R, int(K), int(lo), int(hi), _hptr(sign),
+                                                        _hptr(U), _hptr(V)))
+        return U, V
+
+    def encode_rgb_host_iter(self, rgb, ranks, K, lo, hi, sign=None, out=None):
+        """Generator form: enqueues the whole batch, then yields (first_image, n_images, U, V) as each sub-batch lands on
+        the host (U, V are the full output tensors; rows [first, first + n) are final at that point)."""
+        rgb, B, H, W, R, sign, U, V = self._prepare(rgb, ranks, sign, out)
+        n_sub = c_int()
+        rc = self._lib.lrf_pipe_qmf_encode_submit(self._h, _hptr(rgb), B, H, W, R, int(K), int(lo), int(hi), _hptr(sign), _hptr(U),
+                                                  _hptr(V), ctypes.byref(n_sub))
+        try:
+            check(rc)
+            while True:
+                first, n = c_i64(), c_i64()
+                check(self._lib.lrf_pipe_wait_next(self._h, ctypes.byref(first), ctypes.byref(n)))
+                if n.value == 0:
+                    return
+                yield int(first.value), int(n.value), U, V
+        finally:  # never leave copies into the caller's buffers in flight (an abandoned generator, an error)
+            n = c_i64(1)
+            while n.value:
+                if self._lib.lrf_pipe_wait_next(self._h, None, ctypes.byref(n)):
+                    break
+
+
 _contexts = {}
+_pipes = {}
+
+
+def pipe(device=None, slots=3, sub_batch=0) -> Pipe:
+    """The cached per-(device, slots, sub_batch) pipe of the calling process."""
+    import torch
+    if not torch.cuda.is_available():
+        raise LrfError("lrf_amd needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+    if device is None:
+        device = torch.cuda.current_device()
+    device = torch.device("cuda", device).index if not isinstance(device, int) else device
+    key = (device, int(slots), int(sub_batch))
+    with _lock:
+        p = _pipes.get(key)
+    if p is None:
+        p = Pipe(device, slots, sub_batch)
+        with _lock:
+            _pipes[key] = p
+    return p
 
 
 def context(device=None) -> Context:

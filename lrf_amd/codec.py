@@ -65,6 +65,16 @@ def qmf_factorize_batch(images: torch.Tensor, ranks: Sequence[int], num_iters: i
                           sign, out=out)
 
 
+def qmf_factorize_host(images: torch.Tensor, ranks: Sequence[int], num_iters: int = 10, bounds=(-16, 15), init_sign=None,
+                       out=None, slots: int = 3, sub_batch: int = 0, device=None):
+    """Host -> host form of qmf_factorize_batch: `images` is a uint8 CPU tensor [B,3,H,W]
+    (page-locked — torch's pin_memory — for link-speed copies), the int8 factors come back as CPU tensors.  The batch
+    streams through the pipelined encoder (include/lrf_hip.h, lrf_pipe): uploads, kernels and downloads of different
+    sub-batches overlap.  Same values as qmf_factorize_batch, bit for bit."""
+    pipe = _lib.pipe(device, slots, sub_batch)
+    return pipe.encode_rgb_host(images, list(ranks), num_iters, math.ceil(bounds[0]), math.floor(bounds[1]), init_sign, out)
+
+
 def split_factors(U_row: np.ndarray, V_row: np.ndarray, image_hw, ranks):
     """One image's packed factor rows -> [u_y, v_y, u_cb, v_cb, u_cr, v_cr] numpy int8 matrices."""
     H, W = image_hw
@@ -112,6 +122,14 @@ def _pack_lib():
                                              ctypes.POINTER(ctypes.c_int64)]
         lib.lrf_pack_free.argtypes = [ctypes.c_void_p]
         lib.lrf_pack_free.restype = None
+        # Byte identity with the reference (CPython's zlib module at level 9) needs the same deflate implementation:
+        # a Python built against another zlib (conda, zlib-ng) would make the native streams valid but different.
+        import zlib
+        lib.lrf_pack_zlib_version.restype = ctypes.c_char_p
+        native = (lib.lrf_pack_zlib_version() or b"").decode(errors="replace")
+        if native != zlib.ZLIB_RUNTIME_VERSION:
+            raise OSError(f"liblrf_pack.so links zlib {native}, this Python runs zlib {zlib.ZLIB_RUNTIME_VERSION}: "
+                          "using the Python container code so that streams stay byte-identical to the reference's")
         _PACK_LIB = lib
     return _PACK_LIB
 
@@ -160,9 +178,26 @@ def qmf_encode_batch(images: torch.Tensor, rank=None, quality=None, bounds=(-16,
     (`pack_workers` = 0: one per hardware thread), or, with pack_workers="python", by the Python container code on a
     thread pool.  Other patch sizes and patch=False go through the any-shape kernels (container packed in Python)."""
     assert (rank, quality) != (None, None), "Either 'rank' or 'quality' must be specified."
+    H, W = images.shape[-2:]
+    if (not images.is_cuda) and patch and tuple(patch_size) == (8, 8) and images.dtype == torch.uint8 and num_iters >= 1 \
+            and pack_workers != "python" and not (isinstance(pack_workers, int) and pack_workers < 0):
+        # host tensor in, byte streams out: the pipelined encoder, the container of each finished sub-batch packed by
+        # liblrf_pack.so while the GPU works on the next ones
+        try:
+            _pack_lib()
+        except OSError:
+            pass
+        else:
+            ranks = qmf_ranks((H, W), rank, quality)
+            pipe = _lib.pipe(None)
+            streams = []
+            for first, n, U, V in pipe.encode_rgb_host_iter(images, ranks, num_iters, math.ceil(bounds[0]), math.floor(bounds[1]),
+                                                            init_sign):
+                streams += pack_streams_native(U[first:first + n].numpy(), V[first:first + n].numpy(), (H, W), ranks, bounds,
+                                               (8, 8), "uint8", threads=pack_workers or 0)
+            return streams
     ctx = _lib.context(images.device.index if images.is_cuda else None)
     dev = images if images.is_cuda else images.cuda(ctx.device)
-    H, W = images.shape[-2:]
     if not patch or tuple(patch_size) != (8, 8):
         if images.dtype != torch.uint8:
             raise NotImplementedError("HIP path takes uint8 images")
@@ -174,7 +209,10 @@ def qmf_encode_batch(images: torch.Tensor, rank=None, quality=None, bounds=(-16,
     Uh, Vh = U.cpu().numpy(), V.cpu().numpy()
     dtype_name = str(images.dtype).split(".")[-1]
     if pack_workers != "python" and not (isinstance(pack_workers, int) and pack_workers < 0):
-        return pack_streams_native(Uh, Vh, (H, W), ranks, bounds, (8, 8), dtype_name, threads=pack_workers or 0)
+        try:
+            return pack_streams_native(Uh, Vh, (H, W), ranks, bounds, (8, 8), dtype_name, threads=pack_workers or 0)
+        except OSError:  # liblrf_pack.so missing or linked against another zlib: the Python container code, same bytes
+            pack_workers = "python"
     pack_workers = None if pack_workers == "python" else -pack_workers
 
     def pack(b):
@@ -383,21 +421,32 @@ def parse_stream(encoded_image: bytes):
 
 def qmf_decode_batch(streams: Sequence[bytes], device=None) -> torch.Tensor:
     """Decodes streams of equal geometry and ranks -> uint8 CUDA tensor [B,3,H,W]."""
-    ctx = _lib.context(device)
     metas, Us, Vs = [], [], []
     for s in streams:
         meta, f = parse_stream(s)
+        # a truncated or crafted stream must not reach the kernels: they index the factors from the metadata alone
+        H0, W0 = meta["original size"][0]
+        ranks0 = [int(r) for r in meta["rank"]]
+        if len(ranks0) != 3 or min(ranks0) < 1:
+            raise ValueError("stream metadata: 'rank' must hold three positive integers")
+        for c, (d, R) in enumerate(zip(_lib.plane_dims(H0, W0), ranks0)):
+            u, v = f[2 * c], f[2 * c + 1]
+            if tuple(u.shape) != (d[4], R) or tuple(v.shape) != (64, R) or u.dtype != np.int8 or v.dtype != np.int8:
+                raise ValueError(f"stream factors of plane {c} are {u.dtype}{tuple(u.shape)} / {v.dtype}{tuple(v.shape)}; "
+                                 f"the metadata describes int8 {(d[4], R)} / {(64, R)}")
         metas.append(meta)
         Us.append(np.concatenate([np.ascontiguousarray(f[i], dtype=np.int8).ravel() for i in (0, 2, 4)]))
         Vs.append(np.concatenate([np.ascontiguousarray(f[i], dtype=np.int8).ravel() for i in (1, 3, 5)]))
     m0 = metas[0]
     for m in metas[1:]:
-        assert m["original size"] == m0["original size"] and m["rank"] == m0["rank"], "streams differ in geometry"
+        if m["original size"] != m0["original size"] or m["rank"] != m0["rank"]:
+            raise ValueError("streams differ in geometry or ranks")
     H, W = m0["original size"][0]
     dims = _lib.plane_dims(H, W)
     for c in range(3):  # the stream must describe the geometry the kernels derive from (H, W)
         if list(m0["original size"][c]) != [dims[c][0], dims[c][1]] or list(m0["padded size"][c]) != [dims[c][2], dims[c][3]]:
             raise NotImplementedError("stream geometry is not the scale_factor=(0.5,0.5) / 8x8 layout")
+    ctx = _lib.context(device)
     U = torch.from_numpy(np.stack(Us)).cuda(ctx.device)
     V = torch.from_numpy(np.stack(Vs)).cuda(ctx.device)
     if m0["dtype"] != "uint8":

@@ -36,6 +36,32 @@ static int set_err(int code, const char* fmt, ...)
                                              __FILE__, __LINE__);                                         \
     } while (0)
 
+// Makes the context's device current for the duration of one ABI call and restores the caller's device on the way out
+// (a torch process encoding a cuda:1 tensor while its current device is cuda:0 must not find cuda:1 current afterwards).
+struct DevGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DevGuard(int device)
+    {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) {
+            err = hipSetDevice(device);
+            switched = err == hipSuccess;
+        }
+    }
+    ~DevGuard()
+    {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DevGuard(const DevGuard&) = delete;
+    DevGuard& operator=(const DevGuard&) = delete;
+};
+#define LRF_ON_DEVICE(c)                                                                                  \
+    DevGuard dev_guard_((c)->device);                                                                     \
+    if (dev_guard_.err != hipSuccess)                                                                     \
+        return set_err(LRF_EHIP, "selecting device %d failed: %s", (c)->device, hipGetErrorString(dev_guard_.err))
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -59,7 +85,11 @@ struct lrf_ctx {
     double acc_ms[LRF_K_COUNT] = {0};
     long acc_n[LRF_K_COUNT] = {0};
     int init_sweeps = 0; // developer aid: stop k_init after stage n (0 = run everything)
-    std::vector<char> table_key; // bytes of the descriptor tables now resident on the device
+    std::vector<char> table_key; // bytes of the descriptor tables now resident on the device (planes / blocks)
+    // the previously used tables: calls that alternate between two geometries (a pipeline's full and last, shorter
+    // sub-batch) find both resident and skip the synchronising upload
+    DevBuf planes_alt, blocks_alt;
+    std::vector<char> table_key_alt;
     unsigned attr_done = 0;      // hipFuncSetAttribute call sites already executed for this context's device (bit per site)
 };
 
@@ -232,6 +262,10 @@ static int upload_tables(lrf_ctx* c, const Tables& t)
     std::vector<char> key(pb + bb);
     memcpy(key.data(), t.planes.data(), pb);
     memcpy(key.data() + pb, t.blocks.data(), bb);
+    if (key == c->table_key) return LRF_OK;
+    std::swap(c->planes, c->planes_alt);
+    std::swap(c->blocks, c->blocks_alt);
+    c->table_key.swap(c->table_key_alt);
     if (key == c->table_key) return LRF_OK;
     c->table_key.clear();
     int rc = upload(c, c->planes, t.planes.data(), pb);
@@ -409,7 +443,8 @@ int lrf_ctx_create(int device, lrf_ctx** out)
     int n = 0;
     HIP_TRY(hipGetDeviceCount(&n));
     if (device < 0 || device >= n) return set_err(LRF_EINVAL, "device %d out of range (%d visible)", device, n);
-    HIP_TRY(hipSetDevice(device));
+    DevGuard dev_guard_(device);
+    if (dev_guard_.err != hipSuccess) return set_err(LRF_EHIP, "selecting device %d failed: %s", device, hipGetErrorString(dev_guard_.err));
     lrf_ctx* c = new lrf_ctx();
     c->device = device;
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
@@ -426,11 +461,11 @@ int lrf_ctx_create(int device, lrf_ctx** out)
 void lrf_ctx_destroy(lrf_ctx* c)
 {
     if (!c) return;
-    (void)hipSetDevice(c->device);
+    DevGuard dev_guard_(c->device);
     (void)hipStreamSynchronize(c->stream);
     fold_events(c);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-    DevBuf* bufs[] = {&c->planes, &c->blocks, &c->vf, &c->wf, &c->bf, &c->ppart, &c->qpart, &c->x, &c->sign,
+    DevBuf* bufs[] = {&c->planes_alt, &c->blocks_alt, &c->planes, &c->blocks, &c->vf, &c->wf, &c->bf, &c->ppart, &c->qpart, &c->x, &c->sign,
                       &c->sx, &c->sg, &c->svn, &c->swn, &c->suf, &c->smm,
                       &c->any_uf, &c->any_vf, &c->any_a, &c->any_b, &c->any_p, &c->any_e2, &c->any_g};
     for (DevBuf* b : bufs)
@@ -462,7 +497,7 @@ int lrf_ctx_use_own_stream(lrf_ctx* c)
 int lrf_ctx_synchronize(lrf_ctx* c)
 {
     if (!c) return set_err(LRF_EINVAL, "ctx is NULL");
-    HIP_TRY(hipSetDevice(c->device));
+    LRF_ON_DEVICE(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
     return LRF_OK;
 }
@@ -470,7 +505,7 @@ int lrf_ctx_synchronize(lrf_ctx* c)
 size_t lrf_ctx_workspace_bytes(const lrf_ctx* c)
 {
     if (!c) return 0;
-    const DevBuf* bufs[] = {&c->planes, &c->blocks, &c->vf, &c->wf, &c->bf, &c->ppart, &c->qpart, &c->x, &c->sign,
+    const DevBuf* bufs[] = {&c->planes_alt, &c->blocks_alt, &c->planes, &c->blocks, &c->vf, &c->wf, &c->bf, &c->ppart, &c->qpart, &c->x, &c->sign,
                             &c->sx, &c->sg, &c->svn, &c->swn, &c->suf, &c->smm,
                             &c->any_uf, &c->any_vf, &c->any_a, &c->any_b, &c->any_p, &c->any_e2, &c->any_g};
     size_t total = 0;
@@ -516,7 +551,7 @@ int lrf_ctx_profile_reset(lrf_ctx* c)
 int lrf_malloc(lrf_ctx* c, size_t bytes, void** out)
 {
     if (!c || !out) return set_err(LRF_EINVAL, "NULL argument");
-    HIP_TRY(hipSetDevice(c->device));
+    LRF_ON_DEVICE(c);
     hipError_t e = hipMalloc(out, bytes ? bytes : 1);
     if (e != hipSuccess) return set_err(LRF_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
     return LRF_OK;
@@ -562,7 +597,7 @@ int lrf_qmf_planes_from_rgb_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_
     ImageGeom g;
     int rc = make_geom(H, W, &g);
     if (rc) return rc;
-    HIP_TRY(hipSetDevice(c->device));
+    LRF_ON_DEVICE(c);
     Prof p(c, LRF_K_PLANES);
     if ((long)H * W * 3 >= (1L << 31)) return set_err(LRF_ENOTSUP, "image too large for 32-bit pixel indexing");
     if (H % 16 == 0 && W % 16 == 0 && (reinterpret_cast<uintptr_t>(rgb) & 7) == 0)
@@ -622,7 +657,7 @@ int lrf_qmf_decompose_f32(lrf_ctx* c, const float* X, int64_t B, int64_t M, int6
     int rc = check_params(M, N, R, K, lo, hi);
     if (rc) return rc;
     if (B < 1) return set_err(LRF_EINVAL, "B must be >= 1");
-    HIP_TRY(hipSetDevice(c->device));
+    LRF_ON_DEVICE(c);
     Tables t;
     uniform_tables(t, B, M, R, sign != nullptr);
     if ((rc = upload_tables(c, t))) return rc;
@@ -643,7 +678,7 @@ int lrf_qmf_bcd_f32(lrf_ctx* c, const float* X, int64_t B, int64_t M, int64_t N,
     int rc = check_params(M, N, R, K, lo, hi);
     if (rc) return rc;
     if (B < 1) return set_err(LRF_EINVAL, "B must be >= 1");
-    HIP_TRY(hipSetDevice(c->device));
+    LRF_ON_DEVICE(c);
     Tables t;
     uniform_tables(t, B, M, R, false);
     if ((rc = upload_tables(c, t))) return rc;
@@ -661,7 +696,7 @@ int lrf_qmf_svd_init_f32(lrf_ctx* c, const float* X, int64_t B, int64_t M, int64
     int rc = check_params(M, N, R, 1, -16, 15);
     if (rc) return rc;
     if (B < 1) return set_err(LRF_EINVAL, "B must be >= 1");
-    HIP_TRY(hipSetDevice(c->device));
+    LRF_ON_DEVICE(c);
     Tables t;
     uniform_tables(t, B, M, R, sign != nullptr);
     if ((rc = upload_tables(c, t))) return rc;
@@ -682,7 +717,7 @@ int lrf_qmf_encode_rgb_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_t H, 
     if (rc) return rc;
     for (int ch = 0; ch < 3; ch++)
         if ((rc = check_params(g.p[ch].M, 64, R[ch], K, lo, hi))) return rc;
-    HIP_TRY(hipSetDevice(c->device));
+    LRF_ON_DEVICE(c);
     if ((rc = ensure(c, c->x, (size_t)B * g.img_floats * sizeof(float)))) return rc;
     float* X = (float*)c->x.p;
     if ((rc = lrf_qmf_planes_from_rgb_u8(c, rgb, B, H, W, X))) return rc;
@@ -730,7 +765,7 @@ int lrf_qmf_decode_rgb_u8(lrf_ctx* c, const int8_t* U, const int8_t* V, int64_t 
     if (rc) return rc;
     for (int ch = 0; ch < 3; ch++)
         if (R[ch] < 1 || R[ch] > 64) return set_err(LRF_EINVAL, "rank %d out of range", R[ch]);
-    HIP_TRY(hipSetDevice(c->device));
+    LRF_ON_DEVICE(c);
     long u_img = 0, v_img = 0;
     for (int ch = 0; ch < 3; ch++) {
         u_img += (long)g.p[ch].M * R[ch];
@@ -745,6 +780,208 @@ int lrf_qmf_decode_rgb_u8(lrf_ctx* c, const int8_t* U, const int8_t* V, int64_t 
         hipLaunchKernelGGL(k_decode, dim3((unsigned)((n4 + 255) / 256), (unsigned)B), dim3(256), 0, c->stream, U, V, (int)H, (int)W,
                            g, R[0], R[1], R[2], u_img, v_img, rgb);
     LAUNCH_CHECK();
+    return LRF_OK;
+}
+
+
+/* ---- host -> host pipelined encoder (the protocol of lrf/utils/misc.py:90-100: host tensor in,
+ * encoded factors back on the host) ----
+ * A pipe owns `slots` independent encoder contexts, each with its own stream, scratch workspace and device staging for one
+ * sub-batch.  Sub-batch i goes to slot i % slots as  H2D(rgb) -> planes -> init -> K x (U update, V update) -> D2H(U, V),
+ * all on the slot's stream: the copies of one slot overlap the kernels of the others (separate SDMA queues, full-duplex link),
+ * and the latency-bound initialisation of one sub-batch overlaps the HBM-bound iterations of another. */
+struct PipeSlot {
+    lrf_ctx* ctx = nullptr;
+    DevBuf rgb, u, v, sign;
+};
+struct lrf_pipe {
+    int device = 0;
+    int64_t sub_batch = 0;
+    std::vector<PipeSlot> slots;
+    std::vector<hipEvent_t> done;   // one per sub-batch of the call in flight
+    std::vector<int64_t> first, count;
+    size_t next_wait = 0;
+};
+
+static int pipe_ensure(lrf_pipe* p, PipeSlot& s, DevBuf& b, size_t bytes) { (void)p; return ensure(s.ctx, b, bytes); }
+
+int lrf_pipe_create(int device, int slots, int64_t sub_batch, lrf_pipe** out)
+{
+    if (!out) return set_err(LRF_EINVAL, "out is NULL");
+    if (slots < 1 || slots > 8) return set_err(LRF_EINVAL, "slots=%d out of range [1,8]", slots);
+    if (sub_batch < 0 || sub_batch > 65535) return set_err(LRF_EINVAL, "sub_batch=%ld out of range [0,65535]", (long)sub_batch);
+    lrf_pipe* p = new lrf_pipe();
+    p->device = device;
+    p->sub_batch = sub_batch;
+    p->slots.resize((size_t)slots);
+    for (auto& s : p->slots) {
+        int rc = lrf_ctx_create(device, &s.ctx);
+        if (rc) {
+            lrf_pipe_destroy(p);
+            return rc;
+        }
+    }
+    *out = p;
+    return LRF_OK;
+}
+
+void lrf_pipe_destroy(lrf_pipe* p)
+{
+    if (!p) return;
+    DevGuard dev_guard_(p->device);
+    for (auto& s : p->slots) {
+        if (!s.ctx) continue;
+        (void)hipStreamSynchronize(s.ctx->stream);
+        DevBuf* bufs[] = {&s.rgb, &s.u, &s.v, &s.sign};
+        for (DevBuf* b : bufs)
+            if (b->p) (void)hipFree(b->p);
+        lrf_ctx_destroy(s.ctx);
+    }
+    for (auto e : p->done) (void)hipEventDestroy(e);
+    delete p;
+}
+
+int lrf_pipe_slots(const lrf_pipe* p) { return p ? (int)p->slots.size() : 0; }
+
+lrf_ctx* lrf_pipe_slot_ctx(lrf_pipe* p, int slot)
+{
+    if (!p || slot < 0 || slot >= (int)p->slots.size()) return nullptr;
+    return p->slots[(size_t)slot].ctx;
+}
+
+size_t lrf_pipe_workspace_bytes(const lrf_pipe* p)
+{
+    if (!p) return 0;
+    size_t total = 0;
+    for (const auto& s : p->slots) total += lrf_ctx_workspace_bytes(s.ctx) + s.rgb.cap + s.u.cap + s.v.cap + s.sign.cap;
+    return total;
+}
+
+/* images per sub-batch when the caller left it to the library: about 48 MB of input, i.e. ~0.8 ms of a Gen5 x16 link */
+static int64_t pipe_sub_batch(const lrf_pipe* p, int64_t B, int64_t H, int64_t W)
+{
+    int64_t sb = p->sub_batch;
+    if (sb <= 0) {
+        sb = (48L << 20) / (3 * H * W);
+        if (sb < 1) sb = 1;
+        if (sb > 1024) sb = 1024;
+    }
+    return sb < B ? sb : B;
+}
+
+int lrf_pipe_qmf_encode_submit(lrf_pipe* p, const uint8_t* rgb_host, int64_t B, int64_t H, int64_t W, const int R[3], int K, int lo,
+                               int hi, const int8_t* sign_host, int8_t* U_host, int8_t* V_host, int* n_sub)
+{
+    if (!p || !rgb_host || !R || !U_host || !V_host) return set_err(LRF_EINVAL, "NULL argument");
+    if (B < 1) return set_err(LRF_EINVAL, "B must be >= 1");
+    if (p->next_wait < p->count.size()) return set_err(LRF_EINVAL, "the previous submission has not been waited for");
+    ImageGeom g;
+    int rc = make_geom(H, W, &g);
+    if (rc) return rc;
+    for (int ch = 0; ch < 3; ch++)
+        if ((rc = check_params(g.p[ch].M, 64, R[ch], K, lo, hi))) return rc;
+    long u_img = 0, v_img = 0, s_img = R[0] + R[1] + R[2];
+    for (int ch = 0; ch < 3; ch++) {
+        u_img += (long)g.p[ch].M * R[ch];
+        v_img += 64L * R[ch];
+    }
+    const size_t img_bytes = (size_t)3 * H * W;
+    const int64_t sb = pipe_sub_batch(p, B, H, W);
+    const size_t nsub = (size_t)((B + sb - 1) / sb);
+    DevGuard dev_guard_(p->device);
+    if (dev_guard_.err != hipSuccess) return set_err(LRF_EHIP, "selecting device %d failed", p->device);
+    while (p->done.size() < nsub) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        p->done.push_back(e);
+    }
+    p->first.clear();
+    p->count.clear();
+    p->next_wait = 0;
+    for (size_t i = 0; i < nsub; i++) {
+        PipeSlot& s = p->slots[i % p->slots.size()];
+        const int64_t b0 = (int64_t)i * sb, nb = (b0 + sb <= B) ? sb : B - b0;
+        if ((rc = pipe_ensure(p, s, s.rgb, (size_t)sb * img_bytes))) return rc;
+        if ((rc = pipe_ensure(p, s, s.u, (size_t)sb * u_img))) return rc;
+        if ((rc = pipe_ensure(p, s, s.v, (size_t)sb * v_img))) return rc;
+        hipStream_t st = s.ctx->stream;
+        HIP_TRY(hipMemcpyAsync(s.rgb.p, rgb_host + (size_t)b0 * img_bytes, (size_t)nb * img_bytes, hipMemcpyHostToDevice, st));
+        const int8_t* sign_dev = nullptr;
+        if (sign_host) {
+            if ((rc = pipe_ensure(p, s, s.sign, (size_t)sb * s_img))) return rc;
+            HIP_TRY(hipMemcpyAsync(s.sign.p, sign_host + (size_t)b0 * s_img, (size_t)nb * s_img, hipMemcpyHostToDevice, st));
+            sign_dev = (const int8_t*)s.sign.p;
+        }
+        if ((rc = lrf_qmf_encode_rgb_u8(s.ctx, (const uint8_t*)s.rgb.p, nb, H, W, R, K, lo, hi, sign_dev, (int8_t*)s.u.p, (int8_t*)s.v.p)))
+            return rc;
+        HIP_TRY(hipMemcpyAsync(U_host + (size_t)b0 * u_img, s.u.p, (size_t)nb * u_img, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(V_host + (size_t)b0 * v_img, s.v.p, (size_t)nb * v_img, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(p->done[i], st));
+        p->first.push_back(b0);
+        p->count.push_back(nb);
+    }
+    if (n_sub) *n_sub = (int)nsub;
+    return LRF_OK;
+}
+
+int lrf_pipe_wait_next(lrf_pipe* p, int64_t* first_image, int64_t* n_images)
+{
+    if (!p) return set_err(LRF_EINVAL, "pipe is NULL");
+    if (p->next_wait >= p->count.size()) {
+        if (first_image) *first_image = 0;
+        if (n_images) *n_images = 0;
+        return LRF_OK;
+    }
+    DevGuard dev_guard_(p->device);
+    HIP_TRY(hipEventSynchronize(p->done[p->next_wait]));
+    if (first_image) *first_image = p->first[p->next_wait];
+    if (n_images) *n_images = p->count[p->next_wait];
+    p->next_wait++;
+    return LRF_OK;
+}
+
+int lrf_pipe_qmf_encode_rgb_u8_host(lrf_pipe* p, const uint8_t* rgb_host, int64_t B, int64_t H, int64_t W, const int R[3], int K,
+                                    int lo, int hi, const int8_t* sign_host, int8_t* U_host, int8_t* V_host)
+{
+    int rc = lrf_pipe_qmf_encode_submit(p, rgb_host, B, H, W, R, K, lo, hi, sign_host, U_host, V_host, nullptr);
+    // whatever was enqueued must have finished before the caller may touch (or free) its buffers, also after an error
+    int64_t n = 1;
+    while (n > 0) {
+        int rc2 = lrf_pipe_wait_next(p, nullptr, &n);
+        if (rc2) return rc ? rc : rc2;
+    }
+    if (rc && p) {
+        DevGuard dev_guard_(p->device);
+        for (auto& s : p->slots) (void)hipStreamSynchronize(s.ctx->stream);
+    }
+    return rc;
+}
+
+int lrf_host_alloc(size_t bytes, void** out)
+{
+    if (!out) return set_err(LRF_EINVAL, "out is NULL");
+    hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) return set_err(LRF_ENOMEM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return LRF_OK;
+}
+
+int lrf_host_free(void* p)
+{
+    if (p) HIP_TRY(hipHostFree(p));
+    return LRF_OK;
+}
+
+int lrf_host_register(void* p, size_t bytes)
+{
+    if (!p) return set_err(LRF_EINVAL, "NULL argument");
+    HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return LRF_OK;
+}
+
+int lrf_host_unregister(void* p)
+{
+    if (!p) return set_err(LRF_EINVAL, "NULL argument");
+    HIP_TRY(hipHostUnregister(p));
     return LRF_OK;
 }
 
@@ -779,7 +1016,7 @@ int lrf_svd_encode_rgb_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_t H, 
     int hp, wp, top, left, nw, M, rc;
     if ((rc = svd_geom(H, W, &hp, &wp, &top, &left, &nw, &M))) return rc;
     const int N = 192, nc = 3;
-    HIP_TRY(hipSetDevice(c->device));
+    LRF_ON_DEVICE(c);
     long xs = (long)M * N;
     if ((rc = ensure(c, c->sx, (size_t)B * xs * sizeof(float)))) return rc;
     if ((rc = ensure(c, c->sg, (size_t)B * N * N * sizeof(double)))) return rc;
@@ -819,7 +1056,7 @@ int lrf_svd_decode_rgb_u8(lrf_ctx* c, const uint8_t* U, const uint8_t* V, int64_
     if (R < 1 || R > 192) return set_err(LRF_EINVAL, "rank %d out of range", R);
     int hp, wp, top, left, nw, M, rc;
     if ((rc = svd_geom(H, W, &hp, &wp, &top, &left, &nw, &M))) return rc;
-    HIP_TRY(hipSetDevice(c->device));
+    LRF_ON_DEVICE(c);
     long n4 = 3L * H * ((W + 3) / 4);
     hipLaunchKernelGGL(k_svd_decode, dim3((unsigned)((n4 + 255) / 256), (unsigned)B), dim3(256), 0, c->stream, U, V, (int)H, (int)W, top,
                        left, nw, M, R, qparams6, rgb);
@@ -849,7 +1086,7 @@ int lrf_qmf_rgbspace_encode_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_
     if ((rc = svd_geom(H, W, &hp, &wp, &top, &left, &nw, &M))) return rc;
     if ((rc = rgbspace_check(B, H, W, R, K, lo, hi, M))) return rc;
     const int N = 192, nc = 3;
-    HIP_TRY(hipSetDevice(c->device));
+    LRF_ON_DEVICE(c);
     const long xs = (long)M * N;
     if ((rc = ensure(c, c->sx, (size_t)B * xs * sizeof(float)))) return rc;
     float* X = (float*)c->sx.p;
@@ -886,7 +1123,7 @@ int lrf_qmf_rgbspace_decode_u8(lrf_ctx* c, const int8_t* U, const int8_t* V, int
     if (R < 1 || R > 192) return set_err(LRF_EINVAL, "rank %d out of range", R);
     int hp, wp, top, left, nw, M, rc;
     if ((rc = svd_geom(H, W, &hp, &wp, &top, &left, &nw, &M))) return rc;
-    HIP_TRY(hipSetDevice(c->device));
+    LRF_ON_DEVICE(c);
     const long n = 3L * H * W;
     Prof p(c, LRF_K_DECODE);
     hipLaunchKernelGGL(k_qmf_decode_rgbspace, dim3((unsigned)((n + 255) / 256), (unsigned)B), dim3(256), 0, c->stream, U, V, (int)H, (int)W,
@@ -913,7 +1150,7 @@ int lrf_qmf_planes_any_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_t H, 
     AnyGeom g;
     int rc = any_geom(H, W, p, q, ch, &g);
     if (rc) return rc;
-    HIP_TRY(hipSetDevice(c->device));
+    LRF_ON_DEVICE(c);
     const long elems = g.M * g.N;
     Prof pr(c, LRF_K_PLANES);
     hipLaunchKernelGGL(k_any_planes, dim3((unsigned)((elems + 255) / 256), (unsigned)B), dim3(256), 0, c->stream, rgb, (int)H, (int)W, ch,
@@ -940,7 +1177,7 @@ int lrf_qmf_decode_any_u8(lrf_ctx* c, const int8_t* U0, const int8_t* V0, const 
         d[ch].h = g.h; d[ch].w = g.w; d[ch].p = p; d[ch].q = q; d[ch].top = g.top; d[ch].left = g.left; d[ch].nw = g.nw;
         d[ch].R = R[ch];
     }
-    HIP_TRY(hipSetDevice(c->device));
+    LRF_ON_DEVICE(c);
     Prof pr(c, LRF_K_DECODE);
     hipLaunchKernelGGL(k_any_decode, dim3((unsigned)(((long)H * W + 255) / 256), (unsigned)B), dim3(256), 0, c->stream, d[0], d[1], d[2],
                        (int)H, (int)W, rgb);

@@ -15,13 +15,23 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, min(lo + per, n_items)
 
 
+def collective_device() -> torch.device:
+    """Where the payload of this process group's collectives must live: the current GPU under RCCL ("nccl"), the CPU
+    under gloo.  Every rank must hand tensors of the same kind to a collective, also the ranks whose block is empty."""
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
 def gather_metrics(local: torch.Tensor, n_items: int) -> torch.Tensor:
-    """local: [n_local, k] float32 metrics of this rank's block (in block order) -> [n_items, k] on every rank."""
+    """local: [n_local, k] float32 metrics of this rank's block (in block order) -> [n_items, k] on every rank
+    (on collective_device())."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
     per = (n_items + world - 1) // world
     k = local.shape[1]
+    local = local.to(collective_device())
     padded = torch.zeros((per, k), dtype=local.dtype, device=local.device)
     padded[: local.shape[0]] = local
     out = [torch.empty_like(padded) for _ in range(world)]
@@ -48,5 +58,5 @@ def encode_sharded(n_items: int, load_block: Callable[[int, int], torch.Tensor],
         streams = encode_block(images)
         local = metrics_of(images, streams).float().reshape(hi - lo, n_metrics)
     else:
-        streams, local = [], torch.zeros((0, n_metrics), dtype=torch.float32)
+        streams, local = [], torch.zeros((0, n_metrics), dtype=torch.float32, device=collective_device())
     return streams, gather_metrics(local, n_items)

@@ -144,3 +144,27 @@ def test_ssim_matches_direct_window_statistics():
     assert got < 1.0
     with pytest.raises(ValueError):
         ssim(torch.zeros(3, 4, 4), torch.zeros(3, 4, 4))
+
+
+def test_crafted_streams_are_rejected_before_any_kernel_runs():
+    """A stream whose factor blobs disagree with its metadata (truncated, or crafted: rank 64 in the metadata with
+    2-column factors) would make the decode kernel read past its buffers: qmf_decode_batch must refuse it on the host."""
+    import lrf_amd
+    from lrf_amd.codec import pack_image, parse_stream, qmf_decode_batch
+    case = Case("tiny_q7")
+    meta, fac = parse_stream(case.encoded)
+    H, W = case.image.shape[-2:]
+    lying = pack_image(fac, (H, W), [64, 64, 64], meta["bounds"], meta["patch size"], meta["dtype"])  # metadata says rank 64
+    with pytest.raises(ValueError, match="metadata describes"):
+        qmf_decode_batch([lying])
+    short = [f.copy() for f in fac]
+    short[2] = short[2][:-1]  # one patch row missing in U_Cb
+    with pytest.raises(ValueError, match="metadata describes"):
+        qmf_decode_batch([pack_image(short, (H, W), meta["rank"], meta["bounds"], meta["patch size"], meta["dtype"])])
+    wide = [f.astype(np.int16) for f in fac]
+    with pytest.raises(ValueError, match="metadata describes"):
+        qmf_decode_batch([pack_image(wide, (H, W), meta["rank"], meta["bounds"], meta["patch size"], meta["dtype"])])
+    other = Case("tiny_r7")
+    with pytest.raises(ValueError, match="differ"):
+        qmf_decode_batch([case.encoded, other.encoded])
+    assert lrf_amd is not None
