@@ -51,7 +51,7 @@ def cpu_baseline(images_u8, budget_s=12.0, budget_all_s=10.0):
     except AttributeError:
         cores = os.cpu_count() or 1
     # all cores: as many images as fit the budget at perfect scaling, a multiple of the thread count, wrapped over the batch
-    n_all = max(cores, int(budget_all_s / per_image) * cores // cores * cores)
+    n_all = max(cores, int(budget_all_s / per_image) * cores)
     n_all = min(n_all, 8 * images_u8.shape[0])
     with ThreadPoolExecutor(max_workers=cores) as pool:
         list(pool.map(encode_one, range(min(cores, images_u8.shape[0]))))  # warm: threads started, pages touched
@@ -79,7 +79,7 @@ def host_to_host(torch, _lib, dev_index, images, steps, warmup):
     dims = _lib.plane_dims(H, W)
     Uh = torch.empty((B, sum(d[4] * r for d, r in zip(dims, RANKS))), dtype=torch.int8, pin_memory=True)
     Vh = torch.empty((B, 64 * sum(RANKS)), dtype=torch.int8, pin_memory=True)
-    slots = int(os.environ.get("LRF_PIPE_SLOTS", "3"))
+    slots = int(os.environ.get("LRF_PIPE_SLOTS", "2"))
     sub = int(os.environ.get("LRF_PIPE_SUB", "0"))
     pipe = _lib.Pipe(dev_index, slots=slots, sub_batch=sub)
     for _ in range(max(warmup, 2)):
@@ -106,7 +106,7 @@ def host_to_host(torch, _lib, dev_index, images, steps, warmup):
                          "63 GB/s (PCIe Gen5 x16); the 0.14 B/pixel of factors return on the other direction of the link",
             "h2d_copy_alone_gbs": round(nbytes / dt_copy / 1e9, 2),
             "frac_of_h2d_copy_alone": round(dt_copy / dt, 4),
-            "pipe": {"slots": slots, "sub_batch": sub or "auto (~48 MB of input)"}}, (Uh, Vh)
+            "pipe": {"slots": slots, "sub_batch": sub or "auto (~40 MB of input)"}}, (Uh, Vh)
 
 
 def _cpu_model():

@@ -214,9 +214,12 @@ int lrf_qmf_decode_any_u8(lrf_ctx* ctx, const int8_t* U0, const int8_t* V0, cons
  * the encoded factors come back on the host (lrf/utils/misc.py:90-100 times exactly that around `encoder(image)`;
  * experiments/comparison/eval.py:105-110 loops it over a dataset) — and the metric SURVEY.md section 8(d) defines.
  * A pipe owns `slots` encoder contexts (stream + scratch + device staging each).  A batch is cut into sub-batches of
- * `sub_batch` images (0 = chosen by the library: ~48 MB of input); sub-batch i runs on slot i % slots as
+ * `sub_batch` images (0 = chosen by the library: ~40 MB of input); sub-batch i runs on slot i % slots as
  *     H2D(rgb) -> lrf_qmf_encode_rgb_u8 -> D2H(U, V)
- * on that slot's stream, so uploads, kernels and downloads of different sub-batches overlap.
+ * — the uploads of all sub-batches in order on one upload stream (each gets the whole link, the first lands early), the
+ * kernels and the download on the slot's stream — so uploads, kernels and downloads of different sub-batches overlap.
+ * Two slots are the measured optimum on MI355X (three or more streams of kernels plus the upload stream exceed the HIP
+ * runtime's default of four hardware queues, and streams that share a queue serialise).
  *   rgb_host [B,3,H,W] uint8, U_host / V_host as lrf_qmf_encode_rgb_u8 lays them out, sign_host optional
  *   [B, R[0]+R[1]+R[2]] int8: HOST pointers.  Page-locked memory (lrf_host_alloc, lrf_host_register, or torch's
  *   pin_memory) is what lets the copies run asynchronously at link speed; pageable memory works, slowly.

@@ -398,7 +398,7 @@ class Pipe:
     host; sub-batches stream through `slots` independent encoder contexts so that uploads, kernels and downloads
     overlap.  Not thread-safe; one per (host thread, device)."""
 
-    def __init__(self, device=0, slots=3, sub_batch=0):
+    def __init__(self, device=0, slots=2, sub_batch=0):
         import torch
         if not torch.cuda.is_available():
             raise LrfError("lrf_amd needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU fallback")
@@ -482,7 +482,7 @@ _contexts = {}
 _pipes = {}
 
 
-def pipe(device=None, slots=3, sub_batch=0) -> Pipe:
+def pipe(device=None, slots=2, sub_batch=0) -> Pipe:
     """The cached per-(device, slots, sub_batch) pipe of the calling process."""
     import torch
     if not torch.cuda.is_available():

@@ -66,7 +66,7 @@ def qmf_factorize_batch(images: torch.Tensor, ranks: Sequence[int], num_iters: i
 
 
 def qmf_factorize_host(images: torch.Tensor, ranks: Sequence[int], num_iters: int = 10, bounds=(-16, 15), init_sign=None,
-                       out=None, slots: int = 3, sub_batch: int = 0, device=None):
+                       out=None, slots: int = 2, sub_batch: int = 0, device=None):
     """Host -> host form of qmf_factorize_batch: `images` is a uint8 CPU tensor [B,3,H,W]
     (page-locked — torch's pin_memory — for link-speed copies), the int8 factors come back as CPU tensors.  The batch
     streams through the pipelined encoder (include/lrf_hip.h, lrf_pipe): uploads, kernels and downloads of different

@@ -91,6 +91,7 @@ struct lrf_ctx {
     DevBuf planes_alt, blocks_alt;
     std::vector<char> table_key_alt;
     unsigned attr_done = 0;      // hipFuncSetAttribute call sites already executed for this context's device (bit per site)
+    hipEvent_t planes_done = nullptr; // set by a pipe: recorded after the planes kernel of lrf_qmf_encode_rgb_u8 (input buffer free)
 };
 
 static int ensure(lrf_ctx* c, DevBuf& b, size_t bytes)
@@ -721,6 +722,7 @@ int lrf_qmf_encode_rgb_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_t H, 
     if ((rc = ensure(c, c->x, (size_t)B * g.img_floats * sizeof(float)))) return rc;
     float* X = (float*)c->x.p;
     if ((rc = lrf_qmf_planes_from_rgb_u8(c, rgb, B, H, W, X))) return rc;
+    if (c->planes_done) HIP_TRY(hipEventRecord(c->planes_done, c->stream)); // the RGB bytes are not read again
     // plane table: all Y planes first (four times the work of a chroma plane), then Cb, then Cr
     long u_img = 0, v_img = 0, s_img = R[0] + R[1] + R[2];
     long uoff[3], voff[3], soff[3] = {0, R[0], R[0] + R[1]};
@@ -793,10 +795,14 @@ int lrf_qmf_decode_rgb_u8(lrf_ctx* c, const int8_t* U, const int8_t* V, int64_t 
 struct PipeSlot {
     lrf_ctx* ctx = nullptr;
     DevBuf rgb, u, v, sign;
+    hipEvent_t h2d_done = nullptr;  // recorded on the upload stream: this slot's input has landed
+    hipEvent_t rgb_free = nullptr;  // recorded on the slot's stream after the planes kernel: the input may be overwritten
 };
 struct lrf_pipe {
     int device = 0;
     int64_t sub_batch = 0;
+    hipStream_t h2d = nullptr;      // all uploads, in order: one sub-batch at a time gets the whole link, so the first one
+                                    // lands early and its kernels run under the uploads of the following ones
     std::vector<PipeSlot> slots;
     std::vector<hipEvent_t> done;   // one per sub-batch of the call in flight
     std::vector<int64_t> first, count;
@@ -821,6 +827,17 @@ int lrf_pipe_create(int device, int slots, int64_t sub_batch, lrf_pipe** out)
             return rc;
         }
     }
+    DevGuard dev_guard_(device);
+    hipError_t e = hipStreamCreateWithFlags(&p->h2d, hipStreamNonBlocking);
+    for (auto& s : p->slots) {
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s.h2d_done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s.rgb_free, hipEventDisableTiming);
+        s.ctx->planes_done = s.rgb_free;
+    }
+    if (e != hipSuccess) {
+        lrf_pipe_destroy(p);
+        return set_err(LRF_EHIP, "creating the pipe's stream / events failed: %s", hipGetErrorString(e));
+    }
     *out = p;
     return LRF_OK;
 }
@@ -829,14 +846,19 @@ void lrf_pipe_destroy(lrf_pipe* p)
 {
     if (!p) return;
     DevGuard dev_guard_(p->device);
+    if (p->h2d) (void)hipStreamSynchronize(p->h2d);
     for (auto& s : p->slots) {
         if (!s.ctx) continue;
         (void)hipStreamSynchronize(s.ctx->stream);
         DevBuf* bufs[] = {&s.rgb, &s.u, &s.v, &s.sign};
         for (DevBuf* b : bufs)
             if (b->p) (void)hipFree(b->p);
+        s.ctx->planes_done = nullptr;
         lrf_ctx_destroy(s.ctx);
+        if (s.h2d_done) (void)hipEventDestroy(s.h2d_done);
+        if (s.rgb_free) (void)hipEventDestroy(s.rgb_free);
     }
+    if (p->h2d) (void)hipStreamDestroy(p->h2d);
     for (auto e : p->done) (void)hipEventDestroy(e);
     delete p;
 }
@@ -857,12 +879,15 @@ size_t lrf_pipe_workspace_bytes(const lrf_pipe* p)
     return total;
 }
 
-/* images per sub-batch when the caller left it to the library: about 48 MB of input, i.e. ~0.8 ms of a Gen5 x16 link */
+/* images per sub-batch when the caller left it to the library: about 40 MB of input (0.7 ms of a Gen5 x16 link; 32 images of
+ * 512x768).  Measured at 256 x 512x768 (tools/dev_pipe_sweep.py): 16 images 8.8 ms per batch, 32: 6.57, 64: 6.61 — smaller
+ * sub-batches are bound by the per-matrix latency chain of the initialisation, larger ones lengthen the un-overlapped tail. */
 static int64_t pipe_sub_batch(const lrf_pipe* p, int64_t B, int64_t H, int64_t W)
 {
     int64_t sb = p->sub_batch;
     if (sb <= 0) {
-        sb = (48L << 20) / (3 * H * W);
+        sb = (40L << 20) / (3 * H * W);
+        if (sb >= 8) sb -= sb % 8;
         if (sb < 1) sb = 1;
         if (sb > 1024) sb = 1024;
     }
@@ -898,22 +923,37 @@ int lrf_pipe_qmf_encode_submit(lrf_pipe* p, const uint8_t* rgb_host, int64_t B, 
     p->first.clear();
     p->count.clear();
     p->next_wait = 0;
+    // upload of sub-batch i: on the upload stream, once the planes kernel of the sub-batch that used the slot before has read
+    // its input; enqueued one sub-batch ahead of the kernels so that the link never waits for this host thread
+    auto enqueue_upload = [&](size_t i) -> int {
+        PipeSlot& s = p->slots[i % p->slots.size()];
+        const int64_t b0 = (int64_t)i * sb, nb = (b0 + sb <= B) ? sb : B - b0;
+        int rc2;
+        if ((rc2 = pipe_ensure(p, s, s.rgb, (size_t)sb * img_bytes))) return rc2;
+        HIP_TRY(hipStreamWaitEvent(p->h2d, s.rgb_free, 0));
+        if (sign_host) {
+            if ((rc2 = pipe_ensure(p, s, s.sign, (size_t)sb * s_img))) return rc2;
+            HIP_TRY(hipMemcpyAsync(s.sign.p, sign_host + (size_t)b0 * s_img, (size_t)nb * s_img, hipMemcpyHostToDevice, p->h2d));
+        }
+        HIP_TRY(hipMemcpyAsync(s.rgb.p, rgb_host + (size_t)b0 * img_bytes, (size_t)nb * img_bytes, hipMemcpyHostToDevice, p->h2d));
+        HIP_TRY(hipEventRecord(s.h2d_done, p->h2d));
+        return LRF_OK;
+    };
+    if ((rc = enqueue_upload(0))) return rc;
     for (size_t i = 0; i < nsub; i++) {
         PipeSlot& s = p->slots[i % p->slots.size()];
         const int64_t b0 = (int64_t)i * sb, nb = (b0 + sb <= B) ? sb : B - b0;
-        if ((rc = pipe_ensure(p, s, s.rgb, (size_t)sb * img_bytes))) return rc;
         if ((rc = pipe_ensure(p, s, s.u, (size_t)sb * u_img))) return rc;
         if ((rc = pipe_ensure(p, s, s.v, (size_t)sb * v_img))) return rc;
         hipStream_t st = s.ctx->stream;
-        HIP_TRY(hipMemcpyAsync(s.rgb.p, rgb_host + (size_t)b0 * img_bytes, (size_t)nb * img_bytes, hipMemcpyHostToDevice, st));
-        const int8_t* sign_dev = nullptr;
-        if (sign_host) {
-            if ((rc = pipe_ensure(p, s, s.sign, (size_t)sb * s_img))) return rc;
-            HIP_TRY(hipMemcpyAsync(s.sign.p, sign_host + (size_t)b0 * s_img, (size_t)nb * s_img, hipMemcpyHostToDevice, st));
-            sign_dev = (const int8_t*)s.sign.p;
-        }
-        if ((rc = lrf_qmf_encode_rgb_u8(s.ctx, (const uint8_t*)s.rgb.p, nb, H, W, R, K, lo, hi, sign_dev, (int8_t*)s.u.p, (int8_t*)s.v.p)))
+        HIP_TRY(hipStreamWaitEvent(st, s.h2d_done, 0));
+        // With one slot the next upload overwrites the buffer this sub-batch still has to read: it is enqueued after the
+        // kernels (which record rgb_free); with more slots it goes first, so that the link never waits for this thread.
+        if (i + 1 < nsub && p->slots.size() > 1 && (rc = enqueue_upload(i + 1))) return rc;
+        if ((rc = lrf_qmf_encode_rgb_u8(s.ctx, (const uint8_t*)s.rgb.p, nb, H, W, R, K, lo, hi, sign_host ? (const int8_t*)s.sign.p : nullptr,
+                                        (int8_t*)s.u.p, (int8_t*)s.v.p)))
             return rc;
+        if (i + 1 < nsub && p->slots.size() == 1 && (rc = enqueue_upload(i + 1))) return rc;
         HIP_TRY(hipMemcpyAsync(U_host + (size_t)b0 * u_img, s.u.p, (size_t)nb * u_img, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(V_host + (size_t)b0 * v_img, s.v.p, (size_t)nb * v_img, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipEventRecord(p->done[i], st));
@@ -952,6 +992,7 @@ int lrf_pipe_qmf_encode_rgb_u8_host(lrf_pipe* p, const uint8_t* rgb_host, int64_
     }
     if (rc && p) {
         DevGuard dev_guard_(p->device);
+        (void)hipStreamSynchronize(p->h2d);
         for (auto& s : p->slots) (void)hipStreamSynchronize(s.ctx->stream);
     }
     return rc;
