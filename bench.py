@@ -17,6 +17,10 @@ import os
 import sys
 import time
 
+# more hardware queues than the runtime's default of four: the host->host pipeline's upload stream and two kernel streams
+# must not share a queue with torch's streams (see lrf_amd/__init__.py); read when the HIP runtime initialises
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -11,12 +11,17 @@
 #include <vector>
 
 #include "../../include/lrf_hip.h"
+#include "lrf_gram_kernels.hip"
 #include "lrf_kernels.hip"
 #include "lrf_svd_kernels.hip"
 #include "lrf_bigrank_kernels.hip"
 #include "lrf_bcdw_kernel.hip"
 #include "lrf_qmfn_kernels.hip"
 #include "lrf_anyshape_kernels.hip"
+
+// the planes qmf_encode forms hold YCbCr samples, 0 or in [0.114, 255.5]: all below 2^8 and exact on the grid 2^(8-35)
+// (run_init: selects k_gram64's integer digit extraction; callers with arbitrary X pass LRF_GRAM_EXP_FROM_DATA)
+#define LRF_PLANES_GRAM_EXP 8
 
 static thread_local char g_err[512] = "";
 
@@ -71,7 +76,8 @@ struct lrf_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
-    DevBuf planes, blocks, vf, wf, bf, ppart, qpart, x, sign;
+    DevBuf planes, blocks, gchunks, vf, wf, bf, ppart, qpart, x, sign;
+    DevBuf gpart, gexp; // exact Gram partials (128-bit integers per chunk) and per-matrix grid exponents (lrf_gram_kernels.hip)
     DevBuf sx, sg, svn, swn, suf, smm; // SVD baseline workspace
     DevBuf any_uf, any_vf, any_a, any_b, any_p, any_e2, any_g; // any-shape path (lrf_anyshape_host.inc)
     // host staging for descriptor tables (pinned)
@@ -88,7 +94,7 @@ struct lrf_ctx {
     std::vector<char> table_key; // bytes of the descriptor tables now resident on the device (planes / blocks)
     // the previously used tables: calls that alternate between two geometries (a pipeline's full and last, shorter
     // sub-batch) find both resident and skip the synchronising upload
-    DevBuf planes_alt, blocks_alt;
+    DevBuf planes_alt, blocks_alt, gchunks_alt;
     std::vector<char> table_key_alt;
     unsigned attr_done = 0;      // hipFuncSetAttribute call sites already executed for this context's device (bit per site)
     hipEvent_t planes_done = nullptr; // set by a pipe: recorded after the planes kernel of lrf_qmf_encode_rgb_u8 (input buffer free)
@@ -215,6 +221,7 @@ static int make_geom(int64_t H, int64_t W, ImageGeom* g)
 struct Tables {
     std::vector<PlaneDesc> planes;
     std::vector<BlockDesc> blocks;
+    std::vector<GramChunk> gchunks;
 };
 
 static void add_plane(Tables& t, long x_off, long u_off, long v_off, long u0_off, long v0_off, int M, int R, int sign_off)
@@ -229,6 +236,12 @@ static void add_plane(Tables& t, long x_off, long u_off, long v_off, long u0_off
     pd.sign_off = sign_off;
     int pi = (int)t.planes.size();
     for (int b = 0; b < pd.nblk; b++) t.blocks.push_back(BlockDesc{pi, b * LRF_KC, b, 0});
+    pd.gch0 = (int)t.gchunks.size();
+    pd.ngch = (M + LRF_GRAM_ROWS - 1) / LRF_GRAM_ROWS;
+    for (int g = 0; g < pd.ngch; g++) {
+        const int row0 = g * LRF_GRAM_ROWS;
+        t.gchunks.push_back(GramChunk{pi, row0, pd.gch0 + g, M - row0 < LRF_GRAM_ROWS ? M - row0 : LRF_GRAM_ROWS});
+    }
     t.planes.push_back(pd);
 }
 
@@ -259,6 +272,7 @@ static int table_rp(const Tables& t) { return table_rmax(t) <= 16 ? 16 : LRF_RPB
 static int upload_tables(lrf_ctx* c, const Tables& t)
 {
     // the tables only depend on the call's geometry: skip the (synchronising) upload when nothing changed
+    // (the Gram chunk table follows from the plane table: it is not part of the key)
     size_t pb = t.planes.size() * sizeof(PlaneDesc), bb = t.blocks.size() * sizeof(BlockDesc);
     std::vector<char> key(pb + bb);
     memcpy(key.data(), t.planes.data(), pb);
@@ -266,6 +280,7 @@ static int upload_tables(lrf_ctx* c, const Tables& t)
     if (key == c->table_key) return LRF_OK;
     std::swap(c->planes, c->planes_alt);
     std::swap(c->blocks, c->blocks_alt);
+    std::swap(c->gchunks, c->gchunks_alt);
     c->table_key.swap(c->table_key_alt);
     if (key == c->table_key) return LRF_OK;
     c->table_key.clear();
@@ -273,6 +288,10 @@ static int upload_tables(lrf_ctx* c, const Tables& t)
     if (rc) return rc;
     rc = upload(c, c->blocks, t.blocks.data(), bb);
     if (rc) return rc;
+    rc = upload(c, c->gchunks, t.gchunks.data(), t.gchunks.size() * sizeof(GramChunk));
+    if (rc) return rc;
+    if ((rc = ensure(c, c->gpart, t.gchunks.size() * (size_t)LRF_GRAM_SLOT * sizeof(ulonglong2)))) return rc;
+    if ((rc = ensure(c, c->gexp, t.planes.size() * sizeof(int)))) return rc;
     size_t np = t.planes.size(), nb = t.blocks.size();
     size_t rp = (size_t)table_rp(t), gts = rp == 16 ? (size_t)LRF_GT_STRIDE : (size_t)LRF_GTB_STRIDE;
     if ((rc = ensure(c, c->vf, np * 64 * rp * sizeof(float)))) return rc;
@@ -286,7 +305,9 @@ static int upload_tables(lrf_ctx* c, const Tables& t)
 
 #define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
 
-static int run_init(lrf_ctx* c, const float* X, const Tables& t, const int8_t* sign_dev)
+// gram_exp: the fixed-point grid exponent of the exact Gram matrix (max|x| < 2^gram_exp) when the caller knows it — 8 for the
+// planes of qmf_encode — or LRF_GRAM_EXP_FROM_DATA: one more pass over X finds it per matrix
+static int run_init(lrf_ctx* c, const float* X, const Tables& t, const int8_t* sign_dev, int gram_exp)
 {
     if (!(c->attr_done & (1u << 0))) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_init<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InitLds<8>)));
@@ -295,10 +316,25 @@ static int run_init(lrf_ctx* c, const float* X, const Tables& t, const int8_t* s
         c->attr_done |= 1u << 0;
     }
     int rmax = table_rmax(t), rp = table_rp(t), nplanes = (int)t.planes.size();
+    {
+        Prof p(c, LRF_K_GRAM);
+        if (gram_exp == LRF_GRAM_EXP_FROM_DATA) {
+            hipLaunchKernelGGL(k_gram_exponent, dim3(nplanes), dim3(256), 0, c->stream, X, (const PlaneDesc*)c->planes.p, (int*)c->gexp.p);
+            LAUNCH_CHECK();
+        }
+        if (gram_exp == LRF_PLANES_GRAM_EXP)
+            hipLaunchKernelGGL(k_gram64<true>, dim3((unsigned)t.gchunks.size()), dim3(256), 0, c->stream, X, (const PlaneDesc*)c->planes.p,
+                               (const GramChunk*)c->gchunks.p, (const int*)c->gexp.p, gram_exp, (ulonglong2*)c->gpart.p);
+        else
+            hipLaunchKernelGGL(k_gram64<false>, dim3((unsigned)t.gchunks.size()), dim3(256), 0, c->stream, X, (const PlaneDesc*)c->planes.p,
+                               (const GramChunk*)c->gchunks.p, (const int*)c->gexp.p, gram_exp, (ulonglong2*)c->gpart.p);
+        LAUNCH_CHECK();
+    }
     Prof p(c, LRF_K_INIT);
 #define LRF_LAUNCH_INIT(ZR)                                                                                          \
-    hipLaunchKernelGGL(k_init<ZR>, dim3(nplanes), dim3(256), sizeof(InitLds<ZR>), c->stream, X, (const PlaneDesc*)c->planes.p, \
-                       sign_dev, (float*)c->vf.p, (float*)c->wf.p, c->init_sweeps, rp)
+    hipLaunchKernelGGL(k_init<ZR>, dim3(nplanes), dim3(256), sizeof(InitLds<ZR>), c->stream, (const ulonglong2*)c->gpart.p, \
+                       (const int*)c->gexp.p, gram_exp, (const PlaneDesc*)c->planes.p, sign_dev, (float*)c->vf.p, (float*)c->wf.p, \
+                       c->init_sweeps, rp)
     if (rmax <= 8) LRF_LAUNCH_INIT(8);
     else if (rmax <= 16) LRF_LAUNCH_INIT(16);
     else LRF_LAUNCH_INIT(64);
@@ -466,7 +502,7 @@ void lrf_ctx_destroy(lrf_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     fold_events(c);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-    DevBuf* bufs[] = {&c->planes_alt, &c->blocks_alt, &c->planes, &c->blocks, &c->vf, &c->wf, &c->bf, &c->ppart, &c->qpart, &c->x, &c->sign,
+    DevBuf* bufs[] = {&c->planes_alt, &c->blocks_alt, &c->gchunks_alt, &c->gchunks, &c->gpart, &c->gexp, &c->planes, &c->blocks, &c->vf, &c->wf, &c->bf, &c->ppart, &c->qpart, &c->x, &c->sign,
                       &c->sx, &c->sg, &c->svn, &c->swn, &c->suf, &c->smm,
                       &c->any_uf, &c->any_vf, &c->any_a, &c->any_b, &c->any_p, &c->any_e2, &c->any_g};
     for (DevBuf* b : bufs)
@@ -506,7 +542,7 @@ int lrf_ctx_synchronize(lrf_ctx* c)
 size_t lrf_ctx_workspace_bytes(const lrf_ctx* c)
 {
     if (!c) return 0;
-    const DevBuf* bufs[] = {&c->planes_alt, &c->blocks_alt, &c->planes, &c->blocks, &c->vf, &c->wf, &c->bf, &c->ppart, &c->qpart, &c->x, &c->sign,
+    const DevBuf* bufs[] = {&c->planes_alt, &c->blocks_alt, &c->gchunks_alt, &c->gchunks, &c->gpart, &c->gexp, &c->planes, &c->blocks, &c->vf, &c->wf, &c->bf, &c->ppart, &c->qpart, &c->x, &c->sign,
                             &c->sx, &c->sg, &c->svn, &c->swn, &c->suf, &c->smm,
                             &c->any_uf, &c->any_vf, &c->any_a, &c->any_b, &c->any_p, &c->any_e2, &c->any_g};
     size_t total = 0;
@@ -636,9 +672,9 @@ static int any_bcd_from_init(lrf_ctx* c, const float* X, long x_batch, int B, in
 
 // k_init on the uploaded table, then its factors as fp32 into c->any_e2 (U0 at [0], V0 behind it): offsets from the table
 static int init_to_fp32(lrf_ctx* c, const float* X, const Tables& t, const int8_t* sign, size_t u0_floats, size_t v0_floats, float** U0,
-                        float** V0)
+                        float** V0, int gram_exp)
 {
-    int rc = run_init(c, X, t, sign);
+    int rc = run_init(c, X, t, sign, gram_exp);
     if (rc) return rc;
     if ((rc = ensure(c, c->any_e2, (u0_floats + v0_floats) * sizeof(float)))) return rc;
     *U0 = (float*)c->any_e2.p;
@@ -664,10 +700,10 @@ int lrf_qmf_decompose_f32(lrf_ctx* c, const float* X, int64_t B, int64_t M, int6
     if ((rc = upload_tables(c, t))) return rc;
     if (R > LRF_BIG_TO_ANY_RANK) {
         float *U0, *V0;
-        if ((rc = init_to_fp32(c, X, t, sign, (size_t)B * M * R, (size_t)B * 64 * R, &U0, &V0))) return rc;
+        if ((rc = init_to_fp32(c, X, t, sign, (size_t)B * M * R, (size_t)B * 64 * R, &U0, &V0, LRF_GRAM_EXP_FROM_DATA))) return rc;
         return any_bcd_from_init(c, X, M * 64, (int)B, (int)M, R, K, lo, hi, U0, V0, U, M * R, V, 64L * R);
     }
-    if ((rc = run_init(c, X, t, sign))) return rc;
+    if ((rc = run_init(c, X, t, sign, LRF_GRAM_EXP_FROM_DATA))) return rc;
     return run_bcd(c, X, t, K, lo, hi, 1, nullptr, U, V);
 }
 
@@ -701,7 +737,7 @@ int lrf_qmf_svd_init_f32(lrf_ctx* c, const float* X, int64_t B, int64_t M, int64
     Tables t;
     uniform_tables(t, B, M, R, sign != nullptr);
     if ((rc = upload_tables(c, t))) return rc;
-    if ((rc = run_init(c, X, t, sign))) return rc;
+    if ((rc = run_init(c, X, t, sign, LRF_GRAM_EXP_FROM_DATA))) return rc;
     hipLaunchKernelGGL(k_emit_init, dim3((unsigned)t.blocks.size()), dim3(256), 0, c->stream, X, (const PlaneDesc*)c->planes.p,
                        (const BlockDesc*)c->blocks.p, (const float*)c->vf.p, (const float*)c->wf.p, U0, V0, table_rp(t));
     LAUNCH_CHECK();
@@ -746,14 +782,14 @@ int lrf_qmf_encode_rgb_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_t H, 
     if ((rc = upload_tables(c, t))) return rc;
     if (table_rmax(t) > LRF_BIG_TO_ANY_RANK) {
         float *U0, *V0;
-        if ((rc = init_to_fp32(c, X, t, sign, (size_t)u0c[3], (size_t)v0c[3], &U0, &V0))) return rc;
+        if ((rc = init_to_fp32(c, X, t, sign, (size_t)u0c[3], (size_t)v0c[3], &U0, &V0, LRF_PLANES_GRAM_EXP))) return rc;
         for (int ch = 0; ch < 3; ch++)
             if ((rc = any_bcd_from_init(c, X + g.p[ch].xoff, g.img_floats, (int)B, g.p[ch].M, R[ch], K, lo, hi, U0 + u0c[ch],
                                         V0 + v0c[ch], U + uoff[ch], u_img, V + voff[ch], v_img)))
                 return rc;
         return LRF_OK;
     }
-    if ((rc = run_init(c, X, t, sign))) return rc;
+    if ((rc = run_init(c, X, t, sign, LRF_PLANES_GRAM_EXP))) return rc;
     return run_bcd(c, X, t, K, lo, hi, 1, nullptr, U, V);
 }
 
@@ -804,6 +840,7 @@ struct lrf_pipe {
     hipStream_t h2d = nullptr;      // all uploads, in order: one sub-batch at a time gets the whole link, so the first one
                                     // lands early and its kernels run under the uploads of the following ones
     std::vector<PipeSlot> slots;
+    DevBuf sign;                    // the whole batch's sign vectors, uploaded once per call ahead of the first sub-batch
     std::vector<hipEvent_t> done;   // one per sub-batch of the call in flight
     std::vector<int64_t> first, count;
     size_t next_wait = 0;
@@ -859,6 +896,7 @@ void lrf_pipe_destroy(lrf_pipe* p)
         if (s.rgb_free) (void)hipEventDestroy(s.rgb_free);
     }
     if (p->h2d) (void)hipStreamDestroy(p->h2d);
+    if (p->sign.p) (void)hipFree(p->sign.p);
     for (auto e : p->done) (void)hipEventDestroy(e);
     delete p;
 }
@@ -876,7 +914,7 @@ size_t lrf_pipe_workspace_bytes(const lrf_pipe* p)
     if (!p) return 0;
     size_t total = 0;
     for (const auto& s : p->slots) total += lrf_ctx_workspace_bytes(s.ctx) + s.rgb.cap + s.u.cap + s.v.cap + s.sign.cap;
-    return total;
+    return total + p->sign.cap;
 }
 
 /* images per sub-batch when the caller left it to the library: about 40 MB of input (0.7 ms of a Gen5 x16 link; 32 images of
@@ -931,14 +969,16 @@ int lrf_pipe_qmf_encode_submit(lrf_pipe* p, const uint8_t* rgb_host, int64_t B, 
         int rc2;
         if ((rc2 = pipe_ensure(p, s, s.rgb, (size_t)sb * img_bytes))) return rc2;
         HIP_TRY(hipStreamWaitEvent(p->h2d, s.rgb_free, 0));
-        if (sign_host) {
-            if ((rc2 = pipe_ensure(p, s, s.sign, (size_t)sb * s_img))) return rc2;
-            HIP_TRY(hipMemcpyAsync(s.sign.p, sign_host + (size_t)b0 * s_img, (size_t)nb * s_img, hipMemcpyHostToDevice, p->h2d));
-        }
         HIP_TRY(hipMemcpyAsync(s.rgb.p, rgb_host + (size_t)b0 * img_bytes, (size_t)nb * img_bytes, hipMemcpyHostToDevice, p->h2d));
         HIP_TRY(hipEventRecord(s.h2d_done, p->h2d));
         return LRF_OK;
     };
+    // The sign vectors are read by the initialisation kernel, long after the planes kernel has released the slot's input
+    // buffer: they get a buffer of their own for the whole batch (a few bytes per image), first thing on the upload stream.
+    if (sign_host) {
+        if ((rc = ensure(p->slots[0].ctx, p->sign, (size_t)B * s_img))) return rc;
+        HIP_TRY(hipMemcpyAsync(p->sign.p, sign_host, (size_t)B * s_img, hipMemcpyHostToDevice, p->h2d));
+    }
     if ((rc = enqueue_upload(0))) return rc;
     for (size_t i = 0; i < nsub; i++) {
         PipeSlot& s = p->slots[i % p->slots.size()];
@@ -950,7 +990,7 @@ int lrf_pipe_qmf_encode_submit(lrf_pipe* p, const uint8_t* rgb_host, int64_t B, 
         // With one slot the next upload overwrites the buffer this sub-batch still has to read: it is enqueued after the
         // kernels (which record rgb_free); with more slots it goes first, so that the link never waits for this thread.
         if (i + 1 < nsub && p->slots.size() > 1 && (rc = enqueue_upload(i + 1))) return rc;
-        if ((rc = lrf_qmf_encode_rgb_u8(s.ctx, (const uint8_t*)s.rgb.p, nb, H, W, R, K, lo, hi, sign_host ? (const int8_t*)s.sign.p : nullptr,
+        if ((rc = lrf_qmf_encode_rgb_u8(s.ctx, (const uint8_t*)s.rgb.p, nb, H, W, R, K, lo, hi, sign_host ? (const int8_t*)p->sign.p + (size_t)b0 * s_img : nullptr,
                                         (int8_t*)s.u.p, (int8_t*)s.v.p)))
             return rc;
         if (i + 1 < nsub && p->slots.size() == 1 && (rc = enqueue_upload(i + 1))) return rc;

@@ -1,0 +1,277 @@
+// lrf_gram_kernels.hip — the exact Gram matrix G = X^T X of the 64-column path (input of the SVD initialisation,
+// lrf/factorization/qmf.py:42-48), on the int8 matrix cores.  Included by lrf_api.hip after lrf_kernels.hip.
+//
+// Definition (oracle/lrf_oracle.c lrf_oracle_gram_exact): every element is placed on the fixed-point grid 2^(E-35),
+// n = rint(x 2^(35-E)) with max|x| < 2^E, the integer sums S_ij = sum_m n_mi n_mj are accumulated EXACTLY and rounded once
+// to fp64.  For the matrices qmf_encode forms (fp32 values that are 0 or in [0.114, 255.5]) the grid step holds every
+// value exactly, so G is the exact Gram matrix of X.  Exact means order-free: rows may be summed in any grouping, by any
+// number of workgroups, and the result is the oracle's bit for bit.
+//
+// n (|n| < 2^35) is cut into five 7-bit digits d_a (sign carried by every digit), so that
+//     S_ij = sum_{a,b} 2^(7(a+b)) sum_m d_a[m,i] d_b[m,j]
+// and each digit-pair sum is one chain of v_mfma_i32_16x16x64_i8 (64 rows per instruction, int32 accumulation: nine
+// accumulators per 16 x 16 tile, one per weight a + b, exact for up to 26,000 rows).  One workgroup per chunk of
+// LRF_GRAM_ROWS rows: wave t converts column tile t of each 64-row block to digit bytes in MFMA operand layout (lane
+// (i, kq): column 16 t + i, rows 16 kq .. + 15 — the same bytes serve as A operand (X^T) and as B operand (X)), the four
+// tiles meet in LDS, and each wave owns two or three of the ten upper-triangle tile pairs.  At the end of the chunk the
+// nine weights of every element are folded into one 128-bit integer and written as the chunk's partial; k_init adds the
+// partials of its matrix and rounds.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lrf_internal.h"
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+#define LRF_GRAM_BITS 35
+#define LRF_GRAM_ROWS 1536            // rows per chunk: 24 blocks of 64
+#define LRF_GRAM_PAIRS 10             // upper-triangle pairs of the four 16-column tiles
+#define LRF_GRAM_SLOT (LRF_GRAM_PAIRS * 256) // 128-bit sums per partial, [pair][reg][lane]
+#define LRF_GRAM_EXP_FROM_DATA (-100000)
+
+struct GramChunk {
+    int plane; // index into the PlaneDesc table
+    int row0;  // first row of the chunk
+    int slot;  // partial slot (pd.gch0 + chunk number)
+    int nrows;
+};
+
+// E with max|x| < 2^E per matrix, from the largest magnitude's bit pattern (oracle: lrf_oracle_gram_exponent)
+__global__ __launch_bounds__(256) void k_gram_exponent(const float* __restrict__ X, const PlaneDesc* __restrict__ planes,
+                                                       int* __restrict__ gexp)
+{
+    __shared__ unsigned red[4];
+    const PlaneDesc pd = planes[blockIdx.x];
+    const uint4* xp = reinterpret_cast<const uint4*>(X + pd.x_off);
+    const long n4 = (long)pd.M * 16;
+    unsigned mx = 0;
+    for (long i = threadIdx.x; i < n4; i += 256) {
+        const uint4 v = xp[i];
+        mx = max(max(mx, v.x & 0x7fffffffu), max(v.y & 0x7fffffffu, max(v.z & 0x7fffffffu, v.w & 0x7fffffffu)));
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mx = max(max(red[0], red[1]), max(red[2], red[3]));
+        gexp[blockIdx.x] = mx ? (int)(mx >> 23) - 126 : 0;
+    }
+}
+
+// five signed 7-bit digits of n = clamp(rint(x * scale)), one per byte lane `b` of the packed operand dwords
+__device__ __forceinline__ void gram_digits(float x, double scale, unsigned (&pk)[5], int b)
+{
+    const double lim = 34359738367.0; // 2^35 - 1
+    double r = rint((double)x * scale);
+    r = fmin(fmax(r, -lim), lim);
+    const double hi = trunc(r * 4.76837158203125e-07); // 2^-21: |hi| < 2^14
+    const double lo = fma(-hi, 2097152.0, r);           // exact, |lo| < 2^21, sign of r
+    const int ih = (int)hi, il = (int)lo;
+    const int ah = ih < 0 ? -ih : ih, al = il < 0 ? -il : il;
+    int d[5] = {al & 127, (al >> 7) & 127, al >> 14, ah & 127, ah >> 7};
+    const bool neg = r < 0.0;
+#pragma unroll
+    for (int a = 0; a < 5; a++) {
+        const int v = neg ? -d[a] : d[a];
+        pk[a] |= ((unsigned)v & 0xffu) << (8 * b);
+    }
+}
+
+// The ten upper-triangle tile pairs over the four waves: three pair slots per wave, (tile row, tile column) per slot; waves 2
+// and 3 own two pairs and repeat their last one in the third slot (computed, never stored), so that all waves run the same
+// straight-line code on statically indexed accumulators and only the LDS addresses differ.
+__device__ __forceinline__ void gram_wave_pairs(int wave, int (&ti)[3], int (&tj)[3])
+{
+    ti[0] = wave == 0 ? 0 : wave == 1 ? 0 : wave == 2 ? 1 : 2;  tj[0] = wave == 0 ? 0 : 3;
+    ti[1] = wave == 0 ? 0 : wave == 1 ? 1 : wave == 2 ? 2 : 3;  tj[1] = wave == 0 ? 1 : wave == 1 ? 1 : wave == 2 ? 2 : 3;
+    ti[2] = wave == 0 ? 0 : wave == 1 ? 1 : wave == 2 ? 2 : 3;  tj[2] = wave == 0 ? 2 : wave == 1 ? 2 : wave == 2 ? 2 : 3;
+}
+// pair ids of the slots: wave 0: 0 1 2, wave 1: 3 4 5, wave 2: 6 7 (7), wave 3: 8 9 (9)
+
+// One 64-row block: 25 MFMAs per pair into the nine int32 weight sums of each element, which persist over the whole chunk
+// (5 * 127^2 * LRF_GRAM_ROWS < 2^27).  Folding them into wider sums after every block instead (16 registers per pair instead of
+// 36, three waves per SIMD) was measured slower: 108 quarter-rate 64-bit multiply-adds per block and wave, 0.32 ms per 256
+// images against the 0.49 ms of the whole initialisation it was meant to shorten.
+__device__ __forceinline__ void gram_accumulate(const uint4* __restrict__ lbuf, int lane, const int (&ti)[3], const int (&tj)[3],
+                                                i32x4 (&acc)[3][9])
+{
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+        i32x4 A[5], Bv[5];
+        const uint4* la = lbuf + ti[p] * 5 * 64 + lane;
+        const uint4* lb = lbuf + tj[p] * 5 * 64 + lane;
+#pragma unroll
+        for (int a = 0; a < 5; a++) {
+            const uint4 va = la[a * 64], vb = lb[a * 64];
+            A[a] = (i32x4){(int)va.x, (int)va.y, (int)va.z, (int)va.w};
+            Bv[a] = (i32x4){(int)vb.x, (int)vb.y, (int)vb.z, (int)vb.w};
+        }
+#pragma unroll
+        for (int a = 0; a < 5; a++)
+#pragma unroll
+            for (int b = 0; b < 5; b++) acc[p][a + b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[a], Bv[b], acc[p][a + b], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// sum += (int128)v << sh  (sh < 64), two's complement in (lo, hi)
+__device__ __forceinline__ void add_shifted_i128(unsigned long long& lo, long long& hi, int v, int sh)
+{
+    const long long x = (long long)v;
+    const unsigned long long l = (unsigned long long)x << sh;
+    const long long h = sh ? (x >> (64 - sh)) : (x >> 63);
+    const unsigned long long nl = lo + l;
+    hi += h + (nl < lo ? 1 : 0);
+    lo = nl;
+}
+
+// The five digits of four values (one packed dword per digit) for the matrices qmf_encode forms: every element is 0 or in
+// [2^-4, 2^8) and non-negative, so on the grid 2^-27 (E = 8) n = mantissa << (exponent - 123) exactly, no rounding, no sign.
+__device__ __forceinline__ void gram_digits4_planes(const float (&x)[4], unsigned (&pk)[5])
+{
+    unsigned lo[4], d4[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const unsigned u = __float_as_uint(x[b]), e = u >> 23;
+        const unsigned long long m = e ? (unsigned long long)((u & 0x7fffffu) | 0x800000u) : 0ull;
+        const unsigned long long n = m << ((e - 123u) & 15u);
+        lo[b] = (unsigned)n;
+        d4[b] = (unsigned)(n >> 28);
+    }
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+        pk[a] = ((lo[0] >> (7 * a)) & 127u) | (((lo[1] >> (7 * a)) & 127u) << 8) | (((lo[2] >> (7 * a)) & 127u) << 16) |
+                (((lo[3] >> (7 * a)) & 127u) << 24);
+    pk[4] = d4[0] | (d4[1] << 8) | (d4[2] << 16) | (d4[3] << 24);
+}
+
+// PLANES: the matrices come from k_planes / k_planes16 (fixed_exp = 8, exact integer digit extraction)
+template <bool PLANES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_gram64(const float* __restrict__ X, const PlaneDesc* __restrict__ planes,
+                                                const GramChunk* __restrict__ chunks, const int* __restrict__ gexp, int fixed_exp,
+                                                ulonglong2* __restrict__ Gpart)
+{
+    __shared__ uint4 lds[2][4 * 5 * 64]; // [buffer][tile][digit][lane]: 40 KB
+    const GramChunk ch = chunks[blockIdx.x];
+    const PlaneDesc pd = planes[ch.plane];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+    const int E = fixed_exp != LRF_GRAM_EXP_FROM_DATA ? fixed_exp : gexp[ch.plane];
+    const double scale = scalbn(1.0, LRF_GRAM_BITS - E);
+    const float* Xp = X + pd.x_off + (long)ch.row0 * 64 + 16 * wave + li;
+    const int nrows = ch.nrows, nblk = (nrows + 63) >> 6;
+
+    i32x4 acc[3][9];
+#pragma unroll
+    for (int p = 0; p < 3; p++)
+#pragma unroll
+        for (int w = 0; w < 9; w++) acc[p][w] = (i32x4){0, 0, 0, 0};
+
+    int pti[3], ptj[3];
+    gram_wave_pairs(wave, pti, ptj);
+
+    float vals[16];
+    auto load_block = [&](int blk) {
+        const float* bp = Xp + (long)(blk * 64 + 16 * kq) * 64; // one address per lane, the sixteen rows at immediate offsets
+        if (blk * 64 + 64 <= nrows) {                            // wave-uniform
+#pragma unroll
+            for (int j = 0; j < 16; j++) vals[j] = bp[j * 64];
+        } else { // the last block of a matrix: rows past its end count as zeros
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int row = blk * 64 + 16 * kq + j;
+                const float v = Xp[(long)(row < nrows ? row : nrows - 1) * 64];
+                vals[j] = (row < nrows) ? v : 0.f;
+            }
+        }
+    };
+    load_block(0);
+    for (int blk = 0; blk < nblk; blk++) {
+        unsigned pk[5][4];
+#pragma unroll
+        for (int a = 0; a < 5; a++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) pk[a][q] = 0u;
+        if constexpr (PLANES) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float x4[4] = {vals[4 * q], vals[4 * q + 1], vals[4 * q + 2], vals[4 * q + 3]};
+                unsigned one[5];
+                gram_digits4_planes(x4, one);
+#pragma unroll
+                for (int a = 0; a < 5; a++) pk[a][q] = one[a];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                unsigned one[5] = {0u, 0u, 0u, 0u, 0u};
+                gram_digits(vals[j], scale, one, j & 3);
+#pragma unroll
+                for (int a = 0; a < 5; a++) pk[a][j >> 2] |= one[a];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0); // keep the phases apart: interleaved they overflow the register file
+        if (blk + 1 < nblk) load_block(blk + 1); // wave-uniform; lands under the MFMAs below
+        uint4* lb = lds[blk & 1];
+#pragma unroll
+        for (int a = 0; a < 5; a++) lb[(wave * 5 + a) * 64 + lane] = make_uint4(pk[a][0], pk[a][1], pk[a][2], pk[a][3]);
+        __syncthreads(); // one barrier per block: the other buffer is not written before every wave has passed this point again
+        __builtin_amdgcn_sched_barrier(0);
+        gram_accumulate(lb, lane, pti, ptj, acc);
+    }
+    // fold the nine weights into one 128-bit integer per element and write the chunk's partial: [pair][reg][lane]
+    const int npairs = wave < 2 ? 3 : 2;
+    const int pair0 = wave == 0 ? 0 : wave == 1 ? 3 : wave == 2 ? 6 : 8;
+    ulonglong2* out = Gpart + (long)ch.slot * LRF_GRAM_SLOT;
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+        if (p < npairs) {
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                unsigned long long lo = 0;
+                long long hi = 0;
+#pragma unroll
+                for (int w = 0; w < 9; w++) add_shifted_i128(lo, hi, acc[p][w][reg], 7 * w);
+                out[(pair0 + p) * 256 + reg * 64 + lane] = make_ulonglong2(lo, (unsigned long long)hi);
+            }
+        }
+    }
+}
+
+// signed 128-bit integer (two's complement lo, hi) -> fp64, round to nearest even (oracle: u128_to_double_rne)
+__device__ __forceinline__ double i128_to_double_rne(unsigned long long lo, long long hi)
+{
+    const bool neg = hi < 0;
+    unsigned long long uhi = (unsigned long long)hi;
+    if (neg) {
+        lo = ~lo + 1ull;
+        uhi = ~uhi + (lo == 0ull ? 1ull : 0ull);
+    }
+    if (uhi == 0ull && lo == 0ull) return 0.0;
+    const int nbits = uhi ? 128 - __clzll((long long)uhi) : 64 - __clzll((long long)lo);
+    double v;
+    if (nbits <= 53) {
+        v = (double)lo;
+    } else {
+        const int sh = nbits - 53; // 1..75
+        unsigned long long mant = sh >= 64 ? (uhi >> (sh - 64)) : ((lo >> sh) | (uhi << (64 - sh)));
+        const int rb = sh - 1; // position of the round bit
+        const bool round_bit = rb >= 64 ? ((uhi >> (rb - 64)) & 1ull) : ((lo >> rb) & 1ull);
+        bool sticky;
+        if (rb >= 64) sticky = lo != 0ull || (uhi & ((1ull << (rb - 64)) - 1ull)) != 0ull;
+        else sticky = (lo & ((1ull << rb) - 1ull)) != 0ull;
+        if (round_bit && (sticky || (mant & 1ull))) mant++;
+        v = scalbn((double)mant, sh);
+    }
+    return neg ? -v : v;
+}
+
+// pair id -> (tile row, tile column)
+__device__ __forceinline__ void gram_pair_tiles(int p, int& ti, int& tj)
+{
+    const int TI[10] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 3}, TJ[10] = {0, 1, 2, 3, 1, 2, 3, 2, 3, 3};
+    ti = TI[p];
+    tj = TJ[p];
+}

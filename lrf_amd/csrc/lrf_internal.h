@@ -36,6 +36,7 @@ struct PlaneDesc {
     int blk0, nblk;    // slots in the X^T U partial table
     int native_t2_u;   // ATen native order for `uu @ bb` in update_u: (R-1)*M < 400
     int sign_off;      // offset into the sign vector, or -1
+    int gch0, ngch;    // slots in the Gram partial table (lrf_gram_kernels.hip): one per chunk of LRF_GRAM_ROWS rows
 };
 struct BlockDesc {
     int plane;         // index into the PlaneDesc table

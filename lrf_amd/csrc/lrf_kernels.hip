@@ -293,7 +293,8 @@ struct InitLds {
 };
 
 template <int ZR>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_init(const float* __restrict__ X, const PlaneDesc* __restrict__ planes,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_init(const ulonglong2* __restrict__ Gpart, const int* __restrict__ gexp,
+                                              int fixed_exp, const PlaneDesc* __restrict__ planes,
                                               const int8_t* __restrict__ sign, float* __restrict__ Vf,
                                               float* __restrict__ Wf, int debug_stop, int rp)
 {
@@ -302,69 +303,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     double* G = L.A;
 
     const PlaneDesc pd = planes[blockIdx.x];
-    const float* Xp = X + pd.x_off;
     const int M = pd.M, R = pd.R;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 15, lq = lane >> 4;
 
-    // ---- Gram: wave w takes the 4-row steps s = w, w+4, ...; tile (t,t') holds G[4i+t][4j+t']
+    // ---- Gram matrix: the exact integer partials of k_gram64 (lrf_gram_kernels.hip), one per row chunk, are added as 128-bit
+    // integers (order-free) and rounded once to fp64
     {
-        f64x4 acc[10];
-#pragma unroll
-        for (int i = 0; i < 10; i++) acc[i] = (f64x4){0.0, 0.0, 0.0, 0.0};
-        const int nsteps = (M + 3) >> 2;
-        auto loadx = [&](int s) {
-            int row = 4 * s + lq;
-            f32x4 x = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (s < nsteps && row < M) x = *reinterpret_cast<const f32x4*>(Xp + (long)row * 64 + 4 * li);
-            return x;
-        };
-        // four steps per iteration, the next four prefetched meanwhile (a step past the end loads zeros, and an
-        // MFMA on zeros leaves the accumulators unchanged bit for bit)
-        f32x4 cur[4], nxt[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) cur[u] = loadx(wave + 4 * u);
-        for (int s = wave; s < nsteps; s += 16) {
-#pragma unroll
-            for (int u = 0; u < 4; u++) nxt[u] = loadx(s + 16 + 4 * u);
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                f32x4 x = cur[u];
-                double xd[4] = {(double)x[0], (double)x[1], (double)x[2], (double)x[3]};
-                int n = 0;
-#pragma unroll
-                for (int t = 0; t < 4; t++)
-#pragma unroll
-                    for (int v = t; v < 4; v++) {
-                        acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(xd[t], xd[v], acc[n], 0, 0, 0);
-                        n++;
-                    }
+        const int E = fixed_exp != LRF_GRAM_EXP_FROM_DATA ? fixed_exp : gexp[blockIdx.x];
+        const double back = scalbn(1.0, 2 * (E - LRF_GRAM_BITS));
+        const ulonglong2* gp = Gpart + (long)pd.gch0 * LRF_GRAM_SLOT;
+        for (int e = tid; e < LRF_GRAM_SLOT; e += 256) {
+            unsigned long long lo = 0;
+            long long hi = 0;
+            for (int c = 0; c < pd.ngch; c++) {
+                const ulonglong2 v = gp[(long)c * LRF_GRAM_SLOT + e];
+                const unsigned long long nl = lo + v.x;
+                hi += (long long)v.y + (nl < lo ? 1 : 0);
+                lo = nl;
             }
-#pragma unroll
-            for (int u = 0; u < 4; u++) cur[u] = nxt[u];
+            const double g = i128_to_double_rne(lo, hi) * back;
+            int ti, tj;
+            gram_pair_tiles(e >> 8, ti, tj);
+            const int ln = e & 63, reg = (e >> 6) & 3;
+            const int gi = 16 * ti + 4 * (ln >> 4) + reg, gj = 16 * tj + (ln & 15);
+            G[gi * 64 + gj] = g;
+            G[gj * 64 + gi] = g; // diagonal tiles hold both triangles: the same exact value either way
         }
-        // G = ((g0 + g1) + g2) + g3, in wave order.  f64 C/D layout: col = lane&15, row = (lane>>4) + 4*reg.
-        for (int w = 0; w < 4; w++) {
-            if (wave == w) {
-                int n = 0;
-#pragma unroll
-                for (int t = 0; t < 4; t++)
-#pragma unroll
-                    for (int u = t; u < 4; u++) {
-#pragma unroll
-                        for (int reg = 0; reg < 4; reg++) {
-                            int gi = 4 * (lq + 4 * reg) + t, gj = 4 * li + u;
-                            double v = acc[n][reg];
-                            if (w) v = G[gi * 64 + gj] + v;
-                            G[gi * 64 + gj] = v;
-                            if (t != u) G[gj * 64 + gi] = v;
-                        }
-                        n++;
-                    }
-            }
-            __syncthreads();
-        }
+        __syncthreads();
     }
     if (debug_stop == 1) return;
 

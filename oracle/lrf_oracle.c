@@ -264,6 +264,99 @@ void lrf_oracle_gram_f64(const float* X, long M, long N, double* G)
     free(acc);
 }
 
+/* ---- exact Gram matrix of the 64-column path -------------------------------------------------------
+ * G = X^T X is computed EXACTLY and rounded once: every element x is placed on the fixed-point grid
+ * 2^(E-35), n = rint(x * 2^(35-E)) with max|x| < 2^E (so |n| < 2^35; for the planes qmf_encode forms —
+ * fp32 values that are 0 or in [0.114, 255.5] — no rounding happens for any E <= 8), the integer sums
+ * S_ij = sum_m n_mi n_mj (< 2^87) are accumulated exactly and G_ij = rne_f64(S_ij) * 4^(E-35).
+ * Being exact, the result does not depend on any summation order: the GPU is free to accumulate it with
+ * int8 MFMAs over 7-bit digits, per row chunk, per workgroup, fused into the kernel that produces X.
+ */
+#define LRF_GRAM_BITS 35
+
+/* E with max|x| < 2^E from the largest magnitude's bit pattern: x = 1.m * 2^(e-127) < 2^(e-126); 0 for an all-zero matrix */
+int lrf_oracle_gram_exponent(const float* X, long n)
+{
+    uint32_t mx = 0;
+    for (long i = 0; i < n; i++) {
+        uint32_t b;
+        memcpy(&b, X + i, 4);
+        b &= 0x7fffffffu;
+        if (b > mx) mx = b;
+    }
+    if (mx == 0) return 0;
+    return (int)(mx >> 23) - 126;
+}
+
+/* magnitude (hi:lo, 128 bits) -> double, round to nearest even; spelled out so that the GPU runs the same steps */
+static double u128_to_double_rne(uint64_t hi, uint64_t lo)
+{
+    if (hi == 0 && lo == 0) return 0.0;
+    int nbits = hi ? 128 - __builtin_clzll(hi) : 64 - __builtin_clzll(lo);
+    if (nbits <= 53) return (double)lo;
+    int sh = nbits - 53; /* 1..75 */
+    unsigned __int128 v = ((unsigned __int128)hi << 64) | lo;
+    uint64_t mant = (uint64_t)(v >> sh);
+    unsigned __int128 rem = v & ((((unsigned __int128)1) << sh) - 1), half = ((unsigned __int128)1) << (sh - 1);
+    if (rem > half || (rem == half && (mant & 1))) mant++;
+    return ldexp((double)mant, sh);
+}
+
+void lrf_oracle_gram_exact(const float* X, long M, long N, int E, double* G)
+{
+    /* n = h 2^18 + l with |h| < 2^17, |l| < 2^18 (same sign): the three digit-pair sums of a chunk of <= 2^16 rows fit
+     * int64 exactly (plain 32 x 32 -> 64-bit multiplies, which vectorise); chunks are added as 128-bit integers. */
+    const long CH = 1L << 16;
+    int32_t* h = (int32_t*)malloc(sizeof(int32_t) * (size_t)N);
+    int32_t* l = (int32_t*)malloc(sizeof(int32_t) * (size_t)N);
+    int64_t* hh = (int64_t*)malloc(sizeof(int64_t) * (size_t)N * N * 3);
+    int64_t *hl = hh + N * N, *ll = hl + N * N;
+    __int128* S = (__int128*)calloc((size_t)N * N, sizeof(__int128));
+    const double scale = ldexp(1.0, LRF_GRAM_BITS - E);
+    const long long lim = (1LL << LRF_GRAM_BITS) - 1;
+    for (long m0 = 0; m0 < M; m0 += CH) {
+        long m1 = m0 + CH < M ? m0 + CH : M;
+        memset(hh, 0, sizeof(int64_t) * (size_t)N * N * 3);
+        for (long m = m0; m < m1; m++) {
+            for (long i = 0; i < N; i++) {
+                double r = nearbyint((double)X[m * N + i] * scale);
+                long long n = (r >= (double)lim) ? lim : (r <= -(double)lim) ? -lim : (long long)r;
+                long long a = n < 0 ? -n : n;
+                int32_t hv = (int32_t)(a >> 18), lv = (int32_t)(a & ((1 << 18) - 1));
+                h[i] = n < 0 ? -hv : hv;
+                l[i] = n < 0 ? -lv : lv;
+            }
+            for (long i = 0; i < N; i++) {
+                const int32_t hi_ = h[i], li_ = l[i];
+                int64_t* restrict ph = hh + i * N;
+                int64_t* restrict pm = hl + i * N;
+                int64_t* restrict pl = ll + i * N;
+                for (long j = i; j < N; j++) { /* 32 x 32 -> 64-bit products (vpmuldq) */
+                    ph[j] += (int64_t)hi_ * (int64_t)h[j];
+                    pm[j] += (int64_t)hi_ * (int64_t)l[j] + (int64_t)li_ * (int64_t)h[j];
+                    pl[j] += (int64_t)li_ * (int64_t)l[j];
+                }
+            }
+        }
+        for (long e = 0; e < N * N; e++) S[e] += ((__int128)hh[e] << 36) + ((__int128)hl[e] << 18) + (__int128)ll[e];
+    }
+    const double back = ldexp(1.0, 2 * (E - LRF_GRAM_BITS));
+    for (long i = 0; i < N; i++)
+        for (long j = i; j < N; j++) {
+            __int128 s_ = S[i * N + j];
+            int neg = s_ < 0;
+            unsigned __int128 a = neg ? (unsigned __int128)(-s_) : (unsigned __int128)s_;
+            double v = u128_to_double_rne((uint64_t)(a >> 64), (uint64_t)a) * back;
+            if (neg) v = -v;
+            G[i * N + j] = v;
+            G[j * N + i] = v;
+        }
+    free(S);
+    free(hh);
+    free(l);
+    free(h);
+}
+
 /* Cyclic Jacobi eigen-solve of a symmetric n x n fp64 matrix (n even), round-robin parallel order.
  * A is destroyed (diagonal = eigenvalues); E (n x n, row-major) receives eigenvectors in columns.
  * Each round: rotation parameters for the n/2 disjoint pairs from the current A (upper triangle),
@@ -589,7 +682,8 @@ int lrf_oracle_svd_init(const float* X, long M, long N, int R, const int8_t* sig
 {
     double* G = (double*)malloc(sizeof(double) * N * N);
     float* w0 = (float*)malloc(sizeof(float) * N * R);
-    lrf_oracle_gram_f64(X, M, N, G);
+    /* the 64-column path (the only one init_from_gram takes): the exact Gram matrix */
+    lrf_oracle_gram_exact(X, M, N, lrf_oracle_gram_exponent(X, M * N), G);
     int rc = lrf_oracle_init_from_gram(G, M, N, R, sign, v0, w0);
     if (rc == 0) mm_mkl(X, N, 1, w0, R, 1, u0, R, M, N, R);
     free(G);

@@ -76,6 +76,17 @@ def gram_f64(X):
     return G
 
 
+def gram_exact(X, E=None):
+    """The exact Gram matrix of the 64-column path (rounded once to fp64) and the grid exponent used."""
+    X = _f32(X)
+    M, N = X.shape
+    if E is None:
+        E = int(lib().lrf_oracle_gram_exponent(_ptr(X, _fp), c_long(M * N)))
+    G = np.empty((N, N), np.float64)
+    lib().lrf_oracle_gram_exact(_ptr(X, _fp), c_long(M), c_long(N), c_int(E), _ptr(G, _dp))
+    return G, E
+
+
 def jacobi_f64(A, max_sweeps=30):
     A = np.array(A, dtype=np.float64, order="C")
     n = A.shape[0]
