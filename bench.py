@@ -1,11 +1,16 @@
 #!/usr/bin/env python3
 """bench.py — Mpixels/s of the QMF encoder hot path on MI355X.
 
-One "step" = one pass of the hot path over one batch already resident in HBM: 256 synthetic 512x768x3
-uint8 images -> patch matrices -> SVD initialisation -> 10 BCD iterations -> int8 factors (U, V) in HBM
-(BASELINE.json configs[1]; ranks (7,3,3) = `rank=7`).  The zlib/JSON container is host work and is not
-in the timed region.  With N > 1 every rank encodes its own 256 images (weak scaling, no data-path
-collective); RCCL carries only the barrier, the max-reduction of the time and the final stats gather.
+One "step" = one pass of the hot path over one batch already resident in HBM:
+  --config kodak (default; BASELINE.json configs[1]): 256 synthetic 512x768x3 uint8 images -> patch matrices -> exact Gram
+      matrices -> SVD initialisation -> 10 BCD iterations -> int8 factors (U, V) in HBM; ranks (7,3,3) = `rank=7`.
+  --config clic  (configs[3], per-GPU share): 512 x 1365x2048x3 images per GPU (odd height: 3-row pooling windows, reflect padding).
+  --config svd   (configs[4]): lrf.svd_encode's default branch (RGB, X [M,192], uint8-quantised factors) on the kodak batch.
+The zlib/JSON container is host work and is not in the timed region.  With N > 1 every rank encodes its own batch (weak
+scaling, no data-path collective; `--scaling strong` shards ONE global batch of --batch images over the ranks instead);
+RCCL carries only the barrier, the max-reduction of the time and the final stats gather.
+Next to `value` (inputs and outputs in HBM) the line carries SURVEY 8(d)'s host->host figure (`host_to_host_mpix_s`,
+`pcie_frac`), the decoder (`decode_mpix_s`), the oracle timed on this box's host cores (`cpu_baseline`).
 
   python bench.py --gpus 1 --steps 5 --warmup 2
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -25,13 +30,57 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-H, W, RANKS, NUM_ITERS, BOUNDS = 512, 768, (7, 3, 3), 10, (-16, 15)
+NUM_ITERS, BOUNDS = 10, (-16, 15)
+CONFIGS = {
+    "kodak": {"H": 512, "W": 768, "ranks": (7, 3, 3), "batch": 256,
+              "label": "{B} x 512x768x3 uint8 per GPU, YCbCr 4:2:0, 8x8 patches, ranks (7,3,3), bounds (-16,15), num_iters 10, "
+                       "int8 factors out (BASELINE configs[1])"},
+    "clic": {"H": 1365, "W": 2048, "ranks": (7, 3, 3), "batch": 512,
+             "label": "{B} x 1365x2048x3 uint8 per GPU (CLIC-sized, odd height), YCbCr 4:2:0, 8x8 patches, ranks (7,3,3), "
+                      "bounds (-16,15), num_iters 10, int8 factors out (BASELINE configs[3], one GPU's share of 4096)"},
+    "svd": {"H": 512, "W": 768, "ranks": None, "batch": 256, "svd_rank": 5,
+            "label": "{B} x 512x768x3 uint8 per GPU, svd_encode default branch (RGB, X [6144,192], quality 2.5 -> R = 5, "
+                     "uint8-quantised factors) (BASELINE configs[4])"},
+}
 
 
-def cpu_baseline(images_u8, budget_s=12.0, budget_all_s=10.0):
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _usable_cores():
+    """threads worth starting: the affinity mask, cut by the cgroup CPU quota when there is one"""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    cores = min(cores, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    cores = min(cores, max(1, int(q / p + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return cores
+
+
+def cpu_baseline(images_u8, H, W, ranks, budget_s=12.0, budget_all_s=10.0):
     """The oracle (CPU port of the reference arithmetic) on a bounded sample of the same batch: one thread (`value`),
-    then one thread per core this process may run on (`all_cores`; the oracle is C behind ctypes, which releases the GIL,
-    so plain threads scale and no process is started next to the GPU)."""
+    then one thread per usable core (`all_cores`; the oracle is C behind ctypes, which releases the GIL, so plain
+    threads scale and no process is started next to the GPU)."""
     from concurrent.futures import ThreadPoolExecutor
 
     from oracle import oracle
@@ -40,7 +89,7 @@ def cpu_baseline(images_u8, budget_s=12.0, budget_all_s=10.0):
     def encode_one(b):
         X = oracle.rgb_to_planes(images_u8[b])
         for c in range(3):
-            oracle.qmf_decompose(X[c], RANKS[c], NUM_ITERS, BOUNDS)
+            oracle.qmf_decompose(X[c], ranks[c], NUM_ITERS, BOUNDS)
 
     n, t_used, t0 = 0, 0.0, time.perf_counter()
     for b in range(images_u8.shape[0]):
@@ -50,47 +99,43 @@ def cpu_baseline(images_u8, budget_s=12.0, budget_all_s=10.0):
         if t_used > budget_s and n >= 8:
             break
     per_image = t_used / n
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    # all cores: as many images as fit the budget at perfect scaling, a multiple of the thread count, wrapped over the batch
-    n_all = max(cores, int(budget_all_s / per_image) * cores)
-    n_all = min(n_all, 8 * images_u8.shape[0])
+    cores = _usable_cores()
+    n_all = min(max(cores, int(budget_all_s / per_image) * cores), 8 * images_u8.shape[0])
     with ThreadPoolExecutor(max_workers=cores) as pool:
         list(pool.map(encode_one, range(min(cores, images_u8.shape[0]))))  # warm: threads started, pages touched
         t0 = time.perf_counter()
         list(pool.map(lambda i: encode_one(i % images_u8.shape[0]), range(n_all)))
         t_all = time.perf_counter() - t0
     return {"value": round(n * H * W / t_used / 1e6, 4), "unit": "Mpix/s", "cores": 1, "kind": "port",
-            "sample": f"first {n} images of the batch (512x768x3, ranks {list(RANKS)}, {NUM_ITERS} iters), "
+            "sample": f"first {n} images of the batch ({H}x{W}x3, ranks {list(ranks)}, {NUM_ITERS} iters), "
                       f"oracle/lrf_oracle.c single thread, {t_used:.1f} s",
             "all_cores": {"value": round(n_all * H * W / t_all / 1e6, 3), "unit": "Mpix/s", "cores": cores,
                           "sample": f"{n_all} images of the same batch on {cores} threads (one image per task), {t_all:.1f} s"},
             "ratio_to_reference_per_thread":
                 "the oracle is the reference's arithmetic in scalar C, not the reference's Python: in the build container "
-                "(8-vCPU Xeon 2.1 GHz, one thread) it encodes a 512x768 image at ranks (7,3,3) in 43 ms where the reference's "
-                "torch CPU path takes 91-102 ms (68-90 ms on 8 threads), i.e. it is ~2.1x FASTER per thread than the reference "
-                "(outside SURVEY 8(d)'s +-20 % gate, on the conservative side): GPU/reference ratios are ~2x the GPU/oracle ones",
+                "(8-vCPU Xeon 2.1 GHz, one thread) it encodes a 512x768 image at ranks (7,3,3) in ~60 ms (43 ms before its Gram "
+                "matrix became an exact integer sum) where the reference's torch CPU path takes 91-102 ms (68-90 ms on 8 threads), "
+                "i.e. it is ~1.6x FASTER per thread than the reference (outside SURVEY 8(d)'s +-20 % gate, on the conservative "
+                "side): GPU/reference ratios are ~1.6x the GPU/oracle ones",
             "cpu": _cpu_model(), "host_cores": os.cpu_count()}
 
 
-def host_to_host(torch, _lib, dev_index, images, steps, warmup):
+def host_to_host(torch, _lib, dev_index, images, H, W, ranks, steps, warmup):
     """SURVEY 8(d)'s metric: uint8 batch in page-locked host memory -> int8 factors back in host memory, through the
-    pipelined encoder (lrf_pipe: sub-batches on several streams, H2D / kernels / D2H overlapped)."""
+    pipelined encoder (lrf_pipe: sub-batches on an upload stream and two kernel streams, H2D / kernels / D2H overlapped)."""
     B = images.shape[0]
     host = images.cpu().pin_memory()
     dims = _lib.plane_dims(H, W)
-    Uh = torch.empty((B, sum(d[4] * r for d, r in zip(dims, RANKS))), dtype=torch.int8, pin_memory=True)
-    Vh = torch.empty((B, 64 * sum(RANKS)), dtype=torch.int8, pin_memory=True)
+    Uh = torch.empty((B, sum(d[4] * r for d, r in zip(dims, ranks))), dtype=torch.int8, pin_memory=True)
+    Vh = torch.empty((B, 64 * sum(ranks)), dtype=torch.int8, pin_memory=True)
     slots = int(os.environ.get("LRF_PIPE_SLOTS", "2"))
     sub = int(os.environ.get("LRF_PIPE_SUB", "0"))
     pipe = _lib.Pipe(dev_index, slots=slots, sub_batch=sub)
     for _ in range(max(warmup, 2)):
-        pipe.encode_rgb_host(host, RANKS, NUM_ITERS, BOUNDS[0], BOUNDS[1], out=(Uh, Vh))
+        pipe.encode_rgb_host(host, ranks, NUM_ITERS, BOUNDS[0], BOUNDS[1], out=(Uh, Vh))
     t0 = time.perf_counter()
     for _ in range(steps):
-        pipe.encode_rgb_host(host, RANKS, NUM_ITERS, BOUNDS[0], BOUNDS[1], out=(Uh, Vh))
+        pipe.encode_rgb_host(host, ranks, NUM_ITERS, BOUNDS[0], BOUNDS[1], out=(Uh, Vh))
     dt = (time.perf_counter() - t0) / steps
     # the link itself: the same pinned buffer copied to the device with nothing else going on
     dst = torch.empty_like(images)
@@ -110,17 +155,30 @@ def host_to_host(torch, _lib, dev_index, images, steps, warmup):
                          "63 GB/s (PCIe Gen5 x16); the 0.14 B/pixel of factors return on the other direction of the link",
             "h2d_copy_alone_gbs": round(nbytes / dt_copy / 1e9, 2),
             "frac_of_h2d_copy_alone": round(dt_copy / dt, 4),
-            "pipe": {"slots": slots, "sub_batch": sub or "auto (~40 MB of input)"}}, (Uh, Vh)
+            "pipe": {"slots": slots, "sub_batch": sub or "auto (~40 MB of input)",
+                     "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}}, (Uh, Vh)
 
 
-def _cpu_model():
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                return line.split(":", 1)[1].strip()
-    except OSError:
-        pass
-    return "unknown"
+def decode_leg(torch, _lib, ctx, U, V, H, W, ranks, steps):
+    """qmf_decode's device part (lrf/compression/qmf.py:329-351) on the factors the encoder just produced."""
+    B = U.shape[0]
+    for _ in range(3):
+        out = ctx.decode_rgb(U, V, H, W, ranks)
+    torch.cuda.synchronize()
+    ctx.profile_kernels([_lib.LRF_K_DECODE])
+    ctx.profile_reset()
+    for _ in range(steps):
+        out = ctx.decode_rgb(U, V, H, W, ranks)
+    torch.cuda.synchronize()
+    ms, n = ctx.kernel_time(_lib.LRF_K_DECODE)
+    ctx.profile(False)
+    alg = 3 * B * H * W + U.numel() + V.numel()  # u8 pixels written once + int8 factors read once
+    k = ms / n
+    del out
+    return {"decode_mpix_s": round(B * H * W / (k * 1e-3) / 1e6, 1), "decode_ms_per_batch": round(k, 5),
+            "decode_roofline": {"bound": "hbm", "kernel": "k_decode16" if (H % 16 == 0 and W % 16 == 0) else "k_decode8",
+                                "achieved": round(alg / (k * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                "frac": round(alg / (k * 1e-3) / 1e9 / 8000.0, 4), "algorithmic_bytes_per_launch": alg}}
 
 
 def main():
@@ -128,9 +186,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256, help="images per GPU per step (BASELINE config: 256)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="kodak")
+    ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (0 = the config's: 256 / 512); with "
+                                                         "--scaling strong, the GLOBAL batch sharded over the ranks")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the host->host, decode and CPU legs")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    H, W, RANKS = cfg["H"], cfg["W"], cfg["ranks"]
 
     import torch
     import torch.distributed as dist
@@ -156,17 +220,37 @@ def main():
 
     import lrf_amd
     from lrf_amd import _lib
+    from lrf_amd.sharding import shard_range
 
-    B = args.batch
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    images = torch.randint(0, 256, (B, 3, H, W), dtype=torch.uint8, device=dev, generator=g)
-    dims = _lib.plane_dims(H, W)
-    U = torch.empty((B, sum(d[4] * r for d, r in zip(dims, RANKS))), dtype=torch.int8, device=dev)
-    V = torch.empty((B, 64 * sum(RANKS)), dtype=torch.int8, device=dev)
+    B_cfg = args.batch or cfg["batch"]
+    if args.scaling == "strong":  # one global batch, contiguous per-rank blocks (lrf_amd/sharding.py)
+        lo, hi = shard_range(B_cfg, rank, world)
+        B = hi - lo
+        seed = 1234
+    else:
+        lo, B, seed = 0, B_cfg, 1234 + rank
+    assert B >= 1, "a rank got no images: --batch must be at least the number of GPUs"
+    g = torch.Generator(device=dev).manual_seed(seed)
+    if args.scaling == "strong":  # every rank draws the same global batch and keeps its block: results independent of N
+        full = torch.randint(0, 256, (B_cfg, 3, H, W), dtype=torch.uint8, device=dev, generator=g)
+        images = full[lo:lo + B].clone()
+        del full
+    else:
+        images = torch.randint(0, 256, (B, 3, H, W), dtype=torch.uint8, device=dev, generator=g)
     ctx = _lib.context(dev_index)
+    dims = _lib.plane_dims(H, W)
+    if args.config == "svd":
+        R = cfg["svd_rank"]
 
-    def step():
-        lrf_amd.qmf_factorize_batch(images, RANKS, NUM_ITERS, BOUNDS, out=(U, V))
+        def step():
+            return ctx.svd_encode_rgb(images, R)
+        U = V = None
+    else:
+        U = torch.empty((B, sum(d[4] * r for d, r in zip(dims, RANKS))), dtype=torch.int8, device=dev)
+        V = torch.empty((B, 64 * sum(RANKS)), dtype=torch.int8, device=dev)
+
+        def step():
+            lrf_amd.qmf_factorize_batch(images, RANKS, NUM_ITERS, BOUNDS, out=(U, V))
 
     def barrier():
         torch.cuda.synchronize()
@@ -219,47 +303,64 @@ def main():
             ms, n = ctx.kernel_time(kid)
             if n:
                 kern[name] = {"launches_per_step": n / 2, "avg_ms": ms / n, "ms_per_step": ms / 2}
-        # dominant kernel: one BCD pass (k_bcd).  Algorithmic bytes per launch (DESIGN.md "Roofline"):
-        # X read once (4 B per patch element) + int8 U written once.
-        alg_bytes = B * (sum(d[4] for d in dims) * 64 * 4 + sum(d[4] * r for d, r in zip(dims, RANKS)))
-        bcd_ms = bcd_total_ms / bcd_launches  # live, from the timed region
-        achieved = alg_bytes / (bcd_ms * 1e-3) / 1e9
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tfile):
-            try:
-                traffic = json.load(open(tfile)).get("k_bcd", {}).get("hbm_bytes_per_launch")
-            except (ValueError, OSError):
-                traffic = None
+        ms_step = dt / args.steps * 1e3
+        if args.config == "svd":
+            metric = "Mpixels/sec svd_encode (RGB, 8x8 patch, quality 2.5, uint8 factors)"
+            M = dims[0][4]
+            # whole step: u8 in (3 B/px) + X [M,192] fp32 written once and read twice (Gram, U = X w): 3 + 3 * 12 B/px + factors
+            alg_bytes = B * (3 * H * W + 3 * M * 192 * 4 + (M + 192) * cfg["svd_rank"])
+            achieved = alg_bytes / (ms_step * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "svd_encode (all kernels of the step; no single dominant one)", "achieved": round(achieved, 1),
+                    "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
+                    "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(ms_step, 5)}
+        else:
+            metric = "Mpixels/sec qmf_encode (8x8 patch, r=7, 10 iters)"
+            # dominant kernel: one BCD pass (k_bcd_w).  Algorithmic bytes per launch (DESIGN.md "Roofline"):
+            # X read once (4 B per patch element) + int8 U written once.
+            alg_bytes = B * (sum(d[4] for d in dims) * 64 * 4 + sum(d[4] * r for d, r in zip(dims, RANKS)))
+            bcd_ms = bcd_total_ms / bcd_launches  # live, from the timed region
+            achieved = alg_bytes / (bcd_ms * 1e-3) / 1e9
+            traffic = None
+            tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
+            if args.config == "kodak" and B == 256 and os.path.exists(tfile):
+                try:
+                    traffic = json.load(open(tfile)).get("k_bcd", {}).get("hbm_bytes_per_launch")
+                except (ValueError, OSError):
+                    traffic = None
+            roof = {"bound": "hbm", "kernel": "k_bcd_w", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                    "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(bcd_ms, 5)}
         out = {
-            "metric": "Mpixels/sec qmf_encode (8x8 patch, r=7, 10 iters)",
+            "metric": metric,
             "value": round(value, 2),
             "unit": "Mpix/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "ms_per_step": round(ms_step, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{B} x 512x768x3 uint8 per GPU, YCbCr 4:2:0, 8x8 patches, ranks (7,3,3), "
-                                   f"bounds (-16,15), num_iters 10, int8 factors out (BASELINE configs[1])",
-                       "priming_steps": PRIMING, "global_batch": B * world, "parallelism": f"images sharded over {world} GPU(s), no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": "k_bcd_w", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(achieved / 8000.0, 4), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(bcd_ms, 5)},
+            "config": {"workload": cfg["label"].format(B=B), "priming_steps": PRIMING,
+                       "global_batch": B_cfg if args.scaling == "strong" else B * world,
+                       "parallelism": f"images sharded over {world} GPU(s), no data-path collective"},
+            "roofline": roof,
+            # 75.1 algorithmic bytes per input pixel for the whole encode at K = 10
+            "whole_encode_frac_of_hbm_peak": round(75.1 * total_px / world / dt / 8e12, 4) if args.config != "svd" else None,
             "kernels": {k: {a: round(b, 5) for a, b in v.items()} for k, v in kern.items()},
             "kernels_note": "per-kernel breakdown from a separate untimed pass with every launch bracketed by events; "
                             "roofline.avg_launch_ms is measured inside the timed region (events on the BCD launches only)",
         }
-        if world == 1:
-            h2h, (Uh, Vh) = host_to_host(torch, _lib, dev_index, images, args.steps, args.warmup)
-            assert torch.equal(Uh, U.cpu()) and torch.equal(Vh, V.cpu()), "pipelined factors differ from the one-shot ones"
+        if world == 1 and not args.no_extras and args.config != "svd":
+            out.update(decode_leg(torch, _lib, ctx, U, V, H, W, RANKS, args.steps))
+            Ud, Vd = U.cpu(), V.cpu()
+            h2h, (Uh, Vh) = host_to_host(torch, _lib, dev_index, images, H, W, RANKS, args.steps, args.warmup)
+            assert torch.equal(Uh, Ud) and torch.equal(Vh, Vd), "pipelined factors differ from the one-shot ones"
             out.update(h2h)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(images.cpu().numpy())
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(images[:min(B, 256)].cpu().numpy(), H, W, RANKS)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -1350,6 +1350,108 @@ __global__ __launch_bounds__(256) void k_decode8(const int8_t* __restrict__ U, c
     }
 }
 
+// Fast path of K4 for images whose sides are multiples of 16 and ranks <= 8 (no padding, no crop, exact 2x nearest
+// up-sampling): the inverse of k_planes16's tiling.  One workgroup per 16-row strip x 32 luma patches; a thread owns a
+// 2 x 8 pixel block — two rows of one luma patch, and the four chroma samples under them, one row of one chroma patch —
+// so it loads its three u rows once (two unaligned dwords each), reads V from an LDS table laid out [plane][r][n] (a
+// ds_read_b128 per (r, row) — the lanes of a wave share two patch rows, so the reads are broadcasts) and writes six
+// 8-byte pieces; the 32 lanes of a row pair cover 256 contiguous bytes per store instruction.  Same arithmetic and
+// order as k_decode8 / k_decode (k-ordered fma chain over r from 0; "+ 0.f" / "+ -128.f"; the colour chain; clamp; truncate).
+__global__ __launch_bounds__(256) void k_decode16(const int8_t* __restrict__ U, const int8_t* __restrict__ V, int H, int W,
+                                                  ImageGeom g, int R0, int R1, int R2, long u_img, long v_img,
+                                                  uint8_t* __restrict__ rgb)
+{
+    __shared__ __attribute__((aligned(16))) float Vs[3][8][64];
+    const int8_t* Ui = U + (long)blockIdx.y * u_img;
+    const int8_t* Vi = V + (long)blockIdx.y * v_img;
+    const int8_t* Uc[3] = {Ui, Ui + (long)g.p[0].M * R0, Ui + (long)g.p[0].M * R0 + (long)g.p[1].M * R1};
+    const int8_t* Vc[3] = {Vi, Vi + 64 * R0, Vi + 64 * R0 + 64 * R1};
+    const int Rc[3] = {R0, R1, R2};
+    for (int e = threadIdx.x; e < 3 * 8 * 64; e += 256) {
+        const int c = e >> 9, r = (e >> 6) & 7, n = e & 63;
+        Vs[c][r][n] = (r < Rc[c]) ? (float)Vc[c][n * Rc[c] + r] : 0.f;
+    }
+    __syncthreads();
+    const int nwl = g.p[0].nw, nwc = g.p[1].nw;
+    const int per_strip = (nwl + 31) / 32;
+    const int strip = blockIdx.x / per_strip;
+    const int ww = (blockIdx.x - strip * per_strip) * 32 + (threadIdx.x & 31);
+    const int rp = threadIdx.x >> 5; // row pair inside the strip: image rows 16 strip + 2 rp, + 1
+    if (ww >= nwl) return;
+    // the u rows of the luma patch and of the two chroma patches (zero padded to 8 columns)
+    float u[3][8];
+    const long mrow[3] = {(long)(2 * strip + (rp >> 2)) * nwl + ww, (long)strip * nwc + (ww >> 1), (long)strip * nwc + (ww >> 1)};
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const int R = Rc[c];
+        const int8_t* up = Uc[c] + mrow[c] * R;
+        unsigned lo, hi = 0u;
+        if (R >= 4) { // bytes 0..3 and bytes R-4..R-1 of the row (overlapping): two unaligned dword loads
+            lo = *reinterpret_cast<const unsigned __attribute__((aligned(1)))*>(up);
+            const unsigned h = *reinterpret_cast<const unsigned __attribute__((aligned(1)))*>(up + R - 4);
+            hi = (R > 4) ? h >> (8 * (8 - R)) : 0u;
+        } else {
+            lo = (unsigned)(uint8_t)up[0] | ((unsigned)(uint8_t)up[R > 1 ? 1 : 0] << 8) | ((unsigned)(uint8_t)up[R > 2 ? 2 : 0] << 16);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            u[c][r] = (r < R) ? (float)(int)(int8_t)(lo >> (8 * r)) : 0.f;
+            u[c][4 + r] = (4 + r < R) ? (float)(int)(int8_t)(hi >> (8 * r)) : 0.f;
+        }
+    }
+    // chroma: samples (row 8 strip + rp of the plane = row rp of the patch, columns 4 (ww & 1) .. + 3)
+    float cb[4] = {0.f, 0.f, 0.f, 0.f}, cr[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const f32x4 vb = *reinterpret_cast<const f32x4*>(&Vs[1][r][rp * 8 + 4 * (ww & 1)]);
+        const f32x4 vr = *reinterpret_cast<const f32x4*>(&Vs[2][r][rp * 8 + 4 * (ww & 1)]);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            cb[i] = fmaf(u[1][r], vb[i], cb[i]);
+            cr[i] = fmaf(u[2][r], vr[i], cr[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        cb[i] = cb[i] + -128.f;
+        cr[i] = cr[i] + -128.f;
+    }
+    const float T[3][3] = {{1.0f, 0.0f, 1.402f}, {1.0f, -0.344136f, -0.714136f}, {1.0f, 1.772f, 0.0f}};
+    uint8_t* out = rgb + (long)blockIdx.y * 3 * H * W + (long)(16 * strip + 2 * rp) * W + 8 * ww;
+    const long hw = (long)H * W;
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+        float y[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int n0 = (2 * (rp & 3) + rr) * 8;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(&Vs[0][r][n0]);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(&Vs[0][r][n0 + 4]);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                y[i] = fmaf(u[0][r], v0[i], y[i]);
+                y[4 + i] = fmaf(u[0][r], v1[i], y[4 + i]);
+            }
+        }
+        unsigned long long packed[3] = {0ull, 0ull, 0ull};
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float c0 = y[i] + 0.f, c1 = cb[i >> 1], c2 = cr[i >> 1];
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                float acc = 0.f;
+                acc = fmaf(T[ch][0], c0, acc);
+                acc = fmaf(T[ch][1], c1, acc);
+                acc = fmaf(T[ch][2], c2, acc);
+                acc = fminf(fmaxf(acc, 0.f), 255.f);
+                packed[ch] |= (unsigned long long)(uint8_t)acc << (8 * i); // truncation (to_dtype)
+            }
+        }
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) *reinterpret_cast<unsigned long long*>(out + ch * hw + (long)rr * W) = packed[ch];
+    }
+}
+
 __global__ __launch_bounds__(256) void k_decode(const int8_t* __restrict__ U, const int8_t* __restrict__ V, int H, int W,
                                                 ImageGeom g, int R0, int R1, int R2, long u_img, long v_img,
                                                 uint8_t* __restrict__ rgb)

@@ -19,7 +19,9 @@ def _gpu_usable():
     try:
         import torch
         from lrf_amd import _lib
-        return torch.cuda.is_available() and os.path.exists(_lib.LIB_PATH)
+        # device_count() does not initialise the GPU in this process (is_available() would): the two-rank test starts its
+        # child processes from a parent that has not touched the GPU yet
+        return torch.cuda.device_count() > 0 and os.path.exists(_lib.LIB_PATH)
     except Exception:
         return False
 
@@ -57,6 +59,17 @@ def make_image(spec):
     if kind == "const":
         return torch.full((3, spec["H"], spec["W"]), spec["value"], dtype=torch.uint8)
     raise ValueError(kind)
+
+
+def config3_image(idx):
+    """Image idx (0..23) of the BASELINE config-3 stand-in set (tools/gen_golden.py config3_image): twenty smooth synthetic
+    512x768 images and four 512x768 crops of the natural fixture image."""
+    import torch
+    if idx < 20:
+        return make_image(dict(kind="smooth", seed=100 + idx, H=512, W=768))
+    nat = torch.from_numpy(np.load(os.path.join(GOLDEN, "nat_q7.npz"))["image"])
+    y0, x0 = ((0, 0), (150, 0), (0, 224), (150, 224))[idx - 20]
+    return nat[:, y0:y0 + 512, x0:x0 + 768].contiguous()
 
 
 class Case:

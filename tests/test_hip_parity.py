@@ -181,13 +181,24 @@ def test_full_size_batch_properties(oracle):
     for b in (0, 200):
         Ub, Vb = lrf_amd.qmf_factorize_batch(imgs[b:b + 1].clone(), ranks)
         assert torch.equal(Ub[0], U[b]) and torch.equal(Vb[0], V[b])
-    # oracle spot check
-    b = 255
-    got = split_factors(U[b].cpu().numpy(), V[b].cpu().numpy(), (H, W), ranks)
-    X = oracle.rgb_to_planes(imgs[b].cpu().numpy())
-    for c in range(3):
-        u, v = oracle.qmf_decompose(X[c], ranks[c], 10, (-16, 15))
-        assert np.array_equal(got[2 * c], u.astype(np.int8)) and np.array_equal(got[2 * c + 1], v.astype(np.int8))
+    # the oracle on the host's cores: sixteen images spread over the batch
+    from concurrent.futures import ThreadPoolExecutor
+    sample = list(range(0, 256, 17)) + [255]
+    host = {b: imgs[b].cpu().numpy() for b in sample}
+
+    def oracle_factors(b):
+        X = oracle.rgb_to_planes(host[b])
+        out = []
+        for c in range(3):
+            u, v = oracle.qmf_decompose(X[c], ranks[c], 10, (-16, 15))
+            out += [u.astype(np.int8), v.astype(np.int8)]
+        return out
+
+    with ThreadPoolExecutor(max_workers=16) as pool:
+        want = dict(zip(sample, pool.map(oracle_factors, sample)))
+    for b in sample:
+        got = split_factors(U[b].cpu().numpy(), V[b].cpu().numpy(), (H, W), ranks)
+        assert all(np.array_equal(a, w) for a, w in zip(got, want[b])), b
     # encode -> decode round trip on the whole batch: PSNR of every image close to the reference's figure for
     # i.i.d. uniform noise at these ranks (10.88 dB for the seed-0 image, fixture s1_r7)
     ctx = lrf_amd._lib.context(0)
@@ -411,3 +422,23 @@ def test_ranks_above_32_equal_oracle(oracle):
             for c in range(3):
                 u, v = oracle.qmf_decompose(X[c], ranks[c], 3, (-16, 15))
                 assert np.array_equal(got[2 * c], u.astype(np.int8)) and np.array_equal(got[2 * c + 1], v.astype(np.int8)), (ranks, b, c)
+
+
+@pytest.mark.parametrize("hw,ranks", [((16, 16), [1, 1, 1]), ((48, 80), [3, 2, 1]), ((32, 528), [4, 4, 4]), ((64, 96), [8, 8, 8]),
+                                      ((112, 272), [7, 3, 3]), ((16, 1040), [5, 8, 2])])
+def test_tiled_decode_matches_oracle(hw, ranks, oracle):
+    """k_decode16 (sides multiples of 16, ranks <= 8): random int8 factors over the full int8 range -> the oracle's pixels,
+    for every u-row load form (R < 4, R = 4, 4 < R < 8, R = 8) and widths that are not a multiple of 32 patches."""
+    import lrf_amd
+    from lrf_amd import _lib
+    H, W = hw
+    B = 3
+    dims = _lib.plane_dims(H, W)
+    rng = np.random.default_rng(H * 7 + W)
+    Us = [[rng.integers(-128, 128, (d[4], r), dtype=np.int8) for d, r in zip(dims, ranks)] for _ in range(B)]
+    Vs = [[rng.integers(-16, 16, (64, r), dtype=np.int8) for r in ranks] for _ in range(B)]
+    U = torch.from_numpy(np.stack([np.concatenate([u.ravel() for u in Us[b]]) for b in range(B)])).cuda()
+    V = torch.from_numpy(np.stack([np.concatenate([v.ravel() for v in Vs[b]]) for b in range(B)])).cuda()
+    got = lrf_amd._lib.context(0).decode_rgb(U, V, H, W, ranks).cpu().numpy()
+    for b in range(B):
+        assert np.array_equal(got[b], oracle.planes_to_rgb(Us[b], Vs[b], H, W)), b

@@ -170,6 +170,43 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "sweep":
     gen_sweep()
 
 
+def config3_image(idx, natural=None):
+    """Image idx (0..23) of the BASELINE config-3 stand-in set (the Kodak files are not in the reference repository): twenty
+    smooth synthetic 512x768 images (seeds 100..119) and four 512x768 crops of the reference's natural README figure.
+    tests/conftest.py carries the same recipe."""
+    if idx < 20:
+        return make_image(dict(kind="smooth", seed=100 + idx, H=512, W=768))
+    nat = make_image(dict(kind="natural")) if natural is None else natural
+    y0, x0 = ((0, 0), (150, 0), (0, 224), (150, 224))[idx - 20]
+    return nat[:, y0:y0 + 512, x0:x0 + 768].contiguous()
+
+
+def gen_sweep512():
+    """BASELINE config 3 at its stated size: the reference's (bytes, bpp, PSNR, ranks) for quality 1..32 on three of the 24
+    512x768 images of the stand-in set (one thread, like every fixture)."""
+    torch.set_num_threads(1)
+    ns = ref_loader.load()
+    out = {"images": []}
+    for idx in (0, 10, 20):
+        img = config3_image(idx)
+        recs = []
+        for q in range(1, 33):
+            enc = ns.cqmf.qmf_encode(img, quality=q)
+            dec = ns.cqmf.qmf_decode(enc)
+            mse = torch.mean((img.float() - dec.float()) ** 2, dim=(-3, -2, -1))
+            meta = json.loads(ns.cutils.separate_bytes(enc, 2)[0].decode())
+            recs.append({"quality": q, "bytes": len(enc), "bpp": len(enc) * 8 / (img.shape[-2] * img.shape[-1]),
+                         "psnr": (20 * torch.log10(255 / torch.sqrt(mse))).item(), "ranks": meta["rank"]})
+            print(idx, recs[-1], flush=True)
+        out["images"].append({"index": idx, "image_sha256": hashlib.sha256(img.numpy().tobytes()).hexdigest(), "records": recs})
+    with open(os.path.join(OUT, "sweep512.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "sweep512":
+    gen_sweep512()
+
+
 RGBSPACE_CASES = [
     # qmf_encode(color_space="RGB"): name, image spec, encoder kwargs, store_image
     ("rgbsp_tiny_q4", dict(kind="randint", seed=11, H=64, W=96), dict(quality=4.0), True),
