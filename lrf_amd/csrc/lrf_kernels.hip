@@ -87,19 +87,24 @@ __global__ __launch_bounds__(256) void k_planes(const uint8_t* __restrict__ rgb,
     const uint8_t* img = rgb + (long)blockIdx.y * 3 * H * W;
     float* Xp = X + (long)blockIdx.y * g.img_floats + pg.xoff + (long)hh * pg.nw * 64;
     const int hw = H * W;
-    const bool even2x = (c != 0) && (H == 2 * pg.h) && (W == 2 * pg.w);
-    const bool wordy = (pg.left == 0) && ((W & 7) == 0) && ((reinterpret_cast<uintptr_t>(rgb) & 7) == 0);
+    // F.interpolate(scale 0.5, "area") = adaptive average pooling to (floor(H/2), floor(W/2)): the window of sample (y, x)
+    // starts at (2y, 2x) and is 2 wide for an even side, 3 wide for an odd one (floor(y H / h) = 2y, ceil((y+1) H / h) =
+    // 2y + 2 + [H odd] for every y < h = floor(H/2)), which the general path below evaluates term by term.
+    const int kh = 2 + (H & 1), kw = 2 + (W & 1);
+    typedef uint32_t __attribute__((aligned(1))) u32u;
+    typedef uint64_t __attribute__((aligned(1))) u64u;
     for (int it = threadIdx.x; it < pg.nw * 16; it += 256) {
         const int ww = it >> 4, a = (it >> 1) & 7, b4 = (it & 1) * 4;
         const int y = reflect_idx(hh * 8 + a - pg.top, pg.h);
         const int x0 = ww * 8 + b4 - pg.left;
+        const bool interior = x0 >= 0 && x0 + 3 < pg.w; // no horizontal reflection inside this float4
         f32x4 out;
         if (c == 0) {
-            if (wordy && x0 + 3 < pg.w) {
+            if (interior) { // four consecutive pixels of one row: one (unaligned) word per channel
                 const uint8_t* p0 = img + y * W + x0;
-                uint32_t r4 = *reinterpret_cast<const uint32_t*>(p0);
-                uint32_t g4 = *reinterpret_cast<const uint32_t*>(p0 + hw);
-                uint32_t b4w = *reinterpret_cast<const uint32_t*>(p0 + 2 * hw);
+                uint32_t r4 = *reinterpret_cast<const u32u*>(p0);
+                uint32_t g4 = *reinterpret_cast<const u32u*>(p0 + hw);
+                uint32_t b4w = *reinterpret_cast<const u32u*>(p0 + 2 * hw);
 #pragma unroll
                 for (int i = 0; i < 4; i++)
                     out[i] = ycc_of((float)((r4 >> (8 * i)) & 255u), (float)((g4 >> (8 * i)) & 255u),
@@ -112,28 +117,39 @@ __global__ __launch_bounds__(256) void k_planes(const uint8_t* __restrict__ rgb,
                     out[i] = ycc_of((float)p0[0], (float)p0[hw], (float)p0[2 * hw], 0);
                 }
             }
-        } else if (even2x && wordy && x0 + 3 < pg.w) {
-            // exact 2x2 windows: rows 2y, 2y+1; columns 2x0 .. 2x0+7 (8-byte aligned)
-            uint64_t ch[3][2];
+        } else if (interior) {
+            // windows of samples x0 .. x0+3: rows 2y .. 2y+kh-1, columns 2 x0 .. 2 x0 + 7 (+ 1 more when W is odd): per channel
+            // and row one 8-byte word (unaligned when W is odd) and, for 3-wide windows, the ninth byte.  Window sum in
+            // row-major order from 0, then / kh / kw — the order of the general path below.
+            float sum[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int dy = 0; dy < kh; dy++) {
+                const uint8_t* p0 = img + (long)(2 * y + dy) * W + 2 * x0;
+                uint64_t ch[3];
+                uint32_t ex[3] = {0u, 0u, 0u};
 #pragma unroll
-            for (int k = 0; k < 3; k++)
+                for (int k = 0; k < 3; k++) {
+                    ch[k] = *reinterpret_cast<const u64u*>(p0 + (long)k * hw);
+                    if (kw == 3) ex[k] = p0[(long)k * hw + 8];
+                }
 #pragma unroll
-                for (int rr = 0; rr < 2; rr++)
-                    ch[k][rr] = *reinterpret_cast<const uint64_t*>(img + k * hw + (2 * y + rr) * W + 2 * x0);
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                float sum = 0.f;
-#pragma unroll
-                for (int rr = 0; rr < 2; rr++)
-#pragma unroll
-                    for (int cc = 0; cc < 2; cc++) {
-                        int sh = 8 * (2 * i + cc);
-                        sum = sum + ycc_of((float)((ch[0][rr] >> sh) & 255u), (float)((ch[1][rr] >> sh) & 255u),
-                                           (float)((ch[2][rr] >> sh) & 255u), c);
+                for (int i = 0; i < 4; i++) {
+                    for (int dx = 0; dx < kw; dx++) {
+                        const int col = 2 * i + dx; // 0..8
+                        float r_, g_, b_;
+                        if (col < 8) {
+                            r_ = (float)((ch[0] >> (8 * col)) & 255u);
+                            g_ = (float)((ch[1] >> (8 * col)) & 255u);
+                            b_ = (float)((ch[2] >> (8 * col)) & 255u);
+                        } else {
+                            r_ = (float)ex[0]; g_ = (float)ex[1]; b_ = (float)ex[2];
+                        }
+                        sum[i] = sum[i] + ycc_of(r_, g_, b_, c);
                     }
-                out[i] = sum / 2.f / 2.f;
+                }
             }
-        } else { // general adaptive-average-pool window (odd sizes), row-major fp32 sum, then / kh / kw
+#pragma unroll
+            for (int i = 0; i < 4; i++) out[i] = sum[i] / (float)kh / (float)kw;
+        } else { // general adaptive-average-pool window (reflected columns), row-major fp32 sum, then / kh / kw
             const int h0 = (y * H) / pg.h, h1 = ((y + 1) * H + pg.h - 1) / pg.h;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
