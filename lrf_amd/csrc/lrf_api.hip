@@ -15,6 +15,7 @@
 #include "lrf_kernels.hip"
 #include "lrf_svd_kernels.hip"
 #include "lrf_bigrank_kernels.hip"
+#include "lrf_midrank_kernels.hip"
 #include "lrf_bcdw_kernel.hip"
 #include "lrf_qmfn_kernels.hip"
 #include "lrf_anyshape_kernels.hip"
@@ -22,6 +23,8 @@
 // the planes qmf_encode forms hold YCbCr samples, 0 or in [0.114, 255.5]: all below 2^8 and exact on the grid 2^(8-35)
 // (run_init: selects k_gram64's integer digit extraction; callers with arbitrary X pass LRF_GRAM_EXP_FROM_DATA)
 #define LRF_PLANES_GRAM_EXP 8
+// largest rank of the 64-column BCD kernels (k_bcd_w <= 8, k_bcd <= 16, k_bcd_mid <= 32); above it the any-shape kernels iterate
+#define LRF_BIG_TO_ANY_RANK 32
 
 static thread_local char g_err[512] = "";
 
@@ -393,20 +396,22 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
     }
     if (rp != 16) {
         if (!(c->attr_done & (1u << 2))) {
-            HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_big<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BigLds<0>)));
-            HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_big<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BigLds<1>)));
-            HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_big<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BigLds<2>)));
-            HIP_TRY(hipFuncSetAttribute((const void*)k_vupdate_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BigVLds)));
+            HIP_TRY(hipFuncSetAttribute((const void*)k_vupdate_mid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BigVLds)));
+            HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_mid<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MidLds<0>)));
+            HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_mid<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MidLds<1>)));
+            HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_mid<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MidLds<2>)));
             c->attr_done |= 1u << 2;
         }
     }
     // k_bcd_w (one wave per block, no barriers) is the default; LRF_BCD_WG=1 selects the 4-wave workgroup kernel k_bcd
     static const bool wave_variant = !(getenv("LRF_BCD_WG") && getenv("LRF_BCD_WG")[0] == '1');
-    // gs_row_exact (lrf_bigrank_kernels.hip): all terms of `uu @ bb` exact integers in fp32 for the largest rank of the call
+    if (rmax > LRF_BIG_TO_ANY_RANK) return set_err(LRF_ENOTSUP, "internal: ranks above %d iterate on the any-shape kernels", LRF_BIG_TO_ANY_RANK);
+    // Iterations >= 2 with bounds where every term and partial sum of `uu @ bb` is an exact integer in fp32 for the largest
+    // rank of the call ((R - 1) 64 mx^3 < 2^24): the order of that sum is immaterial, which lets ranks 9..16 (gs_row_lds) and
+    // 17..32 (k_bcd_mid) replace the reference's dependent chain by independent fmas, bit for bit
     const long mx_b = abs(lo) > abs(hi) ? abs(lo) : abs(hi);
-    static const bool exact_off = getenv("LRF_BIG_GENERIC_GS") && getenv("LRF_BIG_GENERIC_GS")[0] == '1';
-    const int big_exact = (!exact_off && (long)(rmax - 1) * 64 * mx_b * mx_b * mx_b < (1L << 24)) ? 1 : 0;
-    gp.exact_int = big_exact; // the same property lets ranks 9..16 of the workgroup kernel drop the ordered chain (gs_row_lds)
+    static const bool exact_off = getenv("LRF_GENERIC_GS") && getenv("LRF_GENERIC_GS")[0] == '1'; // developer comparison aid
+    gp.exact_int = (!exact_off && (long)(rmax - 1) * 64 * mx_b * mx_b * mx_b < (1L << 24)) ? 1 : 0;
     for (int it = 0; it < K; it++) {
         {
             Prof p(c, LRF_K_BCD);
@@ -419,13 +424,13 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
         else                                                                                                         \
             hipLaunchKernelGGL((k_bcd<MODE, RMAX>), dim3(nb), dim3(256), 0, c->stream, X, pl, bl, vf, wf, bf, U0, U, pp, qp, gp); \
     } while (0)
-#define LRF_LAUNCH_BIG(MODE)                                                                                         \
-    hipLaunchKernelGGL((k_bcd_big<MODE>), dim3(nb), dim3(256), sizeof(BigLds<MODE>), c->stream, X, pl, bl, vf, wf, bf, U0, U, pp, qp, \
-                       gp.lo, gp.hi, big_exact)
+            // ranks 17..32: k_bcd_mid (lrf_midrank_kernels.hip)
+#define LRF_LAUNCH_MID(MODE)                                                                                         \
+    hipLaunchKernelGGL((k_bcd_mid<MODE>), dim3(nb), dim3(256), sizeof(MidLds<MODE>), c->stream, X, pl, bl, vf, wf, bf, U0, U, pp, qp, gp)
             if (rp != 16) {
-                if (mode == 1) LRF_LAUNCH_BIG(1);
-                else if (mode == 2) LRF_LAUNCH_BIG(2);
-                else LRF_LAUNCH_BIG(0);
+                if (mode == 1) LRF_LAUNCH_MID(1);
+                else if (mode == 2) LRF_LAUNCH_MID(2);
+                else LRF_LAUNCH_MID(0);
             } else if (rmax <= 8) {
                 if (mode == 1) LRF_LAUNCH_BCD(1, 8);
                 else if (mode == 2) LRF_LAUNCH_BCD(2, 8);
@@ -436,14 +441,14 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
                 else LRF_LAUNCH_BCD(0, 16);
             }
 #undef LRF_LAUNCH_BCD
-#undef LRF_LAUNCH_BIG
+#undef LRF_LAUNCH_MID
             LAUNCH_CHECK();
         }
         {
             Prof p(c, LRF_K_VUPDATE);
             int last = it == K - 1 ? 1 : 0;
             if (rp != 16)
-                hipLaunchKernelGGL(k_vupdate_big, dim3(np), dim3(256), sizeof(BigVLds), c->stream, pl, (const float*)pp,
+                hipLaunchKernelGGL(k_vupdate_mid, dim3(np), dim3(256), sizeof(BigVLds), c->stream, pl, (const float*)pp,
                                    (const float*)qp, vf, bf, V, gp.lo, gp.hi, last);
             else if (rmax <= 8)
                 hipLaunchKernelGGL(k_vupdate<8>, dim3(np), dim3(256), 0, c->stream, pl, (const float*)pp, (const float*)qp, vf, bf,
@@ -653,11 +658,10 @@ static void uniform_tables(Tables& t, int64_t B, int64_t M, int R, bool with_sig
         add_plane(t, b * M * 64, b * M * R, b * 64 * R, b * M * R, b * 64 * R, (int)M, R, with_sign ? (int)(b * R) : -1);
 }
 
-// Ranks 33..64 of the 64-column path: k_bcd_big solves them with the ordered Gauss-Seidel chain on one wave of four and is
-// 2x slower there than the any-shape kernels, which spread the same chain over all waves (tools/dev_big_vs_any.py: ranks
-// (40,20): 20.8 against 11.4 ms per 64 images, (64,32): 45.6 against 20.6).  The initialisation stays with k_init, which mirrors
-// the oracle operation for operation: k_emit_init writes its factors out as fp32 and the any-shape iteration takes over.
-#define LRF_BIG_TO_ANY_RANK 32
+// Ranks 33..64 of the 64-column path iterate on the any-shape kernels, which spread the ordered Gauss-Seidel chain over all
+// waves (a first rank-64 workgroup kernel with the chain on one wave of four was 2x slower there: (40,20) 20.8 against 11.4 ms
+// per 64 images, (64,32) 45.6 against 20.6).  The initialisation stays with k_init, which mirrors the oracle operation for
+// operation: k_emit_init writes its factors out as fp32 and the any-shape iteration takes over.
 
 // one class of B equal-shaped 64-column matrices whose initial factors sit contiguously at U0c / V0c
 static int any_bcd_from_init(lrf_ctx* c, const float* X, long x_batch, int B, int M, int R, int K, int lo, int hi, const float* U0c,
