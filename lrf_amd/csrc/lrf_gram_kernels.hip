@@ -79,8 +79,8 @@ __device__ __forceinline__ void gram_digits(float x, double scale, unsigned (&pk
 }
 
 // The ten upper-triangle tile pairs over the four waves: three pair slots per wave, (tile row, tile column) per slot; waves 2
-// and 3 own two pairs and repeat their last one in the third slot (computed, never stored), so that all waves run the same
-// straight-line code on statically indexed accumulators and only the LDS addresses differ.
+// and 3 own two pairs (their third slot is skipped behind a wave-uniform test), so that all waves run the same code on
+// statically indexed accumulators and only the LDS addresses differ (four per-wave code paths spilled registers).
 __device__ __forceinline__ void gram_wave_pairs(int wave, int (&ti)[3], int (&tj)[3])
 {
     ti[0] = wave == 0 ? 0 : wave == 1 ? 0 : wave == 2 ? 1 : 2;  tj[0] = wave == 0 ? 0 : 3;
@@ -94,10 +94,11 @@ __device__ __forceinline__ void gram_wave_pairs(int wave, int (&ti)[3], int (&tj
 // 36, three waves per SIMD) was measured slower: 108 quarter-rate 64-bit multiply-adds per block and wave, 0.32 ms per 256
 // images against the 0.49 ms of the whole initialisation it was meant to shorten.
 __device__ __forceinline__ void gram_accumulate(const uint4* __restrict__ lbuf, int lane, const int (&ti)[3], const int (&tj)[3],
-                                                i32x4 (&acc)[3][9])
+                                                i32x4 (&acc)[3][9], int npairs)
 {
 #pragma unroll
     for (int p = 0; p < 3; p++) {
+        if (p >= npairs) break; // wave-uniform: waves 2 and 3 own two pairs
         i32x4 A[5], Bv[5];
         const uint4* la = lbuf + ti[p] * 5 * 64 + lane;
         const uint4* lb = lbuf + tj[p] * 5 * 64 + lane;
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         for (int a = 0; a < 5; a++) lb[(wave * 5 + a) * 64 + lane] = make_uint4(pk[a][0], pk[a][1], pk[a][2], pk[a][3]);
         __syncthreads(); // one barrier per block: the other buffer is not written before every wave has passed this point again
         __builtin_amdgcn_sched_barrier(0);
-        gram_accumulate(lb, lane, pti, ptj, acc);
+        gram_accumulate(lb, lane, pti, ptj, acc, wave < 2 ? 3 : 2);
     }
     // fold the nine weights into one 128-bit integer per element and write the chunk's partial: [pair][reg][lane]
     const int npairs = wave < 2 ? 3 : 2;
