@@ -58,8 +58,11 @@ void lrf_ctx_destroy(lrf_ctx* ctx);
 int lrf_ctx_set_stream(lrf_ctx* ctx, void* hip_stream);
 int lrf_ctx_use_own_stream(lrf_ctx* ctx);
 int lrf_ctx_synchronize(lrf_ctx* ctx);
-/* bytes of scratch the context currently holds */
+/* bytes of scratch the context currently holds.  The scratch grows to the largest call seen (2.4 KB per input pixel of the
+ * default branch: a 512 x 1365x2048 batch holds ~9 GB) and is kept for reuse; lrf_ctx_trim waits for the stream and gives
+ * all of it back (the next call allocates again). */
 size_t lrf_ctx_workspace_bytes(const lrf_ctx* ctx);
+int lrf_ctx_trim(lrf_ctx* ctx);
 
 /* Per-kernel timing with HIP events on the context's stream (off by default; when on, every launch
  * of the kernels below is bracketed by events).  kernel ids: LRF_K_*.  lrf_ctx_kernel_time

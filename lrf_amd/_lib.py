@@ -43,6 +43,7 @@ def load():
         lib.lrf_ctx_set_stream.argtypes = [c_void_p, c_void_p]
         lib.lrf_ctx_use_own_stream.argtypes = [c_void_p]
         lib.lrf_ctx_synchronize.argtypes = [c_void_p]
+        lib.lrf_ctx_trim.argtypes = [c_void_p]
         lib.lrf_ctx_profile.argtypes = [c_void_p, c_int]
         lib.lrf_ctx_profile_reset.argtypes = [c_void_p]
         lib.lrf_ctx_profile_kernels.argtypes = [c_void_p, ctypes.c_uint]
@@ -93,7 +94,7 @@ def load():
 
 
 EXPORTS = ["lrf_last_error", "lrf_device_count", "lrf_version", "lrf_ctx_create", "lrf_ctx_destroy", "lrf_ctx_set_stream", "lrf_ctx_use_own_stream",
-           "lrf_ctx_synchronize", "lrf_ctx_workspace_bytes", "lrf_ctx_profile", "lrf_ctx_profile_kernels", "lrf_ctx_kernel_time",
+           "lrf_ctx_synchronize", "lrf_ctx_workspace_bytes", "lrf_ctx_trim", "lrf_ctx_profile", "lrf_ctx_profile_kernels", "lrf_ctx_kernel_time",
            "lrf_ctx_profile_reset", "lrf_malloc", "lrf_free", "lrf_memcpy_h2d", "lrf_memcpy_d2h", "lrf_plane_dims",
            "lrf_qmf_planes_from_rgb_u8", "lrf_qmf_decompose_f32", "lrf_qmf_bcd_f32", "lrf_qmf_svd_init_f32",
            "lrf_qmf_encode_rgb_u8", "lrf_qmf_decode_rgb_u8", "lrf_svd_encode_rgb_u8", "lrf_svd_decode_rgb_u8",
@@ -175,6 +176,10 @@ class Context:
 
     def workspace_bytes(self):
         return int(self._lib.lrf_ctx_workspace_bytes(self._h))
+
+    def trim(self):
+        """waits for the stream and releases the scratch workspace (it is re-grown by the next call)"""
+        check(self._lib.lrf_ctx_trim(self._h))
 
     def profile(self, enable=True):
         check(self._lib.lrf_ctx_profile(self._h, int(bool(enable))))

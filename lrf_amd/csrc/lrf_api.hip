@@ -555,6 +555,24 @@ size_t lrf_ctx_workspace_bytes(const lrf_ctx* c)
     return total;
 }
 
+int lrf_ctx_trim(lrf_ctx* c)
+{
+    if (!c) return set_err(LRF_EINVAL, "ctx is NULL");
+    LRF_ON_DEVICE(c);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    DevBuf* bufs[] = {&c->planes_alt, &c->blocks_alt, &c->gchunks_alt, &c->gchunks, &c->gpart, &c->gexp, &c->planes, &c->blocks, &c->vf,
+                      &c->wf, &c->bf, &c->ppart, &c->qpart, &c->x, &c->sign, &c->sx, &c->sg, &c->svn, &c->swn, &c->suf, &c->smm,
+                      &c->any_uf, &c->any_vf, &c->any_a, &c->any_b, &c->any_p, &c->any_e2, &c->any_g};
+    for (DevBuf* b : bufs) {
+        if (b->p) HIP_TRY(hipFree(b->p));
+        b->p = nullptr;
+        b->cap = 0;
+    }
+    c->table_key.clear();     // the descriptor tables went with their buffers
+    c->table_key_alt.clear();
+    return LRF_OK;
+}
+
 int lrf_ctx_profile(lrf_ctx* c, int enable)
 {
     if (!c) return set_err(LRF_EINVAL, "ctx is NULL");

@@ -442,3 +442,17 @@ def test_tiled_decode_matches_oracle(hw, ranks, oracle):
     got = lrf_amd._lib.context(0).decode_rgb(U, V, H, W, ranks).cpu().numpy()
     for b in range(B):
         assert np.array_equal(got[b], oracle.planes_to_rgb(Us[b], Vs[b], H, W)), b
+
+
+def test_workspace_trim():
+    """lrf_ctx_trim gives the scratch back and the context keeps working (same results)."""
+    import lrf_amd
+    ctx = lrf_amd._lib.context(0)
+    g = torch.Generator().manual_seed(9)
+    imgs = torch.randint(0, 256, (4, 3, 64, 96), dtype=torch.uint8, generator=g).cuda()
+    U, V = lrf_amd.qmf_factorize_batch(imgs, [7, 3, 3])
+    assert ctx.workspace_bytes() > 0
+    ctx.trim()
+    assert ctx.workspace_bytes() == 0
+    U2, V2 = lrf_amd.qmf_factorize_batch(imgs, [7, 3, 3])
+    assert torch.equal(U, U2) and torch.equal(V, V2) and ctx.workspace_bytes() > 0
