@@ -283,129 +283,326 @@ __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, 
     double* Dm = Dp + (long)n * Rc;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int UB = 16 / NCT; // rows per batch and thread in the two passes over the matrix (two batches in flight)
+    constexpr int UB = 16 / NCT; // rows per batch and thread in the passes over the matrix (two batches in flight; 32 / NCT changed nothing)
 
-    // ---- Householder tridiagonalisation; row k of A keeps the reflector v_k
-    for (int k = 0; k < n - 2; k++) {
-        double s = 0.0;
-#pragma unroll
-        for (int c = 0; c < NCT; c++) {
-            const int i = tid + 256 * c;
-            if (i < n && i > k) { const double x = A[(long)k * n + i]; s = fma(x, x, s); }
-        }
-        const double sigma = block_sum(s, Lpart, tid);
-        if (!(sigma > LRF_SIGMA_TINY)) {
-            if (tid == 0) { Ltau[k] = 0.0; Le[k] = 0.0; }
-            continue;
-        }
-        const double x0 = A[(long)k * n + k + 1];
-        const double nrm = sqrt(sigma);
-        const double alpha = (x0 >= 0.0) ? -nrm : nrm;
-        double vi[NCT];
-        s = 0.0;
-#pragma unroll
-        for (int c = 0; c < NCT; c++) {
-            const int i = tid + 256 * c;
-            double v = 0.0;
-            if (i < n) {
-                if (i > k + 1) v = A[(long)k * n + i];
-                else if (i == k + 1) v = x0 - alpha;
-                Lv[i] = v;
-                if (i > k) A[(long)k * n + i] = v;
+    if constexpr (NCT == 1) {
+    // n <= 256 (svd_encode's and the RGB colour space's [M,192] matrices, 16x16 patches): three passes per step over a matrix
+    // that sits in the L2; the fused form below costs one more exposed load round trip per step there (svd_encode of 256 images
+    // 8.07 -> 8.46 ms), so these sizes keep the plain loop.
+        for (int k = 0; k < n - 2; k++) {
+            double s = 0.0;
+    #pragma unroll
+            for (int c = 0; c < NCT; c++) {
+                const int i = tid + 256 * c;
+                if (i < n && i > k) { const double x = A[(long)k * n + i]; s = fma(x, x, s); }
             }
-            vi[c] = v;
-            s = fma(v, v, s);
-        }
-        const double vn = block_sum(s, Lpart, tid); // its barriers publish Lv
-        const double t = 2.0 / vn;
-        if (tid == 0) { Ltau[k] = t; Le[k] = alpha; }
-        double cc[NCT];
-#pragma unroll
-        for (int c = 0; c < NCT; c++) cc[c] = 0.0;
-        // rows in batches of UB, two batches in flight: the loads of the next batch are issued before the current one is
-        // used (a plain loop waits for every single load; the matrix sits in L2 / Infinity Cache, ~1 us away)
-        auto load_rows = [&](int r0, double (&a)[UB][NCT]) __attribute__((always_inline)) {
-#pragma unroll
-            for (int u = 0; u < UB; u++) {
-                const int r = (r0 + u < n) ? r0 + u : n - 1;
-                const double* Ar = A + (long)r * n;
-#pragma unroll
-                for (int c = 0; c < NCT; c++) {
-                    const int i = tid + 256 * c;
-                    a[u][c] = Ar[i < n ? i : n - 1];
+            const double sigma = block_sum(s, Lpart, tid);
+            if (!(sigma > LRF_SIGMA_TINY)) {
+                if (tid == 0) { Ltau[k] = 0.0; Le[k] = 0.0; }
+                continue;
+            }
+            const double x0 = A[(long)k * n + k + 1];
+            const double nrm = sqrt(sigma);
+            const double alpha = (x0 >= 0.0) ? -nrm : nrm;
+            double vi[NCT];
+            s = 0.0;
+    #pragma unroll
+            for (int c = 0; c < NCT; c++) {
+                const int i = tid + 256 * c;
+                double v = 0.0;
+                if (i < n) {
+                    if (i > k + 1) v = A[(long)k * n + i];
+                    else if (i == k + 1) v = x0 - alpha;
+                    Lv[i] = v;
+                    if (i > k) A[(long)k * n + i] = v;
                 }
+                vi[c] = v;
+                s = fma(v, v, s);
             }
-        };
-        auto matvec_rows = [&](int j0, const double (&a)[UB][NCT]) __attribute__((always_inline)) {
-#pragma unroll
-            for (int u = 0; u < UB; u++) {
-                if (j0 + u < n) {
-                    const double vj = Lv[j0 + u];
-#pragma unroll
-                    for (int c = 0; c < NCT; c++) cc[c] = fma(a[u][c], vj, cc[c]);
-                }
-            }
-        };
-        {
-            double a0[UB][NCT], a1[UB][NCT];
-            load_rows(k + 1, a0);
-            for (int j0 = k + 1; j0 < n; j0 += 2 * UB) {
-                load_rows(j0 + UB, a1);
-                matvec_rows(j0, a0);
-                load_rows(j0 + 2 * UB, a0);
-                matvec_rows(j0 + UB, a1);
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < NCT; c++) {
-            const int i = tid + 256 * c;
-            if (!(i < n && i > k)) cc[c] = 0.0;
-        }
-        s = 0.0;
-#pragma unroll
-        for (int c = 0; c < NCT; c++) {
-            cc[c] = t * cc[c];
-            s = fma(cc[c], vi[c], s);
-        }
-        const double Kc = (0.5 * t) * block_sum(s, Lpart, tid);
-        double wi[NCT];
-#pragma unroll
-        for (int c = 0; c < NCT; c++) {
-            const int i = tid + 256 * c;
-            wi[c] = fma(-Kc, vi[c], cc[c]);
-            if (i < n) Lw[i] = wi[c];
-        }
-        __syncthreads();
-        auto update_rows = [&](int r0, const double (&a)[UB][NCT]) __attribute__((always_inline)) {
-#pragma unroll
-            for (int u = 0; u < UB; u++) {
-                const int r = r0 + u;
-                if (r < n) {
-                    const double vr = Lv[r], wr = Lw[r];
-                    double* Ar = A + (long)r * n;
-#pragma unroll
+            const double vn = block_sum(s, Lpart, tid); // its barriers publish Lv
+            const double t = 2.0 / vn;
+            if (tid == 0) { Ltau[k] = t; Le[k] = alpha; }
+            double cc[NCT];
+    #pragma unroll
+            for (int c = 0; c < NCT; c++) cc[c] = 0.0;
+            // rows in batches of UB, two batches in flight: the loads of the next batch are issued before the current one is
+            // used (a plain loop waits for every single load; the matrix sits in L2 / Infinity Cache, ~1 us away)
+            auto load_rows = [&](int r0, double (&a)[UB][NCT]) __attribute__((always_inline)) {
+    #pragma unroll
+                for (int u = 0; u < UB; u++) {
+                    const int r = (r0 + u < n) ? r0 + u : n - 1;
+                    const double* Ar = A + (long)r * n;
+    #pragma unroll
                     for (int c = 0; c < NCT; c++) {
                         const int i = tid + 256 * c;
-                        if (i < n && i > k) {
-                            const bool rc = r >= i; // canonical (row >= column) operand order: the matrix stays exactly symmetric
-                            const double va = rc ? vr : vi[c], wa = rc ? wr : wi[c], vb = rc ? vi[c] : vr, wb = rc ? wi[c] : wr;
-                            Ar[i] = fma(-wa, vb, fma(-va, wb, a[u][c]));
+                        a[u][c] = Ar[i < n ? i : n - 1];
+                    }
+                }
+            };
+            auto matvec_rows = [&](int j0, const double (&a)[UB][NCT]) __attribute__((always_inline)) {
+    #pragma unroll
+                for (int u = 0; u < UB; u++) {
+                    if (j0 + u < n) {
+                        const double vj = Lv[j0 + u];
+    #pragma unroll
+                        for (int c = 0; c < NCT; c++) cc[c] = fma(a[u][c], vj, cc[c]);
+                    }
+                }
+            };
+            {
+                double a0[UB][NCT], a1[UB][NCT];
+                load_rows(k + 1, a0);
+                for (int j0 = k + 1; j0 < n; j0 += 2 * UB) {
+                    load_rows(j0 + UB, a1);
+                    matvec_rows(j0, a0);
+                    load_rows(j0 + 2 * UB, a0);
+                    matvec_rows(j0 + UB, a1);
+                }
+            }
+    #pragma unroll
+            for (int c = 0; c < NCT; c++) {
+                const int i = tid + 256 * c;
+                if (!(i < n && i > k)) cc[c] = 0.0;
+            }
+            s = 0.0;
+    #pragma unroll
+            for (int c = 0; c < NCT; c++) {
+                cc[c] = t * cc[c];
+                s = fma(cc[c], vi[c], s);
+            }
+            const double Kc = (0.5 * t) * block_sum(s, Lpart, tid);
+            double wi[NCT];
+    #pragma unroll
+            for (int c = 0; c < NCT; c++) {
+                const int i = tid + 256 * c;
+                wi[c] = fma(-Kc, vi[c], cc[c]);
+                if (i < n) Lw[i] = wi[c];
+            }
+            __syncthreads();
+            auto update_rows = [&](int r0, const double (&a)[UB][NCT]) __attribute__((always_inline)) {
+    #pragma unroll
+                for (int u = 0; u < UB; u++) {
+                    const int r = r0 + u;
+                    if (r < n) {
+                        const double vr = Lv[r], wr = Lw[r];
+                        double* Ar = A + (long)r * n;
+    #pragma unroll
+                        for (int c = 0; c < NCT; c++) {
+                            const int i = tid + 256 * c;
+                            if (i < n && i > k) {
+                                const bool rc = r >= i; // canonical (row >= column) operand order: the matrix stays exactly symmetric
+                                const double va = rc ? vr : vi[c], wa = rc ? wr : wi[c], vb = rc ? vi[c] : vr, wb = rc ? wi[c] : wr;
+                                Ar[i] = fma(-wa, vb, fma(-va, wb, a[u][c]));
+                            }
                         }
                     }
                 }
+            };
+            { // the loads of the next batch go out before the stores of this one, so a batch waits for one latency, not two
+                double a0[UB][NCT], a1[UB][NCT];
+                load_rows(k + 1, a0);
+                for (int r0 = k + 1; r0 < n; r0 += 2 * UB) {
+                    load_rows(r0 + UB, a1);
+                    update_rows(r0, a0);
+                    load_rows(r0 + 2 * UB, a0);
+                    update_rows(r0 + UB, a1);
+                }
+            }
+            __syncthreads();
+        }
+    } else {
+        // ---- Householder tridiagonalisation; row k of A keeps the reflector v_k.
+        // Two passes over the trailing matrix per step instead of three: the rank-2 update of step k also accumulates the
+        // matrix-vector product of step k + 1 (row k + 1 is updated first, its reflector v_{k+1} formed, then every updated row r
+        // adds A[r][i] v_{k+1}[r] to the next product while it is still in registers), and columns i <= k are neither loaded nor
+        // stored (a thread owns columns; the products and the updates only ever use i > k).
+        double* Lv2 = Ld; // the next reflector (Ld is filled after the loop)
+        auto load_rows = [&](int r0, int k, double (&a)[UB][NCT]) __attribute__((always_inline)) {
+    #pragma unroll
+            for (int u = 0; u < UB; u++) {
+                const int r = (r0 + u < n) ? r0 + u : n - 1;
+                const double* Ar = A + (long)r * n;
+    #pragma unroll
+                for (int c = 0; c < NCT; c++) {
+                    const int i = tid + 256 * c;
+                    a[u][c] = (i < n && i > k) ? Ar[i] : 0.0;
+                }
             }
         };
-        { // the loads of the next batch go out before the stores of this one, so a batch waits for one latency, not two
-            double a0[UB][NCT], a1[UB][NCT];
-            load_rows(k + 1, a0);
-            for (int r0 = k + 1; r0 < n; r0 += 2 * UB) {
-                load_rows(r0 + UB, a1);
-                update_rows(r0, a0);
-                load_rows(r0 + 2 * UB, a0);
-                update_rows(r0 + UB, a1);
+        double vi[NCT], cc[NCT];
+        double t = 0.0;
+        bool have = false; // v_k (Lv, vi), t and cc = sum_{j > k} A[j][.] v_k[j] are ready for the current k
+        for (int k = 0; k < n - 2; k++) {
+            double* Lvk = (k & 1) ? Lv2 : Lv;       // this step's reflector
+            double* Lvn = (k & 1) ? Lv : Lv2;       // the next step's
+            if (!have) {
+                double s = 0.0;
+    #pragma unroll
+                for (int c = 0; c < NCT; c++) {
+                    const int i = tid + 256 * c;
+                    if (i < n && i > k) { const double x = A[(long)k * n + i]; s = fma(x, x, s); }
+                }
+                const double sigma = block_sum(s, Lpart, tid);
+                if (!(sigma > LRF_SIGMA_TINY)) {
+                    if (tid == 0) { Ltau[k] = 0.0; Le[k] = 0.0; }
+                    continue;
+                }
+                const double x0 = A[(long)k * n + k + 1];
+                const double nrm = sqrt(sigma);
+                const double alpha = (x0 >= 0.0) ? -nrm : nrm;
+                s = 0.0;
+    #pragma unroll
+                for (int c = 0; c < NCT; c++) {
+                    const int i = tid + 256 * c;
+                    double v = 0.0;
+                    if (i < n) {
+                        if (i > k + 1) v = A[(long)k * n + i];
+                        else if (i == k + 1) v = x0 - alpha;
+                        Lvk[i] = v;
+                        if (i > k) A[(long)k * n + i] = v;
+                    }
+                    vi[c] = v;
+                    s = fma(v, v, s);
+                }
+                const double vn = block_sum(s, Lpart, tid); // its barriers publish Lvk
+                t = 2.0 / vn;
+                if (tid == 0) { Ltau[k] = t; Le[k] = alpha; }
+    #pragma unroll
+                for (int c = 0; c < NCT; c++) cc[c] = 0.0;
+                // rows in batches of UB, two batches in flight: the loads of the next batch are issued before the current one is used
+                auto matvec_rows = [&](int j0, const double (&a)[UB][NCT]) __attribute__((always_inline)) {
+    #pragma unroll
+                    for (int u = 0; u < UB; u++) {
+                        if (j0 + u < n) {
+                            const double vj = Lvk[j0 + u];
+    #pragma unroll
+                            for (int c = 0; c < NCT; c++) cc[c] = fma(a[u][c], vj, cc[c]);
+                        }
+                    }
+                };
+                double a0[UB][NCT], a1[UB][NCT];
+                load_rows(k + 1, k, a0);
+                for (int j0 = k + 1; j0 < n; j0 += 2 * UB) {
+                    load_rows(j0 + UB, k, a1);
+                    matvec_rows(j0, a0);
+                    load_rows(j0 + 2 * UB, k, a0);
+                    matvec_rows(j0 + UB, a1);
+                }
+            }
+            // ---- w_k = t A v - (t/2 (t A v . v)) v
+    #pragma unroll
+            for (int c = 0; c < NCT; c++) {
+                const int i = tid + 256 * c;
+                if (!(i < n && i > k)) cc[c] = 0.0;
+            }
+            double s = 0.0;
+    #pragma unroll
+            for (int c = 0; c < NCT; c++) {
+                cc[c] = t * cc[c];
+                s = fma(cc[c], vi[c], s);
+            }
+            const double Kc = (0.5 * t) * block_sum(s, Lpart, tid);
+            double wi[NCT];
+    #pragma unroll
+            for (int c = 0; c < NCT; c++) {
+                const int i = tid + 256 * c;
+                wi[c] = fma(-Kc, vi[c], cc[c]);
+                if (i < n) Lw[i] = wi[c];
+            }
+            __syncthreads();
+            // the rank-2 update of one element, canonical (row >= column) operand order: the matrix stays exactly symmetric
+            auto upd = [&](int r, int c, double a) __attribute__((always_inline)) {
+                const int i = tid + 256 * c;
+                const double vr = Lvk[r], wr = Lw[r];
+                const bool rc = r >= i;
+                const double va = rc ? vr : vi[c], wa = rc ? wr : wi[c], vb = rc ? vi[c] : vr, wb = rc ? wi[c] : wr;
+                return fma(-wa, vb, fma(-va, wb, a));
+            };
+            // ---- row k + 1 first: it carries the next reflector
+            bool next = false;
+            double t2 = 0.0, vi2[NCT], cc2[NCT];
+    #pragma unroll
+            for (int c = 0; c < NCT; c++) { vi2[c] = 0.0; cc2[c] = 0.0; }
+            {
+                const int r = k + 1;
+                double rowv[NCT];
+                double s2 = 0.0;
+    #pragma unroll
+                for (int c = 0; c < NCT; c++) {
+                    const int i = tid + 256 * c;
+                    rowv[c] = 0.0;
+                    if (i < n && i > k) {
+                        rowv[c] = upd(r, c, A[(long)r * n + i]);
+                        A[(long)r * n + i] = rowv[c];
+                        if (i > r) s2 = fma(rowv[c], rowv[c], s2);
+                        if (i == r + 1) Lscal[4] = rowv[c];
+                    }
+                }
+                if (k + 1 < n - 2) { // there is a step k + 1
+                    const double sigma2 = block_sum(s2, Lpart, tid); // its barriers publish Lscal[4]
+                    if (sigma2 > LRF_SIGMA_TINY) {
+                        next = true;
+                        const double x0 = Lscal[4];
+                        const double nrm = sqrt(sigma2);
+                        const double alpha = (x0 >= 0.0) ? -nrm : nrm;
+                        double s3 = 0.0;
+    #pragma unroll
+                        for (int c = 0; c < NCT; c++) {
+                            const int i = tid + 256 * c;
+                            double v = 0.0;
+                            if (i < n) {
+                                if (i > r + 1) v = rowv[c];
+                                else if (i == r + 1) v = x0 - alpha;
+                                Lvn[i] = v;
+                                if (i > r) A[(long)r * n + i] = v;
+                            }
+                            vi2[c] = v;
+                            s3 = fma(v, v, s3);
+                        }
+                        const double vn = block_sum(s3, Lpart, tid); // publishes Lvn
+                        t2 = 2.0 / vn;
+                        if (tid == 0) { Ltau[r] = t2; Le[r] = alpha; }
+                    }
+                }
+            }
+            // ---- the remaining rows: update, and (when there is a next reflector) its matrix-vector product on the fly
+            auto update_rows = [&](int r0, const double (&a)[UB][NCT]) __attribute__((always_inline)) {
+    #pragma unroll
+                for (int u = 0; u < UB; u++) {
+                    const int r = r0 + u;
+                    if (r < n) {
+                        double* Ar = A + (long)r * n;
+                        const double vn_r = next ? Lvn[r] : 0.0;
+    #pragma unroll
+                        for (int c = 0; c < NCT; c++) {
+                            const int i = tid + 256 * c;
+                            if (i < n && i > k) {
+                                const double nv = upd(r, c, a[u][c]);
+                                Ar[i] = nv;
+                                cc2[c] = fma(nv, vn_r, cc2[c]);
+                            }
+                        }
+                    }
+                }
+            };
+            { // the loads of the next batch go out before the stores of this one, so a batch waits for one latency, not two
+                double a0[UB][NCT], a1[UB][NCT];
+                load_rows(k + 2, k, a0);
+                for (int r0 = k + 2; r0 < n; r0 += 2 * UB) {
+                    load_rows(r0 + UB, k, a1);
+                    update_rows(r0, a0);
+                    load_rows(r0 + 2 * UB, k, a0);
+                    update_rows(r0 + UB, a1);
+                }
+            }
+            __syncthreads();
+            have = next;
+            if (next) {
+                t = t2;
+    #pragma unroll
+                for (int c = 0; c < NCT; c++) { vi[c] = vi2[c]; cc[c] = cc2[c]; }
             }
         }
-        __syncthreads();
     }
 #pragma unroll
     for (int c = 0; c < NCT; c++) {

@@ -17,7 +17,6 @@
 #include "lrf_bigrank_kernels.hip"
 #include "lrf_midrank_kernels.hip"
 #include "lrf_bcdw_kernel.hip"
-#include "lrf_qmfn_kernels.hip"
 #include "lrf_anyshape_kernels.hip"
 
 // the planes qmf_encode forms hold YCbCr samples, 0 or in [0.114, 255.5]: all below 2^8 and exact on the grid 2^(8-35)
