@@ -130,6 +130,32 @@ int lrf_qmf_bcd_f32(lrf_ctx* ctx, const float* X, int64_t B, int64_t M, int64_t 
                     int lo, int hi, const float* U0, const float* V0, int8_t* U, int8_t* V);
 
 /*
+ * QMF.decompose in its general form — the class as the reference defines it, beyond what qmf_encode asks of it
+ * (lrf/factorization/qmf.py:74-214; the reference's own smoke test, test/test_factorization.py:5-10, is
+ * QMF(rank=5, num_iters=10): unbounded, all three factors).  Float factors out (an unbounded factor need not fit int8).
+ *   bounded / lo / hi   QMF._project (:191-195): round, then clamp to [ceil(lo), floor(hi)] when bounded
+ *   l2_u, l2_v, l1_ratio  the elastic-net terms of CoordinateDescent (:77-91, 154-157, 116-118; soft_thresholding
+ *                       lrf/factorization/utils.py:36-40)
+ *   factors             bit 0: update u, bit 1: update v, bit 2: update w — the affine pair of x ~ w0 + w1 u v^T: the u / v
+ *                       updates then see safe_divide(x - w0, w1) (:104-105, utils.py:18-33) and update_w (:141-147) refits
+ *                       (w0, w1) after them.  The reference solves that least-squares problem with torch.linalg.lstsq
+ *                       (LAPACK); this library with the 2 x 2 normal equations in fp64: everything downstream of an updated
+ *                       w is parity by tolerance (loss to 2e-4), everything else is the reference's bit for bit.
+ *   U0 [B,M,R], V0 [B,N,R] fp32, both or neither: initial factors; NULL = this library's SVD initialisation (sign as in
+ *                       lrf_qmf_decompose_f32).
+ *   U [B,M,R], V [B,N,R], W [B,2] = (w0, w1) fp32, device memory.  eps is the class default 1e-16.  K = 0 returns the
+ *   initial factors.  Runs on the any-shape kernels for every shape (R <= LRF_ANY_MAX_RANK).
+ */
+typedef struct lrf_qmf_opts {
+    int bounded;
+    float lo, hi;
+    double l2_u, l2_v, l1_ratio;
+    int factors;
+} lrf_qmf_opts;
+int lrf_qmf_decompose_ex_f32(lrf_ctx* ctx, const float* X, int64_t B, int64_t M, int64_t N, int R, int K, const lrf_qmf_opts* opts,
+                             const int8_t* sign, const float* U0, const float* V0, float* U, float* V, float* W);
+
+/*
  * The initial factors alone (what SVDInit.forward returns, lrf/factorization/qmf.py:42-71):
  * u0 = U sqrt(s) [B,M,R], v0 = (sqrt(s) Vh)^T [B,N,R], fp32.  Also the arithmetic of svd_encode's
  * lrf/compression/svd.py:179-183 for N == LRF_PATCH_ELEMS.

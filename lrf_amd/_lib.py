@@ -24,6 +24,12 @@ class LrfError(RuntimeError):
     pass
 
 
+class QmfOpts(ctypes.Structure):
+    """lrf_qmf_opts (include/lrf_hip.h)"""
+    _fields_ = [("bounded", c_int), ("lo", ctypes.c_float), ("hi", ctypes.c_float), ("l2_u", ctypes.c_double), ("l2_v", ctypes.c_double),
+                ("l1_ratio", ctypes.c_double), ("factors", c_int)]
+
+
 def load():
     """Loads liblrf_hip.so; raises ImportError when it has not been built (see __graft_entry__.build)."""
     global _lib
@@ -58,6 +64,8 @@ def load():
                                               c_void_p, c_void_p, c_void_p]
         lib.lrf_qmf_bcd_f32.argtypes = [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int,
                                         c_void_p, c_void_p, c_void_p, c_void_p]
+        lib.lrf_qmf_decompose_ex_f32.argtypes = [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_int, ctypes.POINTER(QmfOpts), c_void_p,
+                                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         lib.lrf_qmf_svd_init_f32.argtypes = [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p]
         lib.lrf_qmf_encode_rgb_u8.argtypes = [c_void_p, c_void_p, c_i64, c_i64, c_i64, ctypes.POINTER(c_int), c_int, c_int,
                                               c_int, c_void_p, c_void_p, c_void_p]
@@ -96,7 +104,7 @@ def load():
 EXPORTS = ["lrf_last_error", "lrf_device_count", "lrf_version", "lrf_ctx_create", "lrf_ctx_destroy", "lrf_ctx_set_stream", "lrf_ctx_use_own_stream",
            "lrf_ctx_synchronize", "lrf_ctx_workspace_bytes", "lrf_ctx_trim", "lrf_ctx_profile", "lrf_ctx_profile_kernels", "lrf_ctx_kernel_time",
            "lrf_ctx_profile_reset", "lrf_malloc", "lrf_free", "lrf_memcpy_h2d", "lrf_memcpy_d2h", "lrf_plane_dims",
-           "lrf_qmf_planes_from_rgb_u8", "lrf_qmf_decompose_f32", "lrf_qmf_bcd_f32", "lrf_qmf_svd_init_f32",
+           "lrf_qmf_planes_from_rgb_u8", "lrf_qmf_decompose_f32", "lrf_qmf_decompose_ex_f32", "lrf_qmf_bcd_f32", "lrf_qmf_svd_init_f32",
            "lrf_qmf_encode_rgb_u8", "lrf_qmf_decode_rgb_u8", "lrf_svd_encode_rgb_u8", "lrf_svd_decode_rgb_u8",
            "lrf_qmf_rgbspace_encode_u8", "lrf_qmf_rgbspace_decode_u8",
            "lrf_plane_dims_any", "lrf_qmf_planes_any_u8", "lrf_qmf_decode_any_u8",
@@ -219,6 +227,29 @@ class Context:
         self.use_torch_stream()
         check(self._lib.lrf_qmf_decompose_f32(self._h, _dptr(X), B, M, N, R, K, lo, hi, _dptr(sign), _dptr(U), _dptr(V)))
         return U, V
+
+    def decompose_ex(self, X, R, K, bounds=(None, None), l2=0.0, l1_ratio=0.0, factor=(0, 1, 2), sign=None, init=None):
+        """The general QMF.decompose (lrf_qmf_decompose_ex_f32): X [B,M,N] fp32 CUDA -> fp32 (U [B,M,R], V [B,N,R], W [B,2])."""
+        import torch
+        X = X.float().contiguous()
+        B, M, N = X.shape
+        U = torch.empty((B, M, R), dtype=torch.float32, device=X.device)
+        V = torch.empty((B, N, R), dtype=torch.float32, device=X.device)
+        W = torch.empty((B, 2), dtype=torch.float32, device=X.device)
+        bounded = bounds is not None and tuple(bounds) != (None, None)
+        l2 = tuple(l2) if isinstance(l2, (tuple, list)) else (l2, l2)
+        opts = QmfOpts(int(bounded), float(bounds[0]) if bounded else 0.0, float(bounds[1]) if bounded else 0.0, float(l2[0]), float(l2[1]),
+                       float(l1_ratio), sum(1 << int(f) for f in set(factor)))
+        u0 = v0 = None
+        if init is not None:
+            u0, v0 = (t.to(device=X.device, dtype=torch.float32).contiguous() for t in init)
+            assert tuple(u0.shape) == (B, M, R) and tuple(v0.shape) == (B, N, R)
+        if sign is not None:
+            sign = sign.to(device=X.device, dtype=torch.int8).contiguous()
+        self.use_torch_stream()
+        check(self._lib.lrf_qmf_decompose_ex_f32(self._h, _dptr(X), B, M, N, int(R), int(K), ctypes.byref(opts), _dptr(sign), _dptr(u0),
+                                                 _dptr(v0), _dptr(U), _dptr(V), _dptr(W)))
+        return U, V, W
 
     def bcd(self, X, U0, V0, K, lo, hi):
         import torch

@@ -162,8 +162,18 @@ __device__ __forceinline__ float any_term2(const float* u, const float* __restri
 // Gauss-Seidel over the R columns of 64 rows (lane = row); the rows sit in LDS with an odd pitch.
 // a [B][I][R], bm [B][R][R] (symmetric), F [B][I][R] updated in place.  grid (ceil(I/64), B), 64 threads,
 // dynamic LDS 64 * (R | 1) floats.
+// l1, l2: the elastic-net terms of CoordinateDescent.update_u (qmf.py:116-118; 0 for qmf_encode): numerator
+// soft_thresholding(term1 - term2, l1) (factorization/utils.py:36-40), denominator b_rr + l2.
+__device__ __forceinline__ float any_soft_threshold(float x, float thr)
+{
+    if (thr == 0.f) return x;
+    const float ax = fabsf(x) - thr;
+    const float sg = (x > 0.f) ? 1.f : (x < 0.f ? -1.f : 0.f);
+    return sg * (ax > 0.f ? ax : 0.f);
+}
+
 __global__ __launch_bounds__(64) void k_any_gs(const float* __restrict__ a, const float* __restrict__ bm, float* __restrict__ F,
-                                               int I, int R, int native, float lo, float hi)
+                                               int I, int R, int native, float lo, float hi, float l1, float l2)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* us = reinterpret_cast<float*>(smem);
@@ -183,8 +193,8 @@ __global__ __launch_bounds__(64) void k_any_gs(const float* __restrict__ a, cons
         for (int r = 0; r < R; r++) {
             const float* brow = bb + (long)r * R;
             const float term2 = any_term2(u, brow, r, R, native != 0);
-            const float num = (ab[(long)lane * R + r] - term2) + LRF_EPS;
-            const float den = (brow[r] + 0.f) + LRF_EPS;
+            const float num = any_soft_threshold(ab[(long)lane * R + r] - term2, l1) + LRF_EPS;
+            const float den = (brow[r] + l2) + LRF_EPS;
             const float val = rintf(num / den);
             u[r] = fminf(fmaxf(val, lo), hi);
         }
@@ -194,6 +204,64 @@ __global__ __launch_bounds__(64) void k_any_gs(const float* __restrict__ a, cons
         const int row = e / R, r = e - row * R;
         Fb[e] = us[row * RP + r];
     }
+}
+
+// ---- the affine pair w of the general QMF class (x ~ w0 + w1 u v^T; qmf.py:104-105, 141-147) ---------------------------
+// Xp = safe_divide(X - w0, w1) (factorization/utils.py:18-33: |w1| < eps -> eps * sign(w1)); W [B][2]
+__global__ __launch_bounds__(256) void k_any_affine(const float* __restrict__ X, const float* __restrict__ W, float* __restrict__ Xp, long per)
+{
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= per) return;
+    const float w0 = W[2 * blockIdx.y], w1 = W[2 * blockIdx.y + 1];
+    float den = w1;
+    if (fabsf(w1) < LRF_EPS) den = LRF_EPS * ((w1 > 0.f) ? 1.f : (w1 < 0.f ? -1.f : 0.f));
+    Xp[(long)blockIdx.y * per + e] = (X[(long)blockIdx.y * per + e] - w0) / den;
+}
+
+// update_w, first half: per 64-row tile the fp64 sums of z, z^2, x, x z over its elements, z = u v^T (k-ordered fp32 fma
+// chain like u @ v.mT).  grid (ceil(M/64), B), 256 threads; part [B][ntiles][4].
+__global__ __launch_bounds__(256) void k_any_wstats(const float* __restrict__ X, const float* __restrict__ Uf, const float* __restrict__ Vf,
+                                                    int M, int N, int R, double* __restrict__ part)
+{
+    __shared__ double red[4][4];
+    const int row0 = blockIdx.x * 64, nrows = (M - row0 < 64) ? M - row0 : 64;
+    const float* Xb = X + ((long)blockIdx.y * M + row0) * N;
+    const float* Ub = Uf + ((long)blockIdx.y * M + row0) * R;
+    const float* Vb = Vf + (long)blockIdx.y * N * R;
+    double sz = 0.0, szz = 0.0, sx = 0.0, sxz = 0.0;
+    for (long e = threadIdx.x; e < (long)nrows * N; e += 256) {
+        const int m = (int)(e / N), j = (int)(e - (long)m * N);
+        float z = 0.f;
+        for (int r = 0; r < R; r++) z = fmaf(Ub[(long)m * R + r], Vb[(long)j * R + r], z);
+        const double zd = (double)z, xd = (double)Xb[e];
+        sz += zd; szz = fma(zd, zd, szz); sx += xd; sxz = fma(xd, zd, sxz);
+    }
+    double v[4] = {sz, szz, sx, sxz};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        v[q] = wave_sum(v[q]);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][q] = v[q];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4)
+        part[((long)blockIdx.y * gridDim.x + blockIdx.x) * 4 + threadIdx.x] =
+            ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+// update_w, second half: the tiles' sums added in order, then the least-squares line of x on z by the 2 x 2 normal equations
+// (the reference: torch.linalg.lstsq on [1, z]; equal to ~1e-7 relative, parity by tolerance).  One thread per matrix.
+__global__ void k_any_wsolve(const double* __restrict__ part, int ntiles, double n, float* __restrict__ W, int B)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int t = 0; t < ntiles; t++)
+        for (int q = 0; q < 4; q++) s[q] += part[((long)b * ntiles + t) * 4 + q];
+    const double det = n * s[1] - s[0] * s[0];
+    const double w1 = (det != 0.0) ? (n * s[3] - s[0] * s[2]) / det : 0.0;
+    const double w0 = (s[2] - w1 * s[0]) / n;
+    W[2 * b] = (float)w0;
+    W[2 * b + 1] = (float)w1;
 }
 
 // fp32 factors [B][per] -> int8, matrix b at O + b * o_batch (the fused encode interleaves the planes of an image)

@@ -746,6 +746,42 @@ int lrf_qmf_bcd_f32(lrf_ctx* c, const float* X, int64_t B, int64_t M, int64_t N,
     return run_bcd(c, X, t, K, lo, hi, 2, U0, U, V);
 }
 
+int lrf_qmf_decompose_ex_f32(lrf_ctx* c, const float* X, int64_t B, int64_t M, int64_t N, int R, int K, const lrf_qmf_opts* o,
+                             const int8_t* sign, const float* U0, const float* V0, float* U, float* V, float* W)
+{
+    if (!c || !X || !o || !U || !V || !W) return set_err(LRF_EINVAL, "NULL argument");
+    if ((U0 == nullptr) != (V0 == nullptr)) return set_err(LRF_EINVAL, "U0 and V0 must be given together");
+    if (K < 0) return set_err(LRF_EINVAL, "num_iters must be >= 0");
+    if (o->factors & ~7) return set_err(LRF_EINVAL, "factors: bits 0 (u), 1 (v), 2 (w) only");
+    if (o->bounded && !(o->lo <= o->hi)) return set_err(LRF_EINVAL, "bounds (%g, %g)", (double)o->lo, (double)o->hi);
+    if (!(o->l2_u >= 0.0) || !(o->l2_v >= 0.0) || !(o->l1_ratio >= 0.0 && o->l1_ratio <= 1.0))
+        return set_err(LRF_EINVAL, "l2 must be >= 0 and l1_ratio in [0, 1]");
+    int rc = any_check(B, M, N, R, -128, 127);
+    if (rc) return rc;
+    LRF_ON_DEVICE(c);
+    if ((rc = any_workspace(c, (int)B, (int)M, (int)N, R))) return rc;
+    if (U0) {
+        HIP_TRY(hipMemcpyAsync(c->any_uf.p, U0, (size_t)B * M * R * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->any_vf.p, V0, (size_t)B * N * R * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    } else if ((rc = any_run_init(c, X, (int)B, (int)M, (int)N, R, sign))) {
+        return rc;
+    }
+    // w = [0; 1] (SVDInit, qmf.py:54,70), on the device
+    std::vector<float> w0((size_t)2 * B);
+    for (int64_t b = 0; b < B; b++) { w0[2 * b] = 0.f; w0[2 * b + 1] = 1.f; }
+    if ((rc = upload(c, c->sign, w0.data(), w0.size() * sizeof(float)))) return rc; // the (otherwise unused here) sign scratch holds w
+    float* Wd = (float*)c->sign.p;
+    // qmf.py:154-157: the products in double like Python, fp32 where they meet fp32 tensors; bounds through ceil / floor (:194)
+    const float l1_u = (float)(o->l2_u * o->l1_ratio * (double)N), l2_u = (float)(o->l2_u * (1.0 - o->l1_ratio) * (double)N);
+    const float l1_v = (float)(o->l2_v * o->l1_ratio * (double)M), l2_v = (float)(o->l2_v * (1.0 - o->l1_ratio) * (double)M);
+    const float lo = o->bounded ? ceilf(o->lo) : -INFINITY, hi = o->bounded ? floorf(o->hi) : INFINITY;
+    if ((rc = any_run_bcd_general(c, X, (int)B, (int)M, (int)N, R, K, lo, hi, l1_u, l2_u, l1_v, l2_v, o->factors, Wd))) return rc;
+    HIP_TRY(hipMemcpyAsync(U, c->any_uf.p, (size_t)B * M * R * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(V, c->any_vf.p, (size_t)B * N * R * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(W, Wd, (size_t)2 * B * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    return LRF_OK;
+}
+
 int lrf_qmf_svd_init_f32(lrf_ctx* c, const float* X, int64_t B, int64_t M, int64_t N, int R, const int8_t* sign,
                          float* U0, float* V0)
 {

@@ -10,13 +10,14 @@ from . import _lib
 
 
 class QMF:
-    """X ~ U @ V.T with U, V integer matrices inside `bounds`.
+    """X ~ w0 + w1 * (U @ V.T) with U, V integer matrices, inside `bounds` when given.
 
-    Same constructor and methods as the reference's `lrf.factorization.QMF`.  The HIP path covers what
-    `qmf_encode` uses (lrf/compression/qmf.py:256): factor=(0, 1), l2 = 0, eps = 1e-16, integer bounds
-    within int8; anything else raises NotImplementedError.  Extra keyword (not in the reference):
-    `init_sign` — int8 [R] or [B,R], the sign to impose on each initial component
-    (see include/lrf_hip.h lrf_qmf_decompose_f32).
+    Same constructor and methods as the reference's `lrf.factorization.QMF` (lrf/factorization/qmf.py:167-231), every
+    option of it: `bounds` or none, `factor` subsets (the default (0, 1, 2) also refits the affine pair w every iteration),
+    `l2` / `l1_ratio`.  The configuration `qmf_encode` uses — factor=(0, 1), integer bounds within int8, no penalties — runs on
+    the tuned int8 kernels (lrf_qmf_decompose_f32); everything else on the general entry point (lrf_qmf_decompose_ex_f32,
+    float factors).  Not covered: `eps` other than 1e-16, `num_levels`, a user `project`.  Extra keyword (not in the
+    reference): `init_sign` — int8 [R] or [B,R], the sign to impose on each initial component (include/lrf_hip.h).
     """
 
     def __init__(self, rank: Optional[int], num_iters: int = 10, bounds=(None, None), num_levels=None,
@@ -28,25 +29,33 @@ class QMF:
         self.verbose = verbose
         self.init_sign = kwargs.pop("init_sign", None)
         factor = kwargs.pop("factor", (0, 1, 2))
-        l2 = kwargs.pop("l2", 0)
-        l1_ratio = kwargs.pop("l1_ratio", 0)
+        self.factor = (factor,) if isinstance(factor, int) else tuple(factor)
+        self.l2 = kwargs.pop("l2", 0)
+        self.l1_ratio = kwargs.pop("l1_ratio", 0)
         eps = kwargs.pop("eps", 1e-16)
-        kwargs.pop("project", None)
+        if kwargs.pop("project", None) is not None:
+            raise NotImplementedError("a user `project` is not on the HIP path (QMF builds its own, qmf.py:188)")
         if kwargs:
             raise TypeError(f"unexpected keyword arguments {sorted(kwargs)}")  # CoordinateDescent.__init__ would raise
-        if tuple(factor) != (0, 1) and factor != (0, 1):
-            raise NotImplementedError("only factor=(0, 1) (w fixed at [0; 1]) runs on the HIP path")
-        if l2 not in (0, (0, 0)) or eps != 1e-16 or num_levels:
-            raise NotImplementedError("l2 / l1_ratio / eps / num_levels other than the defaults are not on the HIP path")
-        if self.bounds == (None, None):
-            raise NotImplementedError("unbounded factors are not on the HIP path (int8 factors only)")
-        self._lo, self._hi = math.ceil(self.bounds[0]), math.floor(self.bounds[1])  # qmf.py:194
+        if eps != 1e-16 or num_levels:
+            raise NotImplementedError("eps / num_levels other than the defaults are not on the HIP path")
+        if not set(self.factor) <= {0, 1, 2}:
+            raise ValueError("factor must be a subset of (0, 1, 2)")
+        self._bounded = self.bounds != (None, None)
+        l2 = self.l2 if isinstance(self.l2, (tuple, list)) else (self.l2, self.l2)
+        no_penalty = l2[0] == 0 and l2[1] == 0
+        # what qmf_encode uses (lrf/compression/qmf.py:256): the int8 kernels
+        self._int8_path = (self._bounded and set(self.factor) == {0, 1} and no_penalty and
+                           math.ceil(self.bounds[0]) >= -128 and math.floor(self.bounds[1]) <= 127)
+        if self._bounded:
+            self._lo, self._hi = math.ceil(self.bounds[0]), math.floor(self.bounds[1])  # qmf.py:194
 
     def _ctx(self, x):
         return _lib.context(x.device.index if x.is_cuda else None)
 
     def decompose(self, x: Tensor, *args, **kwargs):
-        """x: [B, M, N].  Returns (u, v, w) like the reference (fp32, integer valued; w = [[0],[1]] per batch)."""
+        """x: [B, M, N].  Returns (u, v, w) like the reference: fp32, integer-valued u and v when num_iters >= 1,
+        w [B, 2, 1] = [[w0], [w1]] ([[0], [1]] unless 2 is in `factor`)."""
         dev_in = x.device
         ctx = self._ctx(x)
         xd = x.float().contiguous()
@@ -56,14 +65,18 @@ class QMF:
         if sign is not None:
             sign = torch.as_tensor(sign, dtype=torch.int8).reshape(-1, self.rank).expand(xd.shape[0], self.rank)
             sign = sign.contiguous().cuda(ctx.device)
+        if self.verbose:
+            print("QMF(verbose=True): per-iteration loss is not reported by the fused HIP path")
         if self.num_iters == 0:
             u, v = ctx.svd_init(xd, self.rank, sign)
-        else:
-            if self.verbose:
-                print("QMF(verbose=True): per-iteration loss is not reported by the fused HIP path")
+            w = torch.cat([torch.zeros_like(xd[..., 0:1, 0:1]), torch.ones_like(xd[..., 0:1, 0:1])], dim=-2)
+        elif self._int8_path:
             u8, v8 = ctx.decompose(xd, self.rank, self.num_iters, self._lo, self._hi, sign)
             u, v = u8.float(), v8.float()
-        w = torch.cat([torch.zeros_like(xd[..., 0:1, 0:1]), torch.ones_like(xd[..., 0:1, 0:1])], dim=-2)
+            w = torch.cat([torch.zeros_like(xd[..., 0:1, 0:1]), torch.ones_like(xd[..., 0:1, 0:1])], dim=-2)
+        else:
+            u, v, w2 = ctx.decompose_ex(xd, self.rank, self.num_iters, self.bounds, self.l2, self.l1_ratio, self.factor, sign)
+            w = w2.reshape(-1, 2, 1)
         return u.to(dev_in), v.to(dev_in), w.to(dev_in)
 
     @staticmethod

@@ -229,6 +229,99 @@ int lrf_oracle_bcd(const float* X, long M, long N, int R, int num_iters,
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * The general CoordinateDescent.forward — lrf/factorization/qmf.py:93-164 with every option the class has:
+ * unbounded or bounded projection (QMF._project :191-195), elastic-net terms l1 / l2 (:116-118,
+ * soft_thresholding factorization/utils.py:36-40), any subset of the factors (0 = u, 1 = v, 2 = w), and the affine pair w
+ * (x ~ w0 + w1 u v^T): x is replaced by safe_divide(x - w0, w1) in the u / v updates (:104-105, utils.py:18-33) and
+ * update_w (:141-147) refits (w0, w1) by least squares of x on [1, u v^T].
+ * update_w: the reference calls torch.linalg.lstsq (LAPACK gelsy on the [M N, 2] design matrix); here the 2 x 2 normal
+ * equations in fp64 — equal to ~1e-7 relative, NOT bit for bit: everything downstream of an updated w is parity by
+ * tolerance.  Without factor 2 (w stays [0; 1], the affine map is the identity) the results are the reference's bit for bit.
+ * ---------------------------------------------------------------------------------------------- */
+static float soft_threshold(float x, float thr)
+{
+    if (thr == 0.f) return x; /* utils.py:37-38 */
+    float ax = fabsf(x) - thr; /* sign(x) * relu(|x| - thr) */
+    float sg = (x > 0.f) ? 1.f : (x < 0.f ? -1.f : 0.f);
+    return sg * (ax > 0.f ? ax : 0.f);
+}
+
+static void update_factor_ex(const float* X, long sxi, long sxk, long rows, long depth, int R,
+                             float* Uo, const float* Vf, int bounded, float lo, float hi, float l1, float l2,
+                             float* a_ws, float* b_ws)
+{
+    mm_torch(X, sxi, sxk, Vf, R, 1, a_ws, R, rows, depth, R);
+    mm_torch(Vf, 1, R, Vf, R, 1, b_ws, R, R, depth, R);
+    if (R == 1) { /* qmf.py:120-124 */
+        for (long i = 0; i < rows; i++)
+            Uo[i] = project((soft_threshold(a_ws[i], l1) + LRF_EPS) / ((b_ws[0] + l2) + LRF_EPS), bounded, lo, hi);
+        return;
+    }
+    int native = aten_uses_native(R - 1, rows, 1);
+    float* uu = (float*)malloc(sizeof(float) * 2 * (size_t)R);
+    float* bb = uu + R;
+    for (int r = 0; r < R; r++) {
+        int n = 0;
+        for (int j = 0; j < R; j++)
+            if (j != r) bb[n++] = b_ws[j * R + r];
+        float den = (b_ws[r * R + r] + l2) + LRF_EPS; /* qmf.py:117-118 */
+        for (long i = 0; i < rows; i++) {
+            n = 0;
+            for (int j = 0; j < R; j++)
+                if (j != r) uu[n++] = Uo[i * R + j];
+            float term2 = native ? dot_native(uu, bb, R - 1) : dot_mkl_n1(uu, bb, R - 1);
+            float num = soft_threshold(a_ws[i * R + r] - term2, l1); /* qmf.py:116 */
+            Uo[i * R + r] = project((num + LRF_EPS) / den, bounded, lo, hi);
+        }
+    }
+    free(uu);
+}
+
+/* factors: bit 0 = update u, bit 1 = update v, bit 2 = update w.  l2u, l2v: the `l2` pair; l1_ratio as in the class
+ * (l1_u = l2u * l1_ratio * N, l2_u = l2u * (1 - l1_ratio) * N, and with M for v: qmf.py:154-157, evaluated in double like
+ * Python and rounded to fp32 where they meet fp32 tensors).  W[2] = (w0, w1), in: the initial pair ([0; 1] from SVDInit). */
+int lrf_oracle_bcd_ex(const float* X, long M, long N, int R, int num_iters, int bounded, float lo, float hi,
+                      double l2u, double l2v, double l1_ratio, int factors, float* U, float* V, float* W)
+{
+    if (R < 1) return -1;
+    long mx = M > N ? M : N;
+    float* a_ws = (float*)malloc(sizeof(float) * ((size_t)mx * R + (size_t)R * R));
+    float* Xp = (float*)malloc(sizeof(float) * (size_t)M * N);
+    if (!a_ws || !Xp) return -1;
+    float* b_ws = a_ws + (size_t)mx * R;
+    if (bounded) { lo = ceilf(lo); hi = floorf(hi); }
+    const float l1_u = (float)(l2u * l1_ratio * (double)N), l2_u = (float)(l2u * (1.0 - l1_ratio) * (double)N);
+    const float l1_v = (float)(l2v * l1_ratio * (double)M), l2_v = (float)(l2v * (1.0 - l1_ratio) * (double)M);
+    for (int it = 0; it < num_iters; it++) {
+        /* x <- safe_divide(x - w0, w1): utils.py:18-33 (|w1| < eps -> eps * sign(w1)) */
+        const float w0 = W[0], w1 = W[1];
+        float den = w1;
+        if (fabsf(w1) < LRF_EPS) den = LRF_EPS * ((w1 > 0.f) ? 1.f : (w1 < 0.f ? -1.f : 0.f));
+        for (long e = 0; e < M * N; e++) Xp[e] = (X[e] - w0) / den;
+        if (factors & 1) update_factor_ex(Xp, N, 1, M, N, R, U, V, bounded, lo, hi, l1_u, l2_u, a_ws, b_ws);
+        if (factors & 2) update_factor_ex(Xp, 1, N, N, M, R, V, U, bounded, lo, hi, l1_v, l2_v, a_ws, b_ws);
+        if (factors & 4) { /* update_w: least squares of x on [1, z], z = u v^T (fp32 product, k-ordered like u @ v.mT) */
+            double n = (double)M * (double)N, sz = 0, szz = 0, sx = 0, sxz = 0;
+            for (long m = 0; m < M; m++)
+                for (long j = 0; j < N; j++) {
+                    float z = 0.f;
+                    for (int r = 0; r < R; r++) z = fmaf(U[m * R + r], V[j * R + r], z);
+                    double zd = (double)z, xd = (double)X[m * N + j];
+                    sz += zd; szz += zd * zd; sx += xd; sxz += xd * zd;
+                }
+            double det = n * szz - sz * sz;
+            double w1n = (det != 0.0) ? (n * sxz - sz * sx) / det : 0.0;
+            double w0n = (sx - w1n * sz) / n;
+            W[0] = (float)w0n;
+            W[1] = (float)w1n;
+        }
+    }
+    free(Xp);
+    free(a_ws);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
  * SVD initialisation (this project's algorithm; replaces LAPACK at lrf/factorization/qmf.py:44-48)
  * ---------------------------------------------------------------------------------------------- */
 

@@ -123,9 +123,10 @@ def test_qmf_class_api(oracle):
     rec = lrf_amd.QMF.reconstruct(u, v)
     assert torch.allclose(qmf.forward(x), rec)
     with pytest.raises(NotImplementedError):
-        lrf_amd.QMF(rank=3)  # unbounded
-    with pytest.raises(NotImplementedError):
-        lrf_amd.QMF(rank=3, bounds=(-16, 15), factor=(0, 1, 2))
+        lrf_amd.QMF(rank=3, eps=1e-8)
+    with pytest.raises(TypeError):
+        lrf_amd.QMF(rank=3, no_such_option=1)
+    # the class's other modes (unbounded, factor (0, 1, 2), penalties): tests/test_qmf_class.py
 
 
 def test_c_abi_argument_errors(ctx):

@@ -1,0 +1,91 @@
+"""The QMF class beyond what qmf_encode uses (lrf/factorization/qmf.py:74-231): unbounded factors, elastic-net terms, factor
+subsets, the affine pair w.  Fixtures: the reference's own results (tools/gen_golden.py qmfx; the first two are the shape of
+the reference's smoke test, test/test_factorization.py:5-10).  CPU part: the oracle from the reference's initial factors —
+bit for bit where w stays [0; 1], by tolerance where update_w (LAPACK lstsq in the reference, normal equations here) runs.
+GPU part: lrf_amd.QMF / the C ABI against the oracle and the reference."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+CASES = ["qmfx_unbounded_f01", "qmfx_unbounded_f012", "qmfx_bounded_l2", "qmfx_unbounded_l2_f012", "qmfx_bounded_f0"]
+
+
+def _case(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    spec, kw = json.loads(str(z["spec"])), json.loads(str(z["kwargs"]))
+    g = torch.Generator().manual_seed(spec["seed"])
+    x = torch.randint(0, 256, (1, spec["M"], spec["N"]), generator=g).float()
+    return z, kw, x
+
+
+def _loss(x, u, v, w):
+    y = w[0] + w[1] * (u.astype(np.float64) @ v.astype(np.float64).T)
+    return float(np.linalg.norm(x - y) / (np.linalg.norm(x) + 1e-16))
+
+
+def _oracle_args(kw):
+    return dict(bounds=tuple(kw.get("bounds", (None, None))), l2=kw.get("l2", 0.0), l1_ratio=kw.get("l1_ratio", 0.0),
+                factor=tuple(kw.get("factor", (0, 1, 2))))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_general_bcd_against_reference(name, oracle):
+    z, kw, x = _case(name)
+    X = x[0].numpy()
+    U, V, W = oracle.bcd_ex(X, z["u0"], z["v0"], kw["num_iters"], **_oracle_args(kw))
+    if 2 not in _oracle_args(kw)["factor"]:
+        assert np.array_equal(U, z["u"]) and np.array_equal(V, z["v"]), "without update_w the reference is reproduced bit for bit"
+        assert np.array_equal(W, z["w"])
+    else:  # update_w: lstsq in the reference, normal equations here
+        assert np.allclose(W, z["w"], rtol=2e-4, atol=2e-3), (W, z["w"])
+        assert abs(_loss(X, U, V, W) - float(z["loss"])) < 2e-4
+        assert np.mean(U == z["u"]) > 0.97 and np.mean(V == z["v"]) > 0.97
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_hip_general_bcd(name, oracle):
+    """The C ABI from the reference's initial factors: equal to the oracle bit for bit where w stays [0; 1] (and therefore
+    to the reference), within tolerance of both where update_w runs."""
+    from lrf_amd import _lib
+    z, kw, x = _case(name)
+    X = x[0].numpy()
+    a = _oracle_args(kw)
+    ctx = _lib.context(0)
+    U, V, W = ctx.decompose_ex(x.cuda(), int(kw["rank"]), kw["num_iters"], init=(torch.from_numpy(z["u0"])[None], torch.from_numpy(z["v0"])[None]), **a)
+    U, V, W = U[0].cpu().numpy(), V[0].cpu().numpy(), W[0].cpu().numpy()
+    Uo, Vo, Wo = oracle.bcd_ex(X, z["u0"], z["v0"], kw["num_iters"], **a)
+    if 2 not in a["factor"]:
+        assert np.array_equal(U, Uo) and np.array_equal(V, Vo) and np.array_equal(W, Wo)
+        assert np.array_equal(U, z["u"]) and np.array_equal(V, z["v"])
+    else:
+        assert np.allclose(W, Wo, rtol=1e-5, atol=1e-4) and np.allclose(W, z["w"], rtol=2e-4, atol=2e-3)
+        assert abs(_loss(X, U, V, W) - float(z["loss"])) < 2e-4
+        assert np.mean(U == Uo) > 0.99 and np.mean(V == Vo) > 0.99
+
+
+@pytest.mark.gpu
+def test_reference_smoke_test_runs():
+    """test/test_factorization.py:5-10 of the reference, with the three-value return its decompose has: QMF(rank=5,
+    num_iters=10) on randint(0, 256, (1, 784, 192)) — unbounded, w updated.  Own SVD initialisation (signs differ from
+    LAPACK's, which is immaterial without bounds): the loss lands on the reference's."""
+    import lrf_amd
+    z, kw, x = _case("qmfx_unbounded_f012")
+    qmf = lrf_amd.QMF(rank=5, num_iters=10)
+    u, v, w = qmf.decompose(x)
+    assert tuple(u.shape) == (1, 784, 5) and tuple(v.shape) == (1, 192, 5) and tuple(w.shape) == (1, 2, 1)
+    assert torch.equal(u, torch.round(u)) and torch.equal(v, torch.round(v))
+    loss = lrf_amd.QMF.loss(x, u, v, w).item()
+    assert abs(loss - float(z["loss"])) < 2e-3, (loss, float(z["loss"]))
+    y = qmf.forward(x)
+    assert tuple(y.shape) == tuple(x.shape)
+    # bounded + elastic net through the class, against the fixture's loss
+    z2, kw2, x2 = _case("qmfx_bounded_l2")
+    u2, v2, w2 = lrf_amd.QMF(**kw2).decompose(x2)
+    assert float(u2.min()) >= -16 and float(u2.max()) <= 15
+    assert abs(lrf_amd.QMF.loss(x2, u2, v2, w2).item() - float(z2["loss"])) < 5e-3

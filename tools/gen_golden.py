@@ -325,6 +325,42 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "anyshape":
     gen_anyshape()
 
 
+def gen_qmfx():
+    """The QMF class beyond what qmf_encode uses (lrf/factorization/qmf.py:74-231): unbounded factors, elastic-net terms,
+    the affine pair w (factor containing 2) — on the shape of the reference's own smoke test (test/test_factorization.py:5-10:
+    randint(0, 256, (1, 784, 192)), rank 5, 10 iterations) and a small bounded case.  Stored: the reference's initial factors
+    (its LAPACK SVD), its final (u, v, w) and loss."""
+    torch.set_num_threads(1)
+    ns = ref_loader.load()
+    QMF = ns.fqmf.QMF
+    cases = [
+        ("qmfx_unbounded_f01", dict(seed=5, M=784, N=192), dict(rank=5, num_iters=10, factor=(0, 1))),
+        ("qmfx_unbounded_f012", dict(seed=5, M=784, N=192), dict(rank=5, num_iters=10)),  # the reference's smoke test, as is
+        ("qmfx_bounded_l2", dict(seed=6, M=300, N=64), dict(rank=4, num_iters=5, bounds=(-16, 15), factor=(0, 1), l2=(0.02, 0.01), l1_ratio=0.5)),
+        ("qmfx_unbounded_l2_f012", dict(seed=7, M=128, N=96), dict(rank=3, num_iters=4, l2=0.001, l1_ratio=0.25)),
+        ("qmfx_bounded_f0", dict(seed=8, M=200, N=64), dict(rank=6, num_iters=3, bounds=(-8, 7), factor=(0,))),
+    ]
+    index = {}
+    for name, spec, kw in cases:
+        g = torch.Generator().manual_seed(spec["seed"])
+        x = torch.randint(0, 256, (1, spec["M"], spec["N"]), generator=g).float()
+        qmf = QMF(**kw)
+        u0, v0, w0 = qmf.init(x)
+        u, v, w = qmf.decompose(x)
+        loss = QMF.loss(x, u, v, w)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), spec=json.dumps(spec), kwargs=json.dumps(kw), u0=u0[0].numpy(), v0=v0[0].numpy(),
+                            u=u[0].numpy(), v=v[0].numpy(), w=w[0].numpy().reshape(2), loss=np.float64(loss.item()),
+                            sign=wsign(v0[0].numpy()))
+        index[name] = {"loss": loss.item(), "w": w[0].reshape(2).tolist()}
+        print(name, index[name], flush=True)
+    with open(os.path.join(OUT, "index_qmfx.json"), "w") as f:
+        json.dump(index, f, indent=1)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "qmfx":
+    gen_qmfx()
+
+
 def gen_loess():
     """LOESS fixture (lrf/utils/misc.py:276-412): the reference's class is taken out of its module by name (the module
     itself needs seaborn / pyinstrument, absent here) and run on seeded samples; inputs and predictions are stored."""
