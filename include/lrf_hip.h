@@ -201,6 +201,20 @@ int lrf_svd_encode_rgb_u8(lrf_ctx* ctx, const uint8_t* rgb, int64_t B, int64_t H
 int lrf_svd_decode_rgb_u8(lrf_ctx* ctx, const uint8_t* U, const uint8_t* V, int64_t B, int64_t H, int64_t W, int R,
                           const float* qparams6, uint8_t* rgb);
 
+/* svd_encode's RGB branch for the other patch sizes, patch=False and float factors (lrf/compression/svd.py:157-193): the host
+ * forms the matrices with lrf_qmf_rgbspace_matrix_u8 (the same X, svd.py:160-167), takes u = U sqrt(s), v = (sqrt(s) Vh)^T from
+ * lrf_qmf_svd_init_f32 (any shape) and, unless dtype is a float type, quantises each factor tensor as a whole:
+ *   lrf_quantize_u8: quantize(t, uint8) (lrf/compression/utils.py:185-220) of B tensors of `per` floats each:
+ *                    scale = (max - min) / 255, q = clamp((t - min) / scale + 0, 0, 255) truncated; qparams [B][2] = (scale, min).
+ *   lrf_svd_decode_any_u8: svd_decode of those streams (svd.py:310-326, 359); U / V uint8 with qparams6 [B][6] = (scale_u, min_u,
+ *                    qmin_u, scale_v, min_v, qmin_v), or float factors (factors_are_float, qparams6 NULL); layouts as
+ *                    lrf_qmf_rgbspace_decode_any_u8.
+ * The YCbCr branch of svd_encode is not built: in the reference it raises TypeError for an integer rank (svd.py:234, 267) and
+ * its streams do not decode ("padded size" is appended twice per plane, svd.py:226,237, so svd_decode reads the wrong entry). */
+int lrf_quantize_u8(lrf_ctx* ctx, const float* T, int64_t B, int64_t per, uint8_t* Q, float* qparams);
+int lrf_svd_decode_any_u8(lrf_ctx* ctx, const void* U, const void* V, int factors_are_float, int64_t B, int64_t H, int64_t W, int p, int q,
+                          int R, const float* qparams6, uint8_t* rgb);
+
 /* ---------------------------------------------------------------------------------------------------
  * QMF, RGB colour-space branch: qmf_encode(color_space="RGB", patch=True, patch_size=(8,8))
  * (lrf/compression/qmf.py:164-187).  One matrix X [M,192] per image (reflect padding to multiples of 8, rows =
@@ -217,6 +231,17 @@ int lrf_qmf_rgbspace_encode_u8(lrf_ctx* ctx, const uint8_t* rgb, int64_t B, int6
 /* qmf_decode, RGB colour-space branch (lrf/compression/qmf.py:311-323, :351): u @ v.mT, depatchify, unpad_image,
  * to_dtype(uint8).  rgb [B,3,H,W] uint8 (device). */
 int lrf_qmf_rgbspace_decode_u8(lrf_ctx* ctx, const int8_t* U, const int8_t* V, int64_t B, int64_t H, int64_t W, int R, uint8_t* rgb);
+
+/* The RGB colour-space branch for the other patch sizes and for patch=False (lrf/compression/qmf.py:164-212, decode :309-323).
+ * The host forms the matrices with lrf_qmf_rgbspace_matrix_u8, factorises them with lrf_qmf_decompose_f32 /
+ * lrf_qmf_bcd_f32 / lrf_qmf_svd_init_f32 (any shape) and decodes with lrf_qmf_rgbspace_decode_any_u8.
+ *   p, q > 0: X [B, M, 3 p q] — reflect-padded image, rows = patches, columns in (c, a, b) order (qmf.py:167-169);
+ *   p = q = 0 (patch=False): X [B, 3, H, W], the channel planes as three matrices per image (qmf.py:193-194), factors
+ *   U [B,3,H,R], V [B,3,W,R].  lrf_rgbspace_dims_any: padded size and the matrix shape [M, N] (p = 0: M = H, N = W). */
+int lrf_rgbspace_dims_any(int64_t H, int64_t W, int p, int q, int64_t* hp, int64_t* wp, int64_t* M, int64_t* N);
+int lrf_qmf_rgbspace_matrix_u8(lrf_ctx* ctx, const uint8_t* rgb, int64_t B, int64_t H, int64_t W, int p, int q, float* X);
+int lrf_qmf_rgbspace_decode_any_u8(lrf_ctx* ctx, const int8_t* U, const int8_t* V, int64_t B, int64_t H, int64_t W, int p, int q, int R,
+                                   uint8_t* rgb);
 
 /* ---------------------------------------------------------------------------------------------------
  * YCbCr branch with any patch size, or none: qmf_encode(color_space="YCbCr", patch_size=(p,q)) and patch=False

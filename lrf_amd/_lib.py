@@ -76,6 +76,11 @@ def load():
         lib.lrf_qmf_rgbspace_encode_u8.argtypes = [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_void_p,
                                                    c_void_p, c_void_p, c_void_p, c_void_p]
         lib.lrf_qmf_rgbspace_decode_u8.argtypes = [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_void_p]
+        lib.lrf_quantize_u8.argtypes = [c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_void_p]
+        lib.lrf_svd_decode_any_u8.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_void_p, c_void_p]
+        lib.lrf_rgbspace_dims_any.argtypes = [c_i64, c_i64, c_int, c_int] + [ctypes.POINTER(c_i64)] * 4
+        lib.lrf_qmf_rgbspace_matrix_u8.argtypes = [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_int, c_void_p]
+        lib.lrf_qmf_rgbspace_decode_any_u8.argtypes = [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_void_p]
         lib.lrf_plane_dims_any.argtypes = [c_i64, c_i64, c_int, c_int, c_int] + [ctypes.POINTER(c_i64)] * 6
         lib.lrf_qmf_planes_any_u8.argtypes = [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_void_p]
         lib.lrf_qmf_decode_any_u8.argtypes = [c_void_p] + [c_void_p] * 6 + [c_i64, c_i64, c_i64, c_int, c_int,
@@ -106,7 +111,8 @@ EXPORTS = ["lrf_last_error", "lrf_device_count", "lrf_version", "lrf_ctx_create"
            "lrf_ctx_profile_reset", "lrf_malloc", "lrf_free", "lrf_memcpy_h2d", "lrf_memcpy_d2h", "lrf_plane_dims",
            "lrf_qmf_planes_from_rgb_u8", "lrf_qmf_decompose_f32", "lrf_qmf_decompose_ex_f32", "lrf_qmf_bcd_f32", "lrf_qmf_svd_init_f32",
            "lrf_qmf_encode_rgb_u8", "lrf_qmf_decode_rgb_u8", "lrf_svd_encode_rgb_u8", "lrf_svd_decode_rgb_u8",
-           "lrf_qmf_rgbspace_encode_u8", "lrf_qmf_rgbspace_decode_u8",
+           "lrf_qmf_rgbspace_encode_u8", "lrf_qmf_rgbspace_decode_u8", "lrf_rgbspace_dims_any", "lrf_qmf_rgbspace_matrix_u8",
+           "lrf_qmf_rgbspace_decode_any_u8", "lrf_quantize_u8", "lrf_svd_decode_any_u8",
            "lrf_plane_dims_any", "lrf_qmf_planes_any_u8", "lrf_qmf_decode_any_u8",
            "lrf_pipe_create", "lrf_pipe_destroy", "lrf_pipe_slots", "lrf_pipe_slot_ctx", "lrf_pipe_workspace_bytes",
            "lrf_pipe_qmf_encode_rgb_u8_host", "lrf_pipe_qmf_encode_submit", "lrf_pipe_wait_next",
@@ -145,6 +151,14 @@ def plane_dims_any(H, W, patch_size):
         check(load().lrf_plane_dims_any(H, W, p, q, c, *[ctypes.byref(x) for x in v]))
         out.append(tuple(int(x.value) for x in v))
     return out
+
+
+def rgbspace_dims_any(H, W, patch_size):
+    """(Hp, Wp, M, N) of the RGB colour-space branch for patches (p, q); patch_size None = patch=False (per channel [H, W])."""
+    p, q = (0, 0) if patch_size is None else (int(patch_size[0]), int(patch_size[1]))
+    v = [c_i64() for _ in range(4)]
+    check(load().lrf_rgbspace_dims_any(H, W, p, q, *[ctypes.byref(x) for x in v]))
+    return tuple(int(x.value) for x in v)
 
 
 def _dptr(t):
@@ -397,6 +411,71 @@ def _svd_methods():
         check(self._lib.lrf_qmf_rgbspace_decode_u8(self._h, _dptr(U), _dptr(V), B, H, W, int(R), _dptr(rgb)))
         return rgb
 
+    def rgbspace_matrix_any(self, rgb, patch_size):
+        """rgb uint8 [B,3,H,W] (CUDA) -> X fp32: [B, M, 3 p q] for patches (p, q), [B, 3, H, W] for patch_size None"""
+        import torch
+        rgb = rgb.contiguous()
+        B, C, H, W = rgb.shape
+        assert C == 3 and rgb.dtype == torch.uint8
+        p, q = (0, 0) if patch_size is None else (int(patch_size[0]), int(patch_size[1]))
+        _, _, M, N = rgbspace_dims_any(H, W, patch_size)
+        X = torch.empty((B, 3, H, W) if patch_size is None else (B, M, N), dtype=torch.float32, device=rgb.device)
+        self.use_torch_stream()
+        check(self._lib.lrf_qmf_rgbspace_matrix_u8(self._h, _dptr(rgb), B, H, W, p, q, _dptr(X)))
+        return X
+
+    def qmf_rgbspace_decode_any(self, U, V, H, W, patch_size):
+        """int8 U [B,M,R] / V [B,3pq,R] (patches) or U [B,3,H,R] / V [B,3,W,R] (patch_size None) -> uint8 [B,3,H,W]"""
+        import torch
+        U, V = U.contiguous(), V.contiguous()
+        B, R = U.shape[0], U.shape[-1]
+        p, q = (0, 0) if patch_size is None else (int(patch_size[0]), int(patch_size[1]))
+        _, _, M, N = rgbspace_dims_any(H, W, patch_size)
+        want_u, want_v = ((B, 3, H, R), (B, 3, W, R)) if patch_size is None else ((B, M, R), (B, N, R))
+        if tuple(U.shape) != want_u or tuple(V.shape) != want_v or U.dtype != torch.int8 or V.dtype != torch.int8:
+            raise ValueError(f"factor shapes {tuple(U.shape)} / {tuple(V.shape)} do not match the geometry {want_u} / {want_v}")
+        rgb = torch.empty((B, 3, H, W), dtype=torch.uint8, device=U.device)
+        self.use_torch_stream()
+        check(self._lib.lrf_qmf_rgbspace_decode_any_u8(self._h, _dptr(U), _dptr(V), B, H, W, p, q, int(R), _dptr(rgb)))
+        return rgb
+
+    def quantize_u8(self, T):
+        """quantize(t, uint8) of each T[b] as a whole (utils.py:185-220): fp32 CUDA [B, ...] -> (uint8 same shape, qparams [B,2])"""
+        import torch
+        T = T.float().contiguous()
+        B = T.shape[0]
+        per = T[0].numel()
+        Q = torch.empty(T.shape, dtype=torch.uint8, device=T.device)
+        qp = torch.empty((B, 2), dtype=torch.float32, device=T.device)
+        self.use_torch_stream()
+        check(self._lib.lrf_quantize_u8(self._h, _dptr(T), B, per, _dptr(Q), _dptr(qp)))
+        return Q, qp
+
+    def svd_decode_any(self, U, V, H, W, patch_size, qparams6=None):
+        """uint8 factors + qparams6 [B,6], or float32 factors (qparams6 None) -> uint8 [B,3,H,W]; layouts as qmf_rgbspace_decode_any"""
+        import torch
+        U, V = U.contiguous(), V.contiguous()
+        B, R = U.shape[0], U.shape[-1]
+        is_float = U.dtype == torch.float32
+        assert U.dtype == V.dtype and (is_float or U.dtype == torch.uint8)
+        p, q = (0, 0) if patch_size is None else (int(patch_size[0]), int(patch_size[1]))
+        _, _, M, N = rgbspace_dims_any(H, W, patch_size)
+        want_u, want_v = ((B, 3, H, R), (B, 3, W, R)) if patch_size is None else ((B, M, R), (B, N, R))
+        if tuple(U.shape) != want_u or tuple(V.shape) != want_v:
+            raise ValueError(f"factor shapes {tuple(U.shape)} / {tuple(V.shape)} do not match the geometry {want_u} / {want_v}")
+        if not is_float:
+            qparams6 = qparams6.float().contiguous()
+            assert tuple(qparams6.shape) == (B, 6)
+        rgb = torch.empty((B, 3, H, W), dtype=torch.uint8, device=U.device)
+        self.use_torch_stream()
+        check(self._lib.lrf_svd_decode_any_u8(self._h, _dptr(U), _dptr(V), int(is_float), B, H, W, p, q, int(R),
+                                              None if is_float else _dptr(qparams6), _dptr(rgb)))
+        return rgb
+
+    Context.quantize_u8 = quantize_u8
+    Context.svd_decode_any = svd_decode_any
+    Context.rgbspace_matrix_any = rgbspace_matrix_any
+    Context.qmf_rgbspace_decode_any = qmf_rgbspace_decode_any
     Context.svd_encode_rgb = svd_encode_rgb
     Context.svd_decode_rgb = svd_decode_rgb
     Context.qmf_rgbspace_encode = qmf_rgbspace_encode

@@ -29,8 +29,6 @@ def qmf_ranks(image_hw, rank=None, quality=None):
 
 
 def _check_hip_branch(color_space, scale_factor, patch, patch_size, bounds, dtype, kwargs):
-    if color_space == "RGB" and (not patch or tuple(patch_size) != (8, 8)):
-        raise NotImplementedError("HIP path covers color_space='RGB' with patch=True, patch_size=(8,8) only")
     if color_space == "YCbCr" and tuple(scale_factor) != (0.5, 0.5):
         raise NotImplementedError("HIP path covers scale_factor=(0.5,0.5) only")
     if dtype is not torch.int8:
@@ -240,7 +238,7 @@ def qmf_encode(image: torch.Tensor, rank=None, quality=None, color_space: str = 
     ctx = _lib.context(image.device.index if image.is_cuda else None)
     dev = (image if image.is_cuda else image.cuda(ctx.device)).unsqueeze(0)
     if color_space == "RGB":
-        return _qmf_encode_rgbspace(ctx, dev, rank, quality, bounds, (lo, hi), patch_size, num_iters, init_sign,
+        return _qmf_encode_rgbspace(ctx, dev, rank, quality, bounds, (lo, hi), tuple(patch_size) if patch else None, num_iters, init_sign,
                                     kwargs.get("init"))
     if not patch or tuple(patch_size) != (8, 8):
         return _qmf_encode_anyshape(ctx, dev, rank, quality, bounds, (lo, hi), tuple(patch_size) if patch else None, num_iters,
@@ -363,32 +361,48 @@ def rgbspace_dims(H, W):
 
 
 def _qmf_encode_rgbspace(ctx, dev, rank, quality, bounds, int_bounds, patch_size, num_iters, init_sign, init):
-    """qmf_encode(color_space="RGB", patch=True) (lrf/compression/qmf.py:164-187, 288-290): one [M,192] matrix."""
+    """qmf_encode(color_space="RGB") (lrf/compression/qmf.py:164-212, 288-290): with patches one [M, 3 p q] matrix per image,
+    without (patch_size None) the three channel planes as matrices [3, H, W].  8x8 patches with num_iters >= 1 run on the
+    fused entry point; the other forms go matrix -> lrf_qmf_decompose_f32 / _bcd_f32 / _svd_init_f32 (any shape)."""
     if isinstance(rank, (list, tuple)) or isinstance(quality, (list, tuple)):
         raise ValueError("color_space='RGB' takes a scalar rank / quality")
     H, W = dev.shape[-2:]
-    Hp, Wp, M = rgbspace_dims(H, W)
+    Hp, Wp, M, N = _lib.rgbspace_dims_any(H, W, patch_size)
     if rank is None:
         assert quality >= 0 and quality <= 100, "'quality' must be between 0 and 100."
-        R = max(round(min(M, 192) * quality / 100), 1)
+        R = max(round(min(M, N) * quality / 100), 1)
     else:
         R = rank
-    if num_iters == 0:
-        raise NotImplementedError("num_iters=0 is not on the HIP path for color_space='RGB'")
-    sign = None if init_sign is None else torch.as_tensor(init_sign, dtype=torch.int8).reshape(1, R)
-    U, V = ctx.qmf_rgbspace_encode(dev, R, num_iters, int_bounds, sign, init)
-    metadata = {
-        "dtype": str(dev.dtype).split(".")[-1],
-        "color space": "RGB",
-        "patch": True,
-        "bounds": bounds,
-        "patch size": patch_size,
-        "original size": [H, W],
-        "padded size": [Hp, Wp],
-        "rank": R,
-    }
-    factors = [U[0].cpu().numpy(), V[0].cpu().numpy()]
-    return combine_bytes([dict_to_bytes(metadata), combine_bytes([encode_tensor(f) for f in factors])])
+    nmat = 1 if patch_size is not None else 3
+    sign = None if init_sign is None else torch.as_tensor(init_sign, dtype=torch.int8).reshape(-1, R).expand(nmat, R).contiguous()
+    metadata = {"dtype": str(dev.dtype).split(".")[-1], "color space": "RGB", "patch": patch_size is not None, "bounds": bounds}
+    if patch_size is not None:
+        metadata.update({"patch size": patch_size, "original size": [H, W], "padded size": [Hp, Wp], "rank": R})
+    else:
+        metadata["rank"] = R
+    if patch_size is not None and tuple(patch_size) == (8, 8) and num_iters >= 1:
+        U, V = ctx.qmf_rgbspace_encode(dev, R, num_iters, int_bounds, sign, init)
+        factors = [U[0].cpu().numpy(), V[0].cpu().numpy()]
+    else:
+        X = ctx.rgbspace_matrix_any(dev, patch_size)
+        X = X[0] if patch_size is None else X  # [3, H, W]: three matrices; [1, M, N]: one
+        if init is not None:
+            u0 = torch.as_tensor(init[0], dtype=torch.float32).reshape(nmat, M, R).contiguous().cuda(dev.device)
+            v0 = torch.as_tensor(init[1], dtype=torch.float32).reshape(nmat, N, R).contiguous().cuda(dev.device)
+        elif num_iters == 0 or init is None:
+            u0 = v0 = None
+        sg = None if sign is None else sign.cuda(dev.device)
+        if num_iters == 0:  # the float factors go straight through torch's truncating cast (qmf.py:188, 210)
+            if init is None:
+                u0, v0 = ctx.svd_init(X, R, sg)
+            u, v = u0.cpu().to(torch.int8), v0.cpu().to(torch.int8)
+        elif init is not None:
+            u, v = ctx.bcd(X, u0, v0, num_iters, int_bounds[0], int_bounds[1])
+        else:
+            u, v = ctx.decompose(X, R, num_iters, int_bounds[0], int_bounds[1], sg)
+        u, v = u.cpu().numpy(), v.cpu().numpy()
+        factors = [u[0], v[0]] if patch_size is not None else [u, v]  # patch=False keeps the channel axis (qmf.py:208-210)
+    return combine_bytes([dict_to_bytes(metadata), combine_bytes([encode_tensor(np.ascontiguousarray(f)) for f in factors])])
 
 
 def _svd_init_factors(ctx, dev, ranks, init_sign):
@@ -458,19 +472,29 @@ def _qmf_decode_rgbspace(encoded_image: bytes, device=None) -> torch.Tensor:
     """RGB colour-space branch of qmf_decode (lrf/compression/qmf.py:309-323) -> uint8 CUDA tensor [3,H,W]."""
     encoded_metadata, encoded_factors = separate_bytes(encoded_image, 2)
     metadata = bytes_to_dict(encoded_metadata)
-    if not metadata["patch"] or list(metadata["patch size"]) != [8, 8]:
-        raise NotImplementedError("HIP decode covers the 8x8-patch branches only")
     if metadata["dtype"] != "uint8":
         raise NotImplementedError("HIP decode writes uint8 images")
     u, v = (decode_tensor(f) for f in separate_bytes(encoded_factors, 2))
-    H, W = metadata["original size"]
-    Hp, Wp, M = rgbspace_dims(H, W)
-    if list(metadata["padded size"]) != [Hp, Wp] or tuple(u.shape) != (M, metadata["rank"]) or tuple(v.shape) != (192, metadata["rank"]):
-        raise NotImplementedError("stream geometry is not the 8x8 / reflect-padded layout")
+    if u.dtype != np.int8 or v.dtype != np.int8:
+        raise ValueError("stream factors are not int8")
+    R = int(metadata["rank"])
+    if metadata["patch"]:
+        patch_size = tuple(metadata["patch size"])
+        H, W = metadata["original size"]
+        Hp, Wp, M, N = _lib.rgbspace_dims_any(H, W, patch_size)
+        if list(metadata["padded size"]) != [Hp, Wp] or tuple(u.shape) != (M, R) or tuple(v.shape) != (N, R):
+            raise ValueError("stream factors do not match the reflect-padded patch geometry its metadata describes")
+    else:  # patch=False: u [3, H, R], v [3, W, R]; the image size is the factors' (qmf.py:320-323)
+        patch_size = None
+        if u.ndim != 3 or v.ndim != 3 or u.shape[0] != 3 or v.shape[0] != 3 or u.shape[2] != R or v.shape[2] != R:
+            raise ValueError("stream factors are not [3, H, R] / [3, W, R]")
+        H, W = int(u.shape[1]), int(v.shape[1])
     ctx = _lib.context(device)
-    U = torch.from_numpy(np.ascontiguousarray(u, dtype=np.int8)).unsqueeze(0).cuda(ctx.device)
-    V = torch.from_numpy(np.ascontiguousarray(v, dtype=np.int8)).unsqueeze(0).cuda(ctx.device)
-    return ctx.qmf_rgbspace_decode(U, V, H, W)[0]
+    U = torch.from_numpy(np.array(u, dtype=np.int8)).unsqueeze(0).cuda(ctx.device)  # copies: decode_tensor may return read-only views
+    V = torch.from_numpy(np.array(v, dtype=np.int8)).unsqueeze(0).cuda(ctx.device)
+    if patch_size == (8, 8):
+        return ctx.qmf_rgbspace_decode(U, V, H, W)[0]
+    return ctx.qmf_rgbspace_decode_any(U, V, H, W, patch_size)[0]
 
 
 def qmf_decode(encoded_image: bytes) -> torch.Tensor:

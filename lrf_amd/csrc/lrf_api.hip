@@ -1274,6 +1274,111 @@ int lrf_qmf_rgbspace_decode_u8(lrf_ctx* c, const int8_t* U, const int8_t* V, int
     return LRF_OK;
 }
 
+// geometry of the RGB colour-space branch for patches (p, q) (reflect padding to multiples, lrf/compression/utils.py:108-132) or
+// none (p = q = 0: per channel the plane [H, W])
+static int rgbspace_geom_any(int64_t H, int64_t W, int p, int q, int* hp, int* wp, int* top, int* left, int* nw, long* M, long* N)
+{
+    if (H < 1 || W < 1) return set_err(LRF_EINVAL, "bad image size");
+    if ((p == 0) != (q == 0) || p < 0 || q < 0) return set_err(LRF_EINVAL, "patch size (%d, %d)", p, q);
+    if (p == 0) {
+        *hp = (int)H; *wp = (int)W; *top = 0; *left = 0; *nw = 0; *M = H; *N = W;
+        return LRF_OK;
+    }
+    const int64_t ph = (p - H % p) % p, pw = (q - W % q) % q;
+    if (ph / 2 >= H || ph - ph / 2 >= H || pw / 2 >= W || pw - pw / 2 >= W)
+        return set_err(LRF_EINVAL, "reflect padding larger than the image (%ldx%ld, patches %dx%d)", (long)H, (long)W, p, q);
+    *hp = (int)(H + ph); *wp = (int)(W + pw); *top = (int)(ph / 2); *left = (int)(pw / 2);
+    *nw = *wp / q;
+    *M = (long)(*hp / p) * (*wp / q);
+    *N = 3L * p * q;
+    return LRF_OK;
+}
+
+int lrf_rgbspace_dims_any(int64_t H, int64_t W, int p, int q, int64_t* hp, int64_t* wp, int64_t* M, int64_t* N)
+{
+    if (!hp || !wp || !M || !N) return set_err(LRF_EINVAL, "NULL argument");
+    int h2, w2, top, left, nw, rc;
+    long m, n;
+    if ((rc = rgbspace_geom_any(H, W, p, q, &h2, &w2, &top, &left, &nw, &m, &n))) return rc;
+    *hp = h2; *wp = w2; *M = m; *N = n;
+    return LRF_OK;
+}
+
+int lrf_qmf_rgbspace_matrix_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_t H, int64_t W, int p, int q, float* X)
+{
+    if (!c || !rgb || !X) return set_err(LRF_EINVAL, "NULL argument");
+    if (B < 1 || B > 65535) return set_err(LRF_EINVAL, "B=%ld out of range [1,65535]", (long)B);
+    int hp, wp, top, left, nw, rc;
+    long M, N;
+    if ((rc = rgbspace_geom_any(H, W, p, q, &hp, &wp, &top, &left, &nw, &M, &N))) return rc;
+    LRF_ON_DEVICE(c);
+    const long elems = p ? M * N : 3L * H * W;
+    Prof pr(c, LRF_K_PLANES);
+    hipLaunchKernelGGL(k_rgb_matrix_any, dim3((unsigned)((elems + 255) / 256), (unsigned)B), dim3(256), 0, c->stream, rgb, (int)H, (int)W, p, q,
+                       top, left, nw, elems, X);
+    LAUNCH_CHECK();
+    return LRF_OK;
+}
+
+int lrf_qmf_rgbspace_decode_any_u8(lrf_ctx* c, const int8_t* U, const int8_t* V, int64_t B, int64_t H, int64_t W, int p, int q, int R,
+                                   uint8_t* rgb)
+{
+    if (!c || !U || !V || !rgb) return set_err(LRF_EINVAL, "NULL argument");
+    if (B < 1 || B > 65535) return set_err(LRF_EINVAL, "B=%ld out of range [1,65535]", (long)B);
+    if (R < 1 || R > LRF_ANY_MAX_RANK) return set_err(LRF_EINVAL, "rank %d out of range", R);
+    int hp, wp, top, left, nw, rc;
+    long M, N;
+    if ((rc = rgbspace_geom_any(H, W, p, q, &hp, &wp, &top, &left, &nw, &M, &N))) return rc;
+    LRF_ON_DEVICE(c);
+    const long u_img = (p ? M : 3L * H) * R, v_img = (p ? N : 3L * W) * R;
+    const long n = 3L * H * W;
+    Prof pr(c, LRF_K_DECODE);
+    hipLaunchKernelGGL(k_rgb_decode_any, dim3((unsigned)((n + 255) / 256), (unsigned)B), dim3(256), 0, c->stream, U, V, (int)H, (int)W, p, q, top,
+                       left, nw, u_img, v_img, R, rgb);
+    LAUNCH_CHECK();
+    return LRF_OK;
+}
+
+int lrf_quantize_u8(lrf_ctx* c, const float* T, int64_t B, int64_t per, uint8_t* Q, float* qparams)
+{
+    if (!c || !T || !Q || !qparams) return set_err(LRF_EINVAL, "NULL argument");
+    if (B < 1 || B > 65535 || per < 1) return set_err(LRF_EINVAL, "bad sizes");
+    LRF_ON_DEVICE(c);
+    int rc;
+    if ((rc = ensure(c, c->smm, (size_t)B * 2 * sizeof(float)))) return rc;
+    float* mm = (float*)c->smm.p;
+    hipLaunchKernelGGL(k_minmax, dim3((unsigned)B), dim3(256), 0, c->stream, T, (long)per, (long)per, mm);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_quantize_u8, dim3((unsigned)((per + 255) / 256), (unsigned)B), dim3(256), 0, c->stream, T, (long)per, (long)per,
+                       (const float*)mm, Q, qparams, 2, 0);
+    LAUNCH_CHECK();
+    return LRF_OK;
+}
+
+int lrf_svd_decode_any_u8(lrf_ctx* c, const void* U, const void* V, int factors_are_float, int64_t B, int64_t H, int64_t W, int p, int q,
+                          int R, const float* qparams6, uint8_t* rgb)
+{
+    if (!c || !U || !V || !rgb) return set_err(LRF_EINVAL, "NULL argument");
+    if (!factors_are_float && !qparams6) return set_err(LRF_EINVAL, "quantised factors need their (scale, min, qmin) parameters");
+    if (B < 1 || B > 65535) return set_err(LRF_EINVAL, "B=%ld out of range [1,65535]", (long)B);
+    if (R < 1 || R > 16384) return set_err(LRF_EINVAL, "rank %d out of range", R);
+    int hp, wp, top, left, nw, rc;
+    long M, N;
+    if ((rc = rgbspace_geom_any(H, W, p, q, &hp, &wp, &top, &left, &nw, &M, &N))) return rc;
+    LRF_ON_DEVICE(c);
+    const long u_img = (p ? M : 3L * H) * R, v_img = (p ? N : 3L * W) * R;
+    const long n = 3L * H * W;
+    Prof pr(c, LRF_K_DECODE);
+    if (factors_are_float)
+        hipLaunchKernelGGL(k_svd_decode_any<false>, dim3((unsigned)((n + 255) / 256), (unsigned)B), dim3(256), 0, c->stream, U, V, (int)H, (int)W, p,
+                           q, top, left, nw, u_img, v_img, R, qparams6, rgb);
+    else
+        hipLaunchKernelGGL(k_svd_decode_any<true>, dim3((unsigned)((n + 255) / 256), (unsigned)B), dim3(256), 0, c->stream, U, V, (int)H, (int)W, p,
+                           q, top, left, nw, u_img, v_img, R, qparams6, rgb);
+    LAUNCH_CHECK();
+    return LRF_OK;
+}
+
 int lrf_plane_dims_any(int64_t H, int64_t W, int p, int q, int ch, int64_t* h, int64_t* w, int64_t* hp, int64_t* wp, int64_t* M,
                        int64_t* N)
 {

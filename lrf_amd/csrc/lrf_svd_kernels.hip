@@ -207,3 +207,97 @@ __global__ __launch_bounds__(256) void k_qmf_decode_rgbspace(const int8_t* __res
     acc = fminf(fmaxf(acc, 0.f), 255.f);
     rgb[(long)blockIdx.y * n + e] = (uint8_t)acc;
 }
+
+// The same branch for any patch size (qmf.py:164-171: X [M, 3 p q], columns in (c, a, b) order) and for patch=False
+// (qmf.py:193-194: the three channel planes themselves, X [3][H][W]; p = 0).  One thread per matrix element.
+__global__ __launch_bounds__(256) void k_rgb_matrix_any(const uint8_t* __restrict__ rgb, int H, int W, int p, int q, int top, int left,
+                                                        int nw, long elems, float* __restrict__ X)
+{
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= elems) return;
+    const uint8_t* img = rgb + (long)blockIdx.y * 3 * H * W;
+    float v;
+    if (p == 0) {
+        v = (float)img[e]; // [3][H][W] as it is
+    } else {
+        const int N = 3 * p * q;
+        const long m = e / N;
+        const int n = (int)(e - m * N);
+        const int c = n / (p * q), rem = n - c * p * q, a = rem / q, b = rem - a * q;
+        const int hh = (int)(m / nw), ww = (int)(m - (long)hh * nw);
+        const int y = reflect_idx(hh * p + a - top, H), x = reflect_idx(ww * q + b - left, W);
+        v = (float)img[(long)c * H * W + (long)y * W + x];
+    }
+    X[(long)blockIdx.y * elems + e] = v;
+}
+
+// qmf_decode of those streams (qmf.py:311-323, 351): u @ v.mT (exact integers), depatchify + unpad (p > 0), clamp + truncate.
+// p > 0: U [B][M][R], V [B][3 p q][R];  p = 0: U [B][3][H][R], V [B][3][W][R].  One thread per pixel.
+__global__ __launch_bounds__(256) void k_rgb_decode_any(const int8_t* __restrict__ U, const int8_t* __restrict__ V, int H, int W, int p,
+                                                        int q, int top, int left, int nw, long u_img, long v_img, int R,
+                                                        uint8_t* __restrict__ rgb)
+{
+    const long n = 3L * H * W;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const int c = (int)(e / ((long)H * W));
+    const int rem = (int)(e - (long)c * H * W);
+    const int y = rem / W, x = rem - y * W;
+    const int8_t *u, *v;
+    if (p == 0) {
+        u = U + (long)blockIdx.y * u_img + ((long)c * H + y) * R;
+        v = V + (long)blockIdx.y * v_img + ((long)c * W + x) * R;
+    } else {
+        const int yy = y + top, xx = x + left;
+        const long m = (long)(yy / p) * nw + (xx / q);
+        const int col = c * p * q + (yy % p) * q + (xx % q);
+        u = U + (long)blockIdx.y * u_img + m * R;
+        v = V + (long)blockIdx.y * v_img + (long)col * R;
+    }
+    float acc = 0.f;
+    for (int r = 0; r < R; r++) acc = fmaf((float)u[r], (float)v[r], acc); // k-ordered chain; exact while |sum| < 2^24
+    acc = fminf(fmaxf(acc, 0.f), 255.f);
+    rgb[(long)blockIdx.y * n + e] = (uint8_t)acc;
+}
+
+// svd_decode of the RGB branch for any patch size / no patches and for quantised (uint8) or float factors
+// (lrf/compression/svd.py:310-326, 359): dequantize (utils.py:223-243: (q - q.min()) * scale + min) when QUANT, u @ v.mT as
+// a k-ordered fp32 fma chain, depatchify + unpad (p > 0), clamp + truncate.  Layouts as k_rgb_decode_any.  One thread per pixel.
+template <bool QUANT>
+__global__ __launch_bounds__(256) void k_svd_decode_any(const void* __restrict__ Uv, const void* __restrict__ Vv, int H, int W, int p, int q,
+                                                        int top, int left, int nw, long u_img, long v_img, int R,
+                                                        const float* __restrict__ qp /*[B][6] or NULL*/, uint8_t* __restrict__ rgb)
+{
+    const long n = 3L * H * W;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const int c = (int)(e / ((long)H * W));
+    const int rem = (int)(e - (long)c * H * W);
+    const int y = rem / W, x = rem - y * W;
+    long uo, vo;
+    if (p == 0) {
+        uo = (long)blockIdx.y * u_img + ((long)c * H + y) * R;
+        vo = (long)blockIdx.y * v_img + ((long)c * W + x) * R;
+    } else {
+        const int yy = y + top, xx = x + left;
+        uo = (long)blockIdx.y * u_img + ((long)(yy / p) * nw + (xx / q)) * R;
+        vo = (long)blockIdx.y * v_img + (long)(c * p * q + (yy % p) * q + (xx % q)) * R;
+    }
+    float acc = 0.f;
+    if (QUANT) {
+        const uint8_t* u = static_cast<const uint8_t*>(Uv) + uo;
+        const uint8_t* v = static_cast<const uint8_t*>(Vv) + vo;
+        const float* g = qp + (long)blockIdx.y * 6; // scale_u, min_u, qmin_u, scale_v, min_v, qmin_v
+        for (int r = 0; r < R; r++) {
+            const float uf = ((float)u[r] - g[2]) * g[0] + g[1];
+            const float vf = ((float)v[r] - g[5]) * g[3] + g[4];
+            acc = fmaf(uf, vf, acc);
+        }
+    } else {
+        const float* u = static_cast<const float*>(Uv) + uo;
+        const float* v = static_cast<const float*>(Vv) + vo;
+        for (int r = 0; r < R; r++) acc = fmaf(u[r], v[r], acc);
+    }
+    acc = fminf(fmaxf(acc, 0.f), 255.f);
+    rgb[(long)blockIdx.y * n + e] = (uint8_t)acc;
+}

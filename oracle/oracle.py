@@ -338,3 +338,33 @@ def qmf_anyshape_decode(factors, H, W, patch_size):
     out = np.empty((3, H, W), np.float32)
     lib().lrf_oracle_ycbcr_to_rgb(_ptr(ycc, _fp), c_long(H), c_long(W), _ptr(out, _fp))
     return to_u8(out)
+
+
+# ---- RGB colour-space branch for any patch size / no patches (lrf/compression/qmf.py:164-212, 309-323): pure data movement
+# and exact integer arithmetic, restated in numpy
+def rgb_matrix_any(rgb, patch_size):
+    """uint8 [3,H,W] -> fp32 X: [M, 3 p q] for patches (p, q) (reflect pad with top = pad // 2, utils.py:108-132; patchify
+    "c (h p) (w q) -> (h w) (c p q)", qmf.py:43-56), or the planes themselves [3, H, W] for patch_size None."""
+    x = np.asarray(rgb, dtype=np.float32)
+    if patch_size is None:
+        return np.ascontiguousarray(x)
+    p, q = patch_size
+    _, H, W = x.shape
+    ph, pw = (p - H % p) % p, (q - W % q) % q
+    x = np.pad(x, ((0, 0), (ph // 2, ph - ph // 2), (pw // 2, pw - pw // 2)), mode="reflect")
+    c, Hp, Wp = x.shape
+    x = x.reshape(c, Hp // p, p, Wp // q, q).transpose(1, 3, 0, 2, 4)  # (h, w, c, p, q)
+    return np.ascontiguousarray(x.reshape((Hp // p) * (Wp // q), c * p * q))
+
+
+def rgb_decode_any(u, v, H, W, patch_size):
+    """int8 factors -> uint8 [3,H,W]: u @ v.mT (exact integers), depatchify + centre crop (patches), clamp, truncate."""
+    if patch_size is None:
+        x = np.einsum("chr,cwr->chw", u.astype(np.int64), v.astype(np.int64))
+    else:
+        p, q = patch_size
+        ph, pw = (p - H % p) % p, (q - W % q) % q
+        Hp, Wp = H + ph, W + pw
+        x = (u.astype(np.int64) @ v.astype(np.int64).T).reshape(Hp // p, Wp // q, 3, p, q).transpose(2, 0, 3, 1, 4).reshape(3, Hp, Wp)
+        x = x[:, ph // 2: ph // 2 + H, pw // 2: pw // 2 + W]
+    return np.clip(x, 0, 255).astype(np.uint8)

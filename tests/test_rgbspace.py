@@ -132,10 +132,9 @@ def test_hip_rgbspace_rejects_what_is_not_implemented():
     img = torch.randint(0, 256, (3, 64, 96), dtype=torch.uint8)
     with pytest.raises(NotImplementedError):
         lrf_amd.qmf_encode(img, color_space="RGB", rank=193)  # more columns than the matrix has
-    with pytest.raises(NotImplementedError):
-        lrf_amd.qmf_encode(img, color_space="RGB", rank=4, num_iters=0)
-    with pytest.raises(NotImplementedError):
-        lrf_amd.qmf_encode(img, color_space="RGB", rank=4, patch=False)
+    with pytest.raises(ValueError):
+        lrf_amd.qmf_encode(img, color_space="RGB", rank=(4, 2, 2))  # the RGB branch takes a scalar rank
+    # num_iters=0, patch=False and the other patch sizes run since round 2: RGBANY_CASES below
 
 
 @pytest.mark.gpu
@@ -153,3 +152,71 @@ def test_hip_bcd_rank_30_equals_oracle(oracle):
                                    (torch.from_numpy(u0[None]), torch.from_numpy(v0[None])))
     u, v = oracle.bcd(X, u0, v0, 3, (-16, 15))
     assert np.array_equal(U[0].cpu().numpy(), u.astype(np.int8)) and np.array_equal(V[0].cpu().numpy(), v.astype(np.int8))
+
+
+# ---------------------------------------------------------------- the same branch for other patch sizes, patch=False, num_iters=0
+RGBANY_CASES = ["rgbany_p4_q6", "rgbany_p16_r5", "rgbany_p8x4_q3", "rgbany_nopatch_q8", "rgbany_nopatch_r2", "rgbany_p8_it0"]
+
+
+class RgbAnyCase:
+    def __init__(self, name):
+        z = np.load(os.path.join(GOLDEN, name + ".npz"))
+        self.z = z
+        self.kwargs = json.loads(str(z["kwargs"]))
+        self.encoded = z["encoded"].tobytes()
+        self.image = torch.from_numpy(z["image"])
+        self.decoded = z["decoded"]
+        self.R, self.psnr = int(z["rank"]), float(z["psnr"])
+        self.K = self.kwargs.get("num_iters", 10)
+        self.patch_size = tuple(self.kwargs.get("patch_size", (8, 8))) if self.kwargs.get("patch", True) else None
+
+    def ref_factors(self):
+        from lrf_amd.container import decode_tensor, separate_bytes
+        _, fac = separate_bytes(self.encoded, 2)
+        return [decode_tensor(f) for f in separate_bytes(fac, 2)]
+
+
+@pytest.mark.parametrize("name", RGBANY_CASES)
+def test_oracle_rgb_any_matches_reference(name, oracle):
+    """CPU: numpy matrices + the oracle's BCD from the reference's initial factors = the reference's int8 factors; the
+    numpy decode of the reference's factors = the reference's pixels."""
+    c = RgbAnyCase(name)
+    u_ref, v_ref = c.ref_factors()
+    H, W = c.image.shape[-2:]
+    assert np.array_equal(oracle.rgb_decode_any(u_ref, v_ref, H, W, c.patch_size), c.decoded)
+    X = oracle.rgb_matrix_any(c.image.numpy(), c.patch_size)
+    u0, v0 = c.z["u0"], c.z["v0"]
+    if c.patch_size is not None:
+        mats, u0s, v0s = [X], [u0[0]], [v0[0]]
+    else:
+        mats, u0s, v0s = list(X), list(u0), list(v0)
+    us, vs = [], []
+    for Xm, a, b in zip(mats, u0s, v0s):
+        if c.K == 0:
+            u, v = torch.from_numpy(a).to(torch.int8).numpy(), torch.from_numpy(b).to(torch.int8).numpy()  # the truncating cast
+        else:
+            u, v = oracle.bcd(Xm, a, b, c.K, (-16, 15))
+        us.append(u.astype(np.int8)); vs.append(v.astype(np.int8))
+    u = us[0] if c.patch_size is not None else np.stack(us)
+    v = vs[0] if c.patch_size is not None else np.stack(vs)
+    assert np.array_equal(u, u_ref) and np.array_equal(v, v_ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", RGBANY_CASES)
+def test_hip_rgb_any_reproduces_reference(name, oracle):
+    import lrf_amd
+    from lrf_amd import _lib
+    c = RgbAnyCase(name)
+    H, W = c.image.shape[-2:]
+    ctx = _lib.context(0)
+    X = ctx.rgbspace_matrix_any(c.image.cuda().unsqueeze(0), c.patch_size)[0].cpu().numpy()
+    assert np.array_equal(X, oracle.rgb_matrix_any(c.image.numpy(), c.patch_size))
+    dec = lrf_amd.qmf_decode(c.encoded)
+    assert np.array_equal(dec.numpy(), c.decoded)
+    enc = lrf_amd.qmf_encode(c.image, color_space="RGB", init=(c.z["u0"], c.z["v0"]), **c.kwargs)
+    assert enc == c.encoded, "from the reference's initial factors the encoder must emit the reference's bytes"
+    own = lrf_amd.qmf_encode(c.image, color_space="RGB", **c.kwargs)  # own initialisation: by tolerance
+    d2 = lrf_amd.qmf_decode(own)
+    assert abs(_psnr(c.image.numpy(), d2.numpy()) - c.psnr) < (1.5 if c.K == 0 else 0.3)
+    assert abs(len(own) / len(c.encoded) - 1) < 0.08

@@ -253,6 +253,50 @@ def gen_rgbspace():
         json.dump(index, f, indent=1, sort_keys=True)
 
 
+RGBSPACE_ANY_CASES = [
+    # qmf_encode(color_space="RGB") beyond 8x8 patches: name, image spec, encoder kwargs
+    ("rgbany_p4_q6", dict(kind="randint", seed=31, H=50, W=70), dict(quality=6.0, patch_size=(4, 4))),
+    ("rgbany_p16_r5", dict(kind="smooth", seed=32, H=96, W=144), dict(rank=5, patch_size=(16, 16))),
+    ("rgbany_p8x4_q3", dict(kind="randint", seed=33, H=61, W=45), dict(quality=3.0, patch_size=(8, 4), num_iters=3)),
+    ("rgbany_nopatch_q8", dict(kind="smooth", seed=34, H=64, W=96), dict(quality=8.0, patch=False)),
+    ("rgbany_nopatch_r2", dict(kind="randint", seed=35, H=37, W=53), dict(rank=2, patch=False, num_iters=2)),
+    ("rgbany_p8_it0", dict(kind="smooth", seed=36, H=64, W=96), dict(quality=4.0, num_iters=0)),
+]
+
+
+def gen_rgbspace_any():
+    """The RGB colour-space branch for other patch sizes, patch=False and num_iters=0 (lrf/compression/qmf.py:164-212):
+    bytes, decoded image, PSNR and the reference's initial factors (from which the BCD is bit-reproducible)."""
+    torch.set_num_threads(1)
+    ns = ref_loader.load()
+    index = {}
+    for name, spec, kw in RGBSPACE_ANY_CASES:
+        img = make_image(spec)
+        enc = ns.cqmf.qmf_encode(img, color_space="RGB", **kw)
+        dec = ns.cqmf.qmf_decode(enc)
+        mse = torch.mean((img.float() - dec.float()) ** 2, dim=(-3, -2, -1))
+        psnr = (20 * torch.log10(255 / torch.sqrt(mse))).item()
+        meta = json.loads(ns.cutils.separate_bytes(enc, 2)[0].decode())
+        R = meta["rank"]
+        if kw.get("patch", True):
+            ps = tuple(kw.get("patch_size", (8, 8)))
+            x = ns.cqmf.patchify(ns.cutils.pad_image(img.float(), ps, mode="reflect"), ps).unsqueeze(0)
+        else:
+            x = img.float()
+        u0, v0, _ = ns.fqmf.SVDInit(rank=R)(x)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), encoded=np.frombuffer(enc, np.uint8), psnr=np.float64(psnr),
+                            spec=np.array(json.dumps(spec)), kwargs=np.array(json.dumps(kw)), image=img.numpy(), decoded=dec.numpy(),
+                            rank=np.int32(R), u0=np.ascontiguousarray(u0.numpy()), v0=np.ascontiguousarray(v0.numpy()))
+        index[name] = dict(bytes=len(enc), psnr=psnr, rank=R)
+        print(name, index[name], flush=True)
+    with open(os.path.join(OUT, "index_rgbspace_any.json"), "w") as f:
+        json.dump(index, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "rgbspace_any":
+    gen_rgbspace_any()
+
+
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "rgbspace":
     gen_rgbspace()
 
@@ -359,6 +403,45 @@ def gen_qmfx():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "qmfx":
     gen_qmfx()
+
+
+SVD_ANY_CASES = [
+    # svd_encode's RGB branch beyond the default: name, image spec, kwargs (dtype by name)
+    ("svdany_p4_q5", dict(kind="smooth", seed=41, H=50, W=70), dict(quality=5.0, patch_size=(4, 4))),
+    ("svdany_p16_r6", dict(kind="smooth", seed=42, H=96, W=144), dict(rank=6, patch_size=(16, 16))),
+    ("svdany_nopatch_q6", dict(kind="smooth", seed=43, H=64, W=96), dict(quality=6.0, patch=False)),
+    ("svdany_p8_float", dict(kind="smooth", seed=44, H=64, W=96), dict(quality=3.0, dtype="float32")),
+    ("svdany_nopatch_float", dict(kind="randint", seed=45, H=37, W=53), dict(rank=3, patch=False, dtype="float32")),
+]
+
+
+def gen_svd_any():
+    """svd_encode / svd_decode RGB branch with other patch sizes, patch=False and float factors (lrf/compression/svd.py:157-193,
+    310-326): reference bytes, decoded pixels, PSNR."""
+    torch.set_num_threads(1)
+    ns = ref_loader.load()
+    import importlib
+    csvd = importlib.import_module("lrf.compression.svd")
+    index = {}
+    for name, spec, kw in SVD_ANY_CASES:
+        img = make_image(spec)
+        kwr = dict(kw)
+        if "dtype" in kwr:
+            kwr["dtype"] = getattr(torch, kwr["dtype"])
+        enc = csvd.svd_encode(img, **kwr)
+        dec = csvd.svd_decode(enc)
+        mse = torch.mean((img.float() - dec.float()) ** 2, dim=(-3, -2, -1))
+        psnr = (20 * torch.log10(255 / torch.sqrt(mse))).item()
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), encoded=np.frombuffer(enc, np.uint8), psnr=np.float64(psnr),
+                            spec=np.array(json.dumps(spec)), kwargs=np.array(json.dumps(kw)), image=img.numpy(), decoded=dec.numpy())
+        index[name] = dict(bytes=len(enc), psnr=psnr)
+        print(name, index[name], flush=True)
+    with open(os.path.join(OUT, "index_svd_any.json"), "w") as f:
+        json.dump(index, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "svd_any":
+    gen_svd_any()
 
 
 def gen_loess():
