@@ -116,10 +116,11 @@ __device__ __forceinline__ void gram_accumulate(const uint4* __restrict__ lbuf, 
     }
 }
 
-// sum += (int128)v << sh  (sh < 64), two's complement in (lo, hi)
+// sum += (int128)v << sh  (sh <= 64), two's complement in (lo, hi)
 __device__ __forceinline__ void add_shifted_i128(unsigned long long& lo, long long& hi, int v, int sh)
 {
     const long long x = (long long)v;
+    if (sh == 64) { hi += x; return; }
     const unsigned long long l = (unsigned long long)x << sh;
     const long long h = sh ? (x >> (64 - sh)) : (x >> 63);
     const unsigned long long nl = lo + l;
@@ -129,21 +130,30 @@ __device__ __forceinline__ void add_shifted_i128(unsigned long long& lo, long lo
 
 // The five digits of four values (one packed dword per digit) for the matrices qmf_encode forms: every element is 0 or in
 // [2^-4, 2^8) and non-negative, so on the grid 2^-27 (E = 8) n = mantissa << (exponent - 123) exactly, no rounding, no sign.
+// Here the digits are BALANCED base-256 ones, d_k in [-128, 127]: n + 0x80808080 has the bytes d_k + 128, i.e. the bytes
+// of (n + 0x80808080) ^ 0x80808080 read as int8 ARE the four low digits, and the fifth is the carry-adjusted top word
+// (0..8) — no shifts or masks per digit, a 4 x 4 byte transpose (eight v_perm_b32) packs four values, and the weights become
+// 2^(8(a+b)) (k_gram64's fold).  172 VALU instructions per 64-row block and wave instead of the 360 of 7-bit digits.
 __device__ __forceinline__ void gram_digits4_planes(const float (&x)[4], unsigned (&pk)[5])
 {
-    unsigned lo[4], d4[4];
+    unsigned xb[4], d4[4];
 #pragma unroll
     for (int b = 0; b < 4; b++) {
         const unsigned u = __float_as_uint(x[b]), e = u >> 23;
         const unsigned long long m = e ? (unsigned long long)((u & 0x7fffffu) | 0x800000u) : 0ull;
-        const unsigned long long n = m << ((e - 123u) & 15u);
-        lo[b] = (unsigned)n;
-        d4[b] = (unsigned)(n >> 28);
+        const unsigned long long n = (m << ((e - 123u) & 15u)) + 0x80808080ull;
+        xb[b] = (unsigned)n ^ 0x80808080u;
+        d4[b] = (unsigned)(n >> 32);
     }
-#pragma unroll
-    for (int a = 0; a < 4; a++)
-        pk[a] = ((lo[0] >> (7 * a)) & 127u) | (((lo[1] >> (7 * a)) & 127u) << 8) | (((lo[2] >> (7 * a)) & 127u) << 16) |
-                (((lo[3] >> (7 * a)) & 127u) << 24);
+    // v_perm_b32(s0, s1, sel): byte selectors 0-3 pick from s1, 4-7 from s0
+    const unsigned t0 = __builtin_amdgcn_perm(xb[1], xb[0], 0x05010400u); // x0.b0 x1.b0 x0.b1 x1.b1
+    const unsigned t1 = __builtin_amdgcn_perm(xb[1], xb[0], 0x07030602u); // x0.b2 x1.b2 x0.b3 x1.b3
+    const unsigned t2 = __builtin_amdgcn_perm(xb[3], xb[2], 0x05010400u);
+    const unsigned t3 = __builtin_amdgcn_perm(xb[3], xb[2], 0x07030602u);
+    pk[0] = __builtin_amdgcn_perm(t2, t0, 0x05040100u); // x0.b0 x1.b0 x2.b0 x3.b0
+    pk[1] = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
+    pk[2] = __builtin_amdgcn_perm(t3, t1, 0x05040100u);
+    pk[3] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
     pk[4] = d4[0] | (d4[1] << 8) | (d4[2] << 16) | (d4[3] << 24);
 }
 
@@ -234,7 +244,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 unsigned long long lo = 0;
                 long long hi = 0;
 #pragma unroll
-                for (int w = 0; w < 9; w++) add_shifted_i128(lo, hi, acc[p][w][reg], 7 * w);
+                for (int w = 0; w < 9; w++) add_shifted_i128(lo, hi, acc[p][w][reg], (PLANES ? 8 : 7) * w); // digit base of the path
                 out[(pair0 + p) * 256 + reg * 64 + lane] = make_ulonglong2(lo, (unsigned long long)hi);
             }
         }
