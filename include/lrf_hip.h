@@ -305,6 +305,18 @@ int lrf_host_free(void* host);
 int lrf_host_register(void* host, size_t bytes);   /* page-locks memory the caller already owns */
 int lrf_host_unregister(void* host);
 
+/* The same three with an explicit chroma plane size hc x wc, for scale_factor other than (0.5, 0.5) (lrf/compression/qmf.py:230:
+ * F.interpolate(scale_factor, mode="area") produces floor(H * s_h) x floor(W * s_w), which the host computes; the pooling
+ * windows follow from the two sizes alone, lrf/compression/utils.py:92-94; decode :346-348 up-samples to the luma size with
+ * mode="nearest").  hc, wc <= 0: the default halves. */
+int lrf_plane_dims_any_hw(int64_t H, int64_t W, int64_t hc, int64_t wc, int p, int q, int ch, int64_t* h, int64_t* w, int64_t* hp,
+                          int64_t* wp, int64_t* M, int64_t* N);
+int lrf_qmf_planes_any_hw_u8(lrf_ctx* ctx, const uint8_t* rgb, int64_t B, int64_t H, int64_t W, int64_t hc, int64_t wc, int p, int q, int ch,
+                             float* X);
+int lrf_qmf_decode_any_hw_u8(lrf_ctx* ctx, const int8_t* U0, const int8_t* V0, const int8_t* U1, const int8_t* V1, const int8_t* U2,
+                             const int8_t* V2, int64_t B, int64_t H, int64_t W, int64_t hc, int64_t wc, int p, int q, const int R[3],
+                             uint8_t* rgb);
+
 #ifdef __cplusplus
 }
 #endif

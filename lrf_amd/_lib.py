@@ -82,6 +82,10 @@ def load():
         lib.lrf_qmf_rgbspace_matrix_u8.argtypes = [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_int, c_void_p]
         lib.lrf_qmf_rgbspace_decode_any_u8.argtypes = [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_void_p]
         lib.lrf_plane_dims_any.argtypes = [c_i64, c_i64, c_int, c_int, c_int] + [ctypes.POINTER(c_i64)] * 6
+        lib.lrf_plane_dims_any_hw.argtypes = [c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_int] + [ctypes.POINTER(c_i64)] * 6
+        lib.lrf_qmf_planes_any_hw_u8.argtypes = [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_void_p]
+        lib.lrf_qmf_decode_any_hw_u8.argtypes = [c_void_p] + [c_void_p] * 6 + [c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int,
+                                                                              ctypes.POINTER(c_int), c_void_p]
         lib.lrf_qmf_planes_any_u8.argtypes = [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_void_p]
         lib.lrf_qmf_decode_any_u8.argtypes = [c_void_p] + [c_void_p] * 6 + [c_i64, c_i64, c_i64, c_int, c_int,
                                                                            ctypes.POINTER(c_int), c_void_p]
@@ -113,7 +117,8 @@ EXPORTS = ["lrf_last_error", "lrf_device_count", "lrf_version", "lrf_ctx_create"
            "lrf_qmf_encode_rgb_u8", "lrf_qmf_decode_rgb_u8", "lrf_svd_encode_rgb_u8", "lrf_svd_decode_rgb_u8",
            "lrf_qmf_rgbspace_encode_u8", "lrf_qmf_rgbspace_decode_u8", "lrf_rgbspace_dims_any", "lrf_qmf_rgbspace_matrix_u8",
            "lrf_qmf_rgbspace_decode_any_u8", "lrf_quantize_u8", "lrf_svd_decode_any_u8",
-           "lrf_plane_dims_any", "lrf_qmf_planes_any_u8", "lrf_qmf_decode_any_u8",
+           "lrf_plane_dims_any", "lrf_qmf_planes_any_u8", "lrf_qmf_decode_any_u8", "lrf_plane_dims_any_hw", "lrf_qmf_planes_any_hw_u8",
+           "lrf_qmf_decode_any_hw_u8",
            "lrf_pipe_create", "lrf_pipe_destroy", "lrf_pipe_slots", "lrf_pipe_slot_ctx", "lrf_pipe_workspace_bytes",
            "lrf_pipe_qmf_encode_rgb_u8_host", "lrf_pipe_qmf_encode_submit", "lrf_pipe_wait_next",
            "lrf_host_alloc", "lrf_host_free", "lrf_host_register", "lrf_host_unregister"]
@@ -142,15 +147,26 @@ def plane_dims(H, W):
     return out
 
 
-def plane_dims_any(H, W, patch_size):
-    """[(h, w, hp, wp, M, N)] of the Y, Cb, Cr planes for patches (p, q); patch_size None = patch=False (M, N = h, w)."""
+def plane_dims_any(H, W, patch_size, chroma=None):
+    """[(h, w, hp, wp, M, N)] of the Y, Cb, Cr planes for patches (p, q); patch_size None = patch=False (M, N = h, w).
+    chroma: (hc, wc) for a scale_factor other than (0.5, 0.5); None = floor(H / 2) x floor(W / 2)."""
     p, q = (0, 0) if patch_size is None else (int(patch_size[0]), int(patch_size[1]))
+    hc, wc = (0, 0) if chroma is None else (int(chroma[0]), int(chroma[1]))
     out = []
     for c in range(3):
         v = [c_i64() for _ in range(6)]
-        check(load().lrf_plane_dims_any(H, W, p, q, c, *[ctypes.byref(x) for x in v]))
+        check(load().lrf_plane_dims_any_hw(H, W, hc, wc, p, q, c, *[ctypes.byref(x) for x in v]))
         out.append(tuple(int(x.value) for x in v))
     return out
+
+
+def chroma_size(H, W, scale_factor):
+    """floor(H * s_h) x floor(W * s_w): what F.interpolate(scale_factor=...) produces (lrf/compression/utils.py:92-94); None for
+    the default (0.5, 0.5)"""
+    import math
+    if tuple(scale_factor) == (0.5, 0.5):
+        return None
+    return (int(math.floor(float(H) * float(scale_factor[0]))), int(math.floor(float(W) * float(scale_factor[1]))))
 
 
 def rgbspace_dims_any(H, W, patch_size):
@@ -326,34 +342,36 @@ class Context:
         return rgb
 
 
-    def planes_any(self, rgb, patch_size, ch):
+    def planes_any(self, rgb, patch_size, ch, chroma=None):
         """rgb uint8 [B,3,H,W] (CUDA) -> X fp32 [B, M, N] of plane ch for patches (p, q) (None: the plane itself)"""
         import torch
         B, C, H, W = rgb.shape
         assert C == 3 and rgb.dtype == torch.uint8
         p, q = (0, 0) if patch_size is None else (int(patch_size[0]), int(patch_size[1]))
-        d = plane_dims_any(H, W, patch_size)[ch]
+        hc, wc = (0, 0) if chroma is None else (int(chroma[0]), int(chroma[1]))
+        d = plane_dims_any(H, W, patch_size, chroma)[ch]
         X = torch.empty((B, d[4], d[5]), dtype=torch.float32, device=rgb.device)
         self.use_torch_stream()
-        check(self._lib.lrf_qmf_planes_any_u8(self._h, _dptr(rgb.contiguous()), B, H, W, p, q, ch, _dptr(X)))
+        check(self._lib.lrf_qmf_planes_any_hw_u8(self._h, _dptr(rgb.contiguous()), B, H, W, hc, wc, p, q, ch, _dptr(X)))
         return X
 
-    def decode_any(self, Us, Vs, H, W, patch_size):
+    def decode_any(self, Us, Vs, H, W, patch_size, chroma=None):
         """three (U [B,M_c,R_c], V [B,N_c,R_c]) int8 CUDA pairs -> uint8 [B,3,H,W]"""
         import torch
         Us = [u.contiguous() for u in Us]
         Vs = [v.contiguous() for v in Vs]
         B = Us[0].shape[0]
         p, q = (0, 0) if patch_size is None else (int(patch_size[0]), int(patch_size[1]))
-        dims = plane_dims_any(H, W, patch_size)
+        hc, wc = (0, 0) if chroma is None else (int(chroma[0]), int(chroma[1]))
+        dims = plane_dims_any(H, W, patch_size, chroma)
         for c in range(3):
             assert Us[c].shape[1] == dims[c][4] and Vs[c].shape[1] == dims[c][5] and Us[c].shape[2] == Vs[c].shape[2], \
                 "factor shapes do not match the image geometry"
         rgb = torch.empty((B, 3, H, W), dtype=torch.uint8, device=Us[0].device)
         R = (c_int * 3)(*[int(u.shape[2]) for u in Us])
         self.use_torch_stream()
-        check(self._lib.lrf_qmf_decode_any_u8(self._h, _dptr(Us[0]), _dptr(Vs[0]), _dptr(Us[1]), _dptr(Vs[1]), _dptr(Us[2]),
-                                              _dptr(Vs[2]), B, H, W, p, q, R, _dptr(rgb)))
+        check(self._lib.lrf_qmf_decode_any_hw_u8(self._h, _dptr(Us[0]), _dptr(Vs[0]), _dptr(Us[1]), _dptr(Vs[1]), _dptr(Us[2]),
+                                                 _dptr(Vs[2]), B, H, W, hc, wc, p, q, R, _dptr(rgb)))
         return rgb
 
 

@@ -29,8 +29,8 @@ def qmf_ranks(image_hw, rank=None, quality=None):
 
 
 def _check_hip_branch(color_space, scale_factor, patch, patch_size, bounds, dtype, kwargs):
-    if color_space == "YCbCr" and tuple(scale_factor) != (0.5, 0.5):
-        raise NotImplementedError("HIP path covers scale_factor=(0.5,0.5) only")
+    if color_space == "YCbCr" and not (len(scale_factor) == 2 and min(scale_factor) > 0):
+        raise ValueError("scale_factor must be two positive numbers")
     if dtype is not torch.int8:
         raise NotImplementedError("HIP path stores int8 factors only")
     num_iters = kwargs.pop("num_iters", 10)
@@ -240,9 +240,10 @@ def qmf_encode(image: torch.Tensor, rank=None, quality=None, color_space: str = 
     if color_space == "RGB":
         return _qmf_encode_rgbspace(ctx, dev, rank, quality, bounds, (lo, hi), tuple(patch_size) if patch else None, num_iters, init_sign,
                                     kwargs.get("init"))
-    if not patch or tuple(patch_size) != (8, 8):
+    chroma = _lib.chroma_size(H, W, scale_factor)
+    if not patch or tuple(patch_size) != (8, 8) or chroma is not None:  # the any-shape path (also 8x8 with another scale factor)
         return _qmf_encode_anyshape(ctx, dev, rank, quality, bounds, (lo, hi), tuple(patch_size) if patch else None, num_iters,
-                                    init_sign, kwargs.get("init"))[0]
+                                    init_sign, kwargs.get("init"), chroma)[0]
     ranks = qmf_ranks((H, W), rank, quality)
     if num_iters == 0:
         factors = _svd_init_factors(ctx, dev, ranks, init_sign)
@@ -256,7 +257,7 @@ def qmf_encode(image: torch.Tensor, rank=None, quality=None, color_space: str = 
     return pack_image(factors, (H, W), ranks, bounds, patch_size, str(image.dtype).split(".")[-1])
 
 
-def anyshape_ranks(image_hw, patch_size, rank=None, quality=None):
+def anyshape_ranks(image_hw, patch_size, rank=None, quality=None, chroma=None):
     """Ranks of (Y, Cb, Cr) for patches `patch_size` (lrf/compression/qmf.py:244-250) or, with patch_size None,
     for patch=False (:268-274): max(round(min(M, N) * quality / 100), 1) on the matrix each plane becomes."""
     H, W = image_hw
@@ -265,7 +266,7 @@ def anyshape_ranks(image_hw, patch_size, rank=None, quality=None):
     if not isinstance(quality, Iterable):
         quality = (None, None, None) if quality is None else (quality, quality / 2, quality / 2)
     out = []
-    for i, d in enumerate(_lib.plane_dims_any(H, W, patch_size)):
+    for i, d in enumerate(_lib.plane_dims_any(H, W, patch_size, chroma)):
         if rank[i] is None:
             assert quality[i] >= 0 and quality[i] <= 100, "'quality' must be between 0 and 100."
             out.append(max(round(min(d[4], d[5]) * quality[i] / 100), 1))
@@ -274,7 +275,7 @@ def anyshape_ranks(image_hw, patch_size, rank=None, quality=None):
     return out
 
 
-def _qmf_encode_anyshape(ctx, dev, rank, quality, bounds, int_bounds, patch_size, num_iters, init_sign, init):
+def _qmf_encode_anyshape(ctx, dev, rank, quality, bounds, int_bounds, patch_size, num_iters, init_sign, init, chroma=None):
     """qmf_encode(color_space="YCbCr") with a patch size other than 8x8 (lrf/compression/qmf.py:232-262) or with
     patch=False (patch_size None, :264-286) for a batch dev [B,3,H,W]: per plane one matrix [M, N] per image, all images
     of a plane factorised in one call of the any-shape kernels.  Returns one byte stream per image.
@@ -282,11 +283,11 @@ def _qmf_encode_anyshape(ctx, dev, rank, quality, bounds, int_bounds, patch_size
     initialisation (tests); `init_sign`: [R0+R1+R2] or [B, R0+R1+R2]."""
     B = dev.shape[0]
     H, W = dev.shape[-2:]
-    dims = _lib.plane_dims_any(H, W, patch_size)
-    ranks = anyshape_ranks((H, W), patch_size, rank, quality)
+    dims = _lib.plane_dims_any(H, W, patch_size, chroma)
+    ranks = anyshape_ranks((H, W), patch_size, rank, quality, chroma)
     per_plane, soff = [], 0
     for c in range(3):
-        X = ctx.planes_any(dev, patch_size, c)
+        X = ctx.planes_any(dev, patch_size, c, chroma)
         R = ranks[c]
         sign = None
         if init_sign is not None:
@@ -310,15 +311,15 @@ def _qmf_encode_anyshape(ctx, dev, rank, quality, bounds, int_bounds, patch_size
         for u, v in per_plane:
             # patch=False keeps the plane's channel axis: the factors are 3-D there (qmf.py:281-282), 2-D with patches
             factors += [u[b:b + 1], v[b:b + 1]] if patch_size is None else [u[b], v[b]]
-        streams.append(pack_anyshape(factors, (H, W), ranks, bounds, patch_size, str(dev.dtype).split(".")[-1]))
+        streams.append(pack_anyshape(factors, (H, W), ranks, bounds, patch_size, str(dev.dtype).split(".")[-1], chroma))
     return streams
 
 
-def pack_anyshape(factors, image_hw, ranks, bounds, patch_size, dtype_name="uint8") -> bytes:
+def pack_anyshape(factors, image_hw, ranks, bounds, patch_size, dtype_name="uint8", chroma=None) -> bytes:
     """Byte stream of the patch-size / patch=False branches (metadata keys in the reference's order, qmf.py:157-162,
     233-254, 265-277, 288-290).  factors: [u_y, v_y, u_cb, v_cb, u_cr, v_cr] int8, 2-D with patches, [1, rows, R]
     without (the reference keeps the plane's channel axis there and encode_tensor stores such tensors whole)."""
-    dims = _lib.plane_dims_any(image_hw[0], image_hw[1], patch_size)
+    dims = _lib.plane_dims_any(image_hw[0], image_hw[1], patch_size, chroma)
     metadata = {"dtype": dtype_name, "color space": "YCbCr", "patch": patch_size is not None, "bounds": bounds}
     if patch_size is not None:
         metadata["patch size"] = patch_size
@@ -339,11 +340,16 @@ def _qmf_decode_anyshape(encoded_image: bytes, device=None) -> torch.Tensor:
     patch_size = tuple(metadata["patch size"]) if metadata["patch"] else None
     f = [decode_tensor(x) for x in separate_bytes(encoded_factors, 6)]
     H, W = metadata["original size"][0]
-    dims = _lib.plane_dims_any(H, W, patch_size)
+    chroma = tuple(int(v) for v in metadata["original size"][1])  # any scale_factor: the stream carries the plane sizes
+    if chroma == (H // 2, W // 2):
+        chroma = None
+    dims = _lib.plane_dims_any(H, W, patch_size, chroma)
     for c in range(3):
         if list(metadata["original size"][c]) != [dims[c][0], dims[c][1]] or \
                 (patch_size is not None and list(metadata["padded size"][c]) != [dims[c][2], dims[c][3]]):
-            raise NotImplementedError("stream geometry is not the scale_factor=(0.5,0.5) / reflect-padded layout")
+            raise ValueError("stream geometry is not the reflect-padded layout its plane sizes imply (Cb and Cr must agree)")
+        if tuple(f[2 * c].shape[-2:]) != (dims[c][4], f[2 * c].shape[-1]) or tuple(f[2 * c + 1].shape[-2:]) != (dims[c][5], f[2 * c].shape[-1]):
+            raise ValueError("stream factors do not match the plane geometry its metadata describes")
     ctx = _lib.context(device)
     Us, Vs = [], []
     for c in range(3):
@@ -351,7 +357,7 @@ def _qmf_decode_anyshape(encoded_image: bytes, device=None) -> torch.Tensor:
         v = np.array(f[2 * c + 1], dtype=np.int8)
         Us.append(torch.from_numpy(u.reshape(1, dims[c][4], -1)).cuda(ctx.device))
         Vs.append(torch.from_numpy(v.reshape(1, dims[c][5], -1)).cuda(ctx.device))
-    return ctx.decode_any(Us, Vs, H, W, patch_size)[0]
+    return ctx.decode_any(Us, Vs, H, W, patch_size, chroma)[0]
 
 
 def rgbspace_dims(H, W):
@@ -503,6 +509,7 @@ def qmf_decode(encoded_image: bytes) -> torch.Tensor:
     meta = bytes_to_dict(separate_bytes(encoded_image, 2)[0])
     if meta["color space"] == "RGB":
         return _qmf_decode_rgbspace(encoded_image).cpu()
-    if not meta["patch"] or list(meta["patch size"]) != [8, 8]:
+    H, W = meta["original size"][0]
+    if not meta["patch"] or list(meta["patch size"]) != [8, 8] or list(meta["original size"][1]) != [H // 2, W // 2]:
         return _qmf_decode_anyshape(encoded_image).cpu()
     return qmf_decode_batch([encoded_image])[0].cpu()

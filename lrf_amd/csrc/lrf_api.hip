@@ -1379,23 +1379,30 @@ int lrf_svd_decode_any_u8(lrf_ctx* c, const void* U, const void* V, int factors_
     return LRF_OK;
 }
 
-int lrf_plane_dims_any(int64_t H, int64_t W, int p, int q, int ch, int64_t* h, int64_t* w, int64_t* hp, int64_t* wp, int64_t* M,
-                       int64_t* N)
+int lrf_plane_dims_any_hw(int64_t H, int64_t W, int64_t hc, int64_t wc, int p, int q, int ch, int64_t* h, int64_t* w, int64_t* hp,
+                          int64_t* wp, int64_t* M, int64_t* N)
 {
     if (!h || !w || !hp || !wp || !M || !N) return set_err(LRF_EINVAL, "NULL argument");
     AnyGeom g;
-    int rc = any_geom(H, W, p, q, ch, &g);
+    int rc = any_geom(H, W, p, q, ch, &g, hc, wc);
     if (rc) return rc;
     *h = g.h; *w = g.w; *hp = g.hp; *wp = g.wp; *M = g.M; *N = g.N;
     return LRF_OK;
 }
 
-int lrf_qmf_planes_any_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_t H, int64_t W, int p, int q, int ch, float* X)
+int lrf_plane_dims_any(int64_t H, int64_t W, int p, int q, int ch, int64_t* h, int64_t* w, int64_t* hp, int64_t* wp, int64_t* M,
+                       int64_t* N)
+{
+    return lrf_plane_dims_any_hw(H, W, 0, 0, p, q, ch, h, w, hp, wp, M, N);
+}
+
+int lrf_qmf_planes_any_hw_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_t H, int64_t W, int64_t hc, int64_t wc, int p, int q, int ch,
+                             float* X)
 {
     if (!c || !rgb || !X) return set_err(LRF_EINVAL, "NULL argument");
     if (B < 1 || B > 65535) return set_err(LRF_EINVAL, "B=%ld out of range [1,65535]", (long)B);
     AnyGeom g;
-    int rc = any_geom(H, W, p, q, ch, &g);
+    int rc = any_geom(H, W, p, q, ch, &g, hc, wc);
     if (rc) return rc;
     LRF_ON_DEVICE(c);
     const long elems = g.M * g.N;
@@ -1406,8 +1413,20 @@ int lrf_qmf_planes_any_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_t H, 
     return LRF_OK;
 }
 
+int lrf_qmf_planes_any_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_t H, int64_t W, int p, int q, int ch, float* X)
+{
+    return lrf_qmf_planes_any_hw_u8(c, rgb, B, H, W, 0, 0, p, q, ch, X);
+}
+
 int lrf_qmf_decode_any_u8(lrf_ctx* c, const int8_t* U0, const int8_t* V0, const int8_t* U1, const int8_t* V1, const int8_t* U2,
                           const int8_t* V2, int64_t B, int64_t H, int64_t W, int p, int q, const int R[3], uint8_t* rgb)
+{
+    return lrf_qmf_decode_any_hw_u8(c, U0, V0, U1, V1, U2, V2, B, H, W, 0, 0, p, q, R, rgb);
+}
+
+int lrf_qmf_decode_any_hw_u8(lrf_ctx* c, const int8_t* U0, const int8_t* V0, const int8_t* U1, const int8_t* V1, const int8_t* U2,
+                             const int8_t* V2, int64_t B, int64_t H, int64_t W, int64_t hc, int64_t wc, int p, int q, const int R[3],
+                             uint8_t* rgb)
 {
     if (!c || !U0 || !V0 || !U1 || !V1 || !U2 || !V2 || !R || !rgb) return set_err(LRF_EINVAL, "NULL argument");
     if (B < 1 || B > 65535) return set_err(LRF_EINVAL, "B=%ld out of range [1,65535]", (long)B);
@@ -1416,7 +1435,7 @@ int lrf_qmf_decode_any_u8(lrf_ctx* c, const int8_t* U0, const int8_t* V0, const 
     AnyDecodePlane d[3];
     for (int ch = 0; ch < 3; ch++) {
         AnyGeom g;
-        int rc = any_geom(H, W, p, q, ch, &g);
+        int rc = any_geom(H, W, p, q, ch, &g, hc, wc);
         if (rc) return rc;
         if (R[ch] < 1 || R[ch] > 16384) return set_err(LRF_EINVAL, "rank %d out of range", R[ch]);
         d[ch].U = Us[ch]; d[ch].V = Vs[ch];

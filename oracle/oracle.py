@@ -285,13 +285,14 @@ def svd_topr_any(X, R, sign=None):
     return u, v
 
 
-def ycbcr_planes(rgb):
-    """uint8 [3,H,W] -> [Y [H,W], Cb [h,w], Cr [h,w]] fp32: rgb_to_ycbcr + chroma_downsampling(0.5, area)."""
+def ycbcr_planes(rgb, chroma=None):
+    """uint8 [3,H,W] -> [Y [H,W], Cb [h,w], Cr [h,w]] fp32: rgb_to_ycbcr + chroma_downsampling(area) to `chroma` = (h, w)
+    (None: scale_factor (0.5, 0.5), i.e. floor(H / 2) x floor(W / 2); F.interpolate's area mode only sees the two sizes)."""
     rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
     _, H, W = rgb.shape
     ycc = np.empty((3, H, W), np.float32)
     lib().lrf_oracle_rgb_to_ycbcr(_ptr(rgb, _u8p), c_long(H), c_long(W), _ptr(ycc, _fp))
-    h, w = H // 2, W // 2
+    h, w = (H // 2, W // 2) if chroma is None else chroma
     out = [ycc[0].copy()]
     for c in (1, 2):
         ds = np.empty((h, w), np.float32)
@@ -300,28 +301,28 @@ def ycbcr_planes(rgb):
     return out
 
 
-def anyshape_matrices(rgb, patch_size):
+def anyshape_matrices(rgb, patch_size, chroma=None):
     """The three matrices qmf_encode factorises: patches (p, q) of the reflect-padded planes, or the planes (None)."""
-    planes = ycbcr_planes(rgb)
+    planes = ycbcr_planes(rgb, chroma)
     if patch_size is None:
         return planes
     return [pad_patchify(pl[None], patch_size[0], patch_size[1]) for pl in planes]
 
 
-def qmf_anyshape_decompose(rgb, patch_size, ranks, num_iters=10, bounds=(-16, 15), signs=None, inits=None):
+def qmf_anyshape_decompose(rgb, patch_size, ranks, num_iters=10, bounds=(-16, 15), signs=None, inits=None, chroma=None):
     """-> [(u, v)] * 3 fp32 (integer valued for num_iters >= 1)."""
     out = []
-    for c, X in enumerate(anyshape_matrices(rgb, patch_size)):
+    for c, X in enumerate(anyshape_matrices(rgb, patch_size, chroma)):
         u0, v0 = inits[c] if inits is not None else svd_topr_any(X, ranks[c], None if signs is None else signs[c])
         out.append(bcd(X, u0, v0, num_iters, bounds) if num_iters > 0 else (u0, v0))
     return out
 
 
-def qmf_anyshape_decode(factors, H, W, patch_size):
+def qmf_anyshape_decode(factors, H, W, patch_size, chroma=None):
     """[(u, v)] * 3 integer factors -> uint8 [3,H,W]: u @ v.mT, depatchify + unpad, nearest up-sampling, ycbcr_to_rgb, to_dtype."""
     ycc = np.empty((3, H, W), np.float32)
     for c, (u, v) in enumerate(factors):
-        h, w = (H, W) if c == 0 else (H // 2, W // 2)
+        h, w = (H, W) if c == 0 else ((H // 2, W // 2) if chroma is None else chroma)
         X = np.asarray(u, dtype=np.float32) @ np.asarray(v, dtype=np.float32).T  # exact small integers
         if patch_size is not None:
             p, q = patch_size

@@ -291,3 +291,63 @@ def test_hip_batch_encode_equals_single_calls():
     for kw in (dict(patch_size=(16, 16)), dict(patch=False), dict(patch_size=(4, 4))):
         got = lrf_amd.qmf_encode_batch(imgs, quality=12, **kw)
         assert got == [lrf_amd.qmf_encode(im, quality=12, **kw) for im in imgs]
+
+
+# ---------------------------------------------------------------- chroma scale factors other than (0.5, 0.5) (qmf.py:230)
+SCALE = ["sf_quarter_q10", "sf_444_r5", "sf_mixed_odd_q12", "sf_nopatch_q8"]
+
+
+def _sf_params(c):
+    import math
+    kw = c.kwargs
+    ps = tuple(kw.get("patch_size", (8, 8))) if kw.get("patch", True) else None
+    H, W = c.image.shape[-2:]
+    sf = kw["scale_factor"]
+    return ps, (int(math.floor(float(H) * sf[0])), int(math.floor(float(W) * sf[1])))
+
+
+@pytest.mark.parametrize("name", SCALE)
+def test_oracle_scale_factors_reproduce_reference(name, oracle):
+    """CPU: planes at the stream's chroma size, BCD from the reference's initial factors, container = the reference's bytes;
+    decode of its factors = its pixels."""
+    from lrf_amd.codec import pack_anyshape
+    c = Case(name)
+    ps, chroma = _sf_params(c)
+    H, W = c.image.shape[-2:]
+    inits = [(c.z[f"u0_{i}"], c.z[f"v0_{i}"]) for i in range(3)]
+    fac = oracle.qmf_anyshape_decompose(c.image.numpy(), ps, c.ranks, 10, (-16, 15), inits=inits, chroma=chroma)
+    flat = []
+    for u, v in fac:
+        u8, v8 = u.astype(np.int8), v.astype(np.int8)
+        flat += [u8, v8] if ps is not None else [u8[None], v8[None]]
+    import lrf_amd
+    from lrf_amd import _lib
+    dims = _lib.plane_dims_any(H, W, ps, chroma)
+    assert [list(d[:2]) for d in dims][1] == list(chroma)
+    assert pack_anyshape(flat, (H, W), c.ranks, (-16, 15), ps, "uint8", chroma) == c.encoded
+    f = _ref_factors2d(c)
+    dec = oracle.qmf_anyshape_decode(list(zip(f[0::2], f[1::2])), H, W, ps, chroma)
+    assert _sha(dec) == c.decoded_sha256
+    assert lrf_amd is not None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SCALE)
+def test_hip_scale_factors(name, oracle):
+    import lrf_amd
+    from lrf_amd import _lib
+    c = Case(name)
+    ps, chroma = _sf_params(c)
+    H, W = c.image.shape[-2:]
+    ctx = _lib.context(0)
+    want = oracle.anyshape_matrices(c.image.numpy(), ps, chroma)
+    for ch in range(3):
+        X = ctx.planes_any(c.image.cuda().unsqueeze(0), ps, ch, chroma)[0].cpu().numpy()
+        assert np.array_equal(X.view(np.int32), np.ascontiguousarray(want[ch]).view(np.int32)), ch
+    dec = lrf_amd.qmf_decode(c.encoded)
+    assert _sha(dec.numpy()) == c.decoded_sha256
+    inits = [(c.z[f"u0_{i}"], c.z[f"v0_{i}"]) for i in range(3)]
+    enc = lrf_amd.qmf_encode(c.image, init=inits, **c.kwargs)
+    assert enc == c.encoded, "from the reference's initial factors the encoder must emit the reference's bytes"
+    own = lrf_amd.qmf_encode(c.image, **c.kwargs)
+    assert abs(_psnr(c.image.numpy(), lrf_amd.qmf_decode(own).numpy()) - c.psnr) < 0.3

@@ -82,13 +82,13 @@ def test_unsupported_branches_raise():
         lrf_amd.qmf_encode(img)
     with pytest.raises(AssertionError):
         lrf_amd.qmf_encode(img, quality=7, color_space="HSV")
-    with pytest.raises(NotImplementedError):
-        lrf_amd.qmf_encode(img, quality=7, scale_factor=(0.25, 0.25))
+    with pytest.raises(ValueError):
+        lrf_amd.qmf_encode(img, quality=7, scale_factor=(0.0, 0.5))
     with pytest.raises(NotImplementedError):
         lrf_amd.svd_encode(img, quality=7, color_space="YCbCr")
     if not torch.cuda.is_available():  # the implemented branches need the GPU: no CPU fallback
         for kw in (dict(color_space="RGB"), dict(patch=False), dict(patch_size=(4, 4)), dict(color_space="RGB", patch_size=(16, 16)),
-                   dict(color_space="RGB", patch=False)):
+                   dict(color_space="RGB", patch=False), dict(scale_factor=(0.25, 0.25))):
             with pytest.raises(RuntimeError):
                 lrf_amd.qmf_encode(img, quality=7, **kw)
 

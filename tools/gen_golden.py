@@ -89,7 +89,7 @@ def main():
         cr = img.numel() * img.element_size() / len(enc)                   # lrf/utils/metrics.py:120-133
         # the reference's init signs (and small init factors) per plane
         ycbcr = ns.cutils.rgb_to_ycbcr(img.float())
-        chans = ns.cutils.chroma_downsampling(ycbcr, scale_factor=(0.5, 0.5), mode="area")
+        chans = ns.cutils.chroma_downsampling(ycbcr, scale_factor=tuple(kw.get("scale_factor", (0.5, 0.5))), mode="area")
         meta = json.loads(ns.cutils.separate_bytes(enc, 2)[0].decode())
         arrays = dict(encoded=np.frombuffer(enc, np.uint8), psnr=np.float64(psnr), bpp=np.float64(bpp),
                       cr=np.float64(cr), spec=np.array(json.dumps(spec)), kwargs=np.array(json.dumps(kw)),
@@ -319,15 +319,22 @@ ANYSHAPE_CASES = [
     ("any_s1_p32_q20", dict(kind="smooth", seed=5, H=512, W=768), dict(quality=20, patch_size=(32, 32)), False, False),
     ("any_s1_nopatch_q20", dict(kind="smooth", seed=5, H=512, W=768), dict(quality=20, patch=False), False, False),
 ]
+SCALE_CASES = [
+    # chroma scale factors other than (0.5, 0.5) (lrf/compression/qmf.py:230): 8x8 patches, another patch size, no patches
+    ("sf_quarter_q10", dict(kind="smooth", seed=51, H=64, W=96), dict(quality=10, scale_factor=(0.25, 0.25)), True, True),
+    ("sf_444_r5", dict(kind="randint", seed=52, H=40, W=56), dict(rank=5, scale_factor=(1.0, 1.0)), True, True),
+    ("sf_mixed_odd_q12", dict(kind="smooth", seed=53, H=75, W=101), dict(quality=12, scale_factor=(0.3, 0.7), patch_size=(4, 4)), True, True),
+    ("sf_nopatch_q8", dict(kind="smooth", seed=54, H=64, W=96), dict(quality=8, scale_factor=(0.5, 0.25), patch=False), True, True),
+]
 
 
-def gen_anyshape():
+def gen_anyshape(cases=None, index_name="index_anyshape.json"):
     """Fixtures of the patch-size / patch=False branches: bytes, decoded image, PSNR, the reference's per-plane matrices'
     initial factors (u0, v0) for the small cases and their column signs for all."""
     torch.set_num_threads(1)
     ns = ref_loader.load()
     index = {}
-    for name, spec, kw, store_image, store_init in ANYSHAPE_CASES:
+    for name, spec, kw, store_image, store_init in (ANYSHAPE_CASES if cases is None else cases):
         img = make_image(spec)
         enc = ns.cqmf.qmf_encode(img, **kw)
         dec = ns.cqmf.qmf_decode(enc)
@@ -335,7 +342,7 @@ def gen_anyshape():
         psnr = (20 * torch.log10(255 / torch.sqrt(mse))).item()
         meta = json.loads(ns.cutils.separate_bytes(enc, 2)[0].decode())
         ycbcr = ns.cutils.rgb_to_ycbcr(img.float())
-        chans = ns.cutils.chroma_downsampling(ycbcr, scale_factor=(0.5, 0.5), mode="area")
+        chans = ns.cutils.chroma_downsampling(ycbcr, scale_factor=tuple(kw.get("scale_factor", (0.5, 0.5))), mode="area")
         arrays = dict(encoded=np.frombuffer(enc, np.uint8), psnr=np.float64(psnr),
                       bpp=np.float64(len(enc) * 8 / (img.shape[-2] * img.shape[-1])),
                       spec=np.array(json.dumps(spec)), kwargs=np.array(json.dumps(kw)),
@@ -344,7 +351,7 @@ def gen_anyshape():
                       ranks=np.array(meta["rank"], np.int32))
         for c, ch in enumerate(chans):
             if kw.get("patch", True):
-                ps = kw["patch_size"]
+                ps = kw.get("patch_size", (8, 8))
                 x = ns.cqmf.patchify(ns.cutils.pad_image(ch, ps, mode="reflect"), ps)
             else:
                 x = ch[0]
@@ -361,8 +368,12 @@ def gen_anyshape():
         index[name] = dict(spec=spec, kwargs=kw, bytes=len(enc), psnr=psnr, ranks=meta["rank"],
                            enc_sha256=hashlib.sha256(enc).hexdigest()[:16])
         print(name, index[name], flush=True)
-    with open(os.path.join(OUT, "index_anyshape.json"), "w") as f:
+    with open(os.path.join(OUT, index_name), "w") as f:
         json.dump(index, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "scale":
+    gen_anyshape(SCALE_CASES, "index_scale.json")
 
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "anyshape":
