@@ -457,3 +457,24 @@ def test_workspace_trim():
     assert ctx.workspace_bytes() == 0
     U2, V2 = lrf_amd.qmf_factorize_batch(imgs, [7, 3, 3])
     assert torch.equal(U, U2) and torch.equal(V, V2) and ctx.workspace_bytes() > 0
+
+
+@pytest.mark.parametrize("bounds", [(-16, 15), (-3, 5), (-32, 31), (-128, 127)])
+def test_ranks_17_to_32_equal_oracle(bounds, oracle):
+    """k_bcd_mid / k_vupdate_mid (ranks 17..32): the exact-integer quad solve (bounds where (R-1) 64 mx^3 < 2^24 for the
+    largest rank of the call: the first two sets) and the ordered chain in registers (first iteration, and every iteration
+    of the wider bounds), mixed with planes of smaller rank in the same call; ragged blocks (173x264) and a block-aligned size."""
+    import lrf_amd
+    from lrf_amd.codec import split_factors
+    for hw, seed in (((173, 264), 78), ((128, 192), 79)):
+        g = torch.Generator().manual_seed(seed)
+        img = torch.randint(0, 256, (3,) + hw, dtype=torch.uint8, generator=g)
+        X = oracle.rgb_to_planes(img.numpy())
+        H, W = hw
+        for ranks in ((17, 9, 8), (20, 10, 10), (26, 13, 13), (32, 17, 1), (5, 32, 24)):
+            U, V = lrf_amd.qmf_factorize_batch(img.cuda().unsqueeze(0), ranks, num_iters=3, bounds=bounds)
+            got = split_factors(U[0].cpu().numpy(), V[0].cpu().numpy(), (H, W), ranks)
+            for c in range(3):
+                u, v = oracle.qmf_decompose(X[c], ranks[c], 3, bounds)
+                assert np.array_equal(got[2 * c], u.astype(np.int8)), f"{hw} ranks {ranks} bounds {bounds}: U plane {c}"
+                assert np.array_equal(got[2 * c + 1], v.astype(np.int8)), f"{hw} ranks {ranks} bounds {bounds}: V plane {c}"
