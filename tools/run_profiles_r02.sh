@@ -15,6 +15,7 @@ python bench.py --config svd --steps 5 --warmup 1 > $OUT/bench_svd.json 2> $OUT/
 python tools/run_config3.py $OUT/config3.json > $OUT/config3.txt 2> $OUT/config3.err
 cd /tmp
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats -o run -- python3 $REPO/bench.py --no-cpu-baseline > $OUT/stats_bench.json 2> $OUT/stats.err
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats_plain -o run -- python3 $REPO/bench.py --no-extras > $OUT/stats_plain_bench.json 2> $OUT/stats_plain.err
 rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o run -- python3 $REPO/bench.py --no-extras --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o run -- python3 $REPO/bench.py --no-extras --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_write.err
 rocprofv3 --output-format csv --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU GRBM_GUI_ACTIVE -d $OUT/sq_a -o run -- python3 $REPO/bench.py --no-extras --steps 2 --warmup 1 > /dev/null 2> $OUT/sq_a.err
