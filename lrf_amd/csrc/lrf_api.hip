@@ -1127,7 +1127,7 @@ int lrf_host_unregister(void* p)
     return LRF_OK;
 }
 
-#ifdef LRF_STAMPS
+#if defined(LRF_STAMPS) || defined(LRF_INIT_STAMPS)
 int lrf_debug_read_stamps(lrf_ctx* c, unsigned long long* out_host, int n)
 {
     HIP_TRY(hipStreamSynchronize(c->stream));

@@ -20,6 +20,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double d16 __attribute__((ext_vector_type(16)));
 
 #define LRF_EPS 1e-16f
 // Householder columns whose squared norm is at or below this are skipped (oracle: tridiagonalize): cascaded rounding noise of
@@ -27,7 +28,7 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 #define LRF_SIGMA_TINY 1e-280
 
 // Diagnostic build only (-DLRF_STAMPS, never shipped): per-phase cycle sums of k_bcd, wave 0 of each workgroup.
-#ifdef LRF_STAMPS
+#if defined(LRF_STAMPS) || defined(LRF_INIT_STAMPS)
 __device__ unsigned long long g_stamps[8 * 16384];
 __device__ __forceinline__ unsigned long long stamp_now()
 {
@@ -37,6 +38,8 @@ __device__ __forceinline__ unsigned long long stamp_now()
     __builtin_amdgcn_sched_barrier(0);
     return t;
 }
+#endif
+#ifdef LRF_STAMPS
 #define STAMP(var) unsigned long long var = stamp_now()
 #define STAMP_ADD(acc, a, b) acc += (b) - (a)
 __device__ unsigned long long g_gsp[4 * 16384];
@@ -329,16 +332,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const int E = fixed_exp != LRF_GRAM_EXP_FROM_DATA ? fixed_exp : gexp[blockIdx.x];
         const double back = scalbn(1.0, 2 * (E - LRF_GRAM_BITS));
         const ulonglong2* gp = Gpart + (long)pd.gch0 * LRF_GRAM_SLOT;
-        for (int e = tid; e < LRF_GRAM_SLOT; e += 256) {
-            unsigned long long lo = 0;
-            long long hi = 0;
-            for (int c = 0; c < pd.ngch; c++) {
-                const ulonglong2 v = gp[(long)c * LRF_GRAM_SLOT + e];
-                const unsigned long long nl = lo + v.x;
-                hi += (long long)v.y + (nl < lo ? 1 : 0);
-                lo = nl;
+        // chunk by chunk with the ten elements of a thread in flight together (one memory round trip per chunk, not per load)
+        constexpr int NE = LRF_GRAM_SLOT / 256;
+        unsigned long long lo[NE];
+        long long hi[NE];
+#pragma unroll
+        for (int m = 0; m < NE; m++) { lo[m] = 0; hi[m] = 0; }
+        for (int c = 0; c < pd.ngch; c++) {
+            ulonglong2 v[NE];
+#pragma unroll
+            for (int m = 0; m < NE; m++) v[m] = gp[(long)c * LRF_GRAM_SLOT + tid + 256 * m];
+#pragma unroll
+            for (int m = 0; m < NE; m++) {
+                const unsigned long long nl = lo[m] + v[m].x;
+                hi[m] += (long long)v[m].y + (nl < lo[m] ? 1 : 0);
+                lo[m] = nl;
             }
-            const double g = i128_to_double_rne(lo, hi) * back;
+        }
+#pragma unroll
+        for (int m = 0; m < NE; m++) {
+            const int e = tid + 256 * m;
+            const double g = i128_to_double_rne(lo[m], hi[m]) * back;
             int ti, tj;
             gram_pair_tiles(e >> 8, ti, tj);
             const int ln = e & 63, reg = (e >> 6) & 3;
@@ -354,74 +368,103 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     // wave g) holds A[16g + jj][i] (= A[i][16g + jj], the matrix stays exactly symmetric), jj = 0..15.  The LDS copy of
     // the Gram matrix is dead from here on and its rows are reused for the Householder vectors v_k (read again by the
     // back-transformation).  Terms the oracle skips (j <= k) are fma(a, 0, c) = c here: v_k[j] = 0 there.
-    double Ar[16];
+    d16 Ar; // a vector, not an array: row k is picked with a wave-uniform register index (s_set_gpr_idx), not 15 selects
 #pragma unroll
     for (int jj = 0; jj < 16; jj++) Ar[jj] = G[(16 * wave + jj) * 64 + lane];
     __syncthreads();
+#ifdef LRF_INIT_STAMPS
+    unsigned long long acc_a = 0, acc_b = 0, acc_c = 0, acc_d = 0;
+    const unsigned long long t_begin = stamp_now();
+#define ISTAMP(var) unsigned long long var = stamp_now()
+#else
+#define ISTAMP(var)
+#endif
     for (int k = 0; k < 62; k++) {
+        ISTAMP(s0);
         double* vbuf = L.v + 64 * (k & 1); // v, w double-buffered: one barrier fewer per step
         double* wbuf = L.w + 64 * (k & 1);
         if (wave == (k >> 4)) { // the wave that holds row k
             const int i = lane;
-            double xk = Ar[0];
-#pragma unroll
-            for (int jj = 1; jj < 16; jj++) xk = ((k & 15) == jj) ? Ar[jj] : xk;
+            const double xk = Ar[k & 15];
             double x = (i > k) ? xk : 0.0;
             double sigma = wave_tree64(x * x);
-            double tk = 0.0, ek = 0.0, vi = 0.0;
+            double hk = 0.0, ek = 0.0, vi = 0.0;
             if (sigma > LRF_SIGMA_TINY) {
-                double x0 = __shfl(x, k + 1, 64);
+                const double x0 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), k + 1),
+                                                   __builtin_amdgcn_readlane(__double2loint(x), k + 1));
                 double nrm = sqrt(sigma);
                 double alpha = (x0 >= 0.0) ? -nrm : nrm;
                 vi = (i > k + 1) ? x : 0.0;
                 if (i == k + 1) vi = x0 - alpha;
-                double vn = wave_tree64(vi * vi);
-                tk = 2.0 / vn;
+                hk = fma(fabs(x0), nrm, sigma); // |v|^2 / 2
                 ek = alpha;
             }
             vbuf[i] = vi;
             if (i > k) G[k * 64 + i] = vi; // row k of the LDS matrix: v_k for the back-transformation
-            if (i == 0) { L.tau[k] = tk; L.e[k] = ek; L.scal[0] = tk; L.flag[k & 1] = (sigma > LRF_SIGMA_TINY); }
+            if (i == 0) { L.tau[k] = 0.0; L.e[k] = ek; L.scal[0] = hk; L.flag[k & 1] = (sigma > LRF_SIGMA_TINY); }
         }
         __syncthreads();
+        ISTAMP(s1);
+#ifdef LRF_INIT_STAMPS
+        acc_a += s1 - s0;
+#endif
         if (L.flag[k & 1]) { // flag double-buffered like v: a wave that skips ahead must not overwrite what others still read
             double vj[16];
 #pragma unroll
             for (int jj = 0; jj < 16; jj++) vj[jj] = vbuf[16 * wave + jj];
-            { // matvec partial chains: thread (row i, column group g)
-                double c = 0.0;
+            double t = 0.0;
+            if (wave == 0) t = 1.0 / L.scal[0]; // 2 / |v|^2: the division runs under the chains below
+            { // matvec partial chains: thread (row i, column group g), two chains of eight
+                double ca = 0.0, cb = 0.0;
 #pragma unroll
-                for (int jj = 0; jj < 16; jj++) c = fma(Ar[jj], vj[jj], c);
-                L.cpart[wave * 64 + lane] = (lane > k) ? c : 0.0;
+                for (int jj = 0; jj < 8; jj++) {
+                    ca = fma(Ar[jj], vj[jj], ca);
+                    cb = fma(Ar[8 + jj], vj[8 + jj], cb);
+                }
+                L.cpart[wave * 64 + lane] = (lane > k) ? ca + cb : 0.0;
             }
             __syncthreads();
+            ISTAMP(s2);
             if (wave == 0) {
                 const int i = lane;
-                double t = L.scal[0];
                 double p = t * (((L.cpart[i] + L.cpart[64 + i]) + L.cpart[128 + i]) + L.cpart[192 + i]);
                 double vi = vbuf[i];
                 double K = (0.5 * t) * wave_tree64(p * vi);
                 wbuf[i] = fma(-K, vi, p);
+                if (i == 0) L.tau[k] = t;
             }
             __syncthreads();
-            { // rank-2 update, canonical (max,min) formula so that the matrix stays exactly symmetric
-                const int c = lane;
-                const double vc = vbuf[c], wc = wbuf[c];
-                double wj[16];
-#pragma unroll
-                for (int jj = 0; jj < 16; jj++) wj[jj] = wbuf[16 * wave + jj];
+            ISTAMP(s3);
+#ifdef LRF_INIT_STAMPS
+            acc_b += s2 - s1;
+            acc_c += s3 - s2;
+#endif
+            { // rank-2 update A -= v w^T + w v^T: the two products are rounded, then added (commutative), so element (r, c) and
+              // its mirror image get the same bits without choosing an order per element.  v and w are zero up to index k,
+              // which leaves the finished rows and columns as they are.
+                const double vc = vbuf[lane], wc = wbuf[lane];
 #pragma unroll
                 for (int jj = 0; jj < 16; jj++) {
-                    const int r = 16 * wave + jj;
-                    const double vr = vj[jj], wr = wj[jj];
-                    const bool rc = r >= c;
-                    const double va = rc ? vr : vc, wa = rc ? wr : wc, vb = rc ? vc : vr, wb = rc ? wc : wr;
-                    const double upd = fma(-wa, vb, fma(-va, wb, Ar[jj]));
-                    Ar[jj] = (r > k && c > k) ? upd : Ar[jj];
+                    const double wr = wbuf[16 * wave + jj];
+                    const double m1 = vj[jj] * wc, m2 = wr * vc;
+                    Ar[jj] = Ar[jj] - (m1 + m2);
                 }
             }
+#ifdef LRF_INIT_STAMPS
+            {
+                asm volatile("" ::"v"(Ar[0]), "v"(Ar[15]));
+                ISTAMP(s4);
+                acc_d += s4 - s3;
+            }
+#endif
         }
     }
+#ifdef LRF_INIT_STAMPS
+    if (tid == 0 && blockIdx.x < 16384) {
+        unsigned long long* o = g_stamps + 8 * blockIdx.x;
+        o[0] = stamp_now() - t_begin; o[1] = acc_a; o[2] = acc_b; o[3] = acc_c; o[4] = acc_d;
+    }
+#endif
     __syncthreads();
     { // d = diag, e[62] = A[63][62]
         const int i = lane;
@@ -437,9 +480,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     __syncthreads();
     if (debug_stop == 2) return;
 
-    // ---- eigenvalues: Gershgorin hull, pivmin (oracle: top_eigenvalues)
+    // ---- eigenvalues: Gershgorin hull, pivmin, the matrix scaled into [-1, 1] (oracle: top_eigenvalues)
     const int rmax = M < 64 ? M : 64;
     const int Rc = R < rmax ? R : rmax;
+    double2* de = reinterpret_cast<double2*>(L.cpart); // (d'_i, e'_{i-1}^2): the matvec partials are dead
     if (wave == 0) {
         const int i = lane;
         double ei = (i < 63) ? L.e[i] : 0.0, eim = (i > 0) ? L.e[i - 1] : 0.0;
@@ -456,23 +500,64 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         double tn = fabs(a) > fabs(b) ? fabs(a) : fabs(b);
         double pivmin = 2.2250738585072014e-300 * (m2 > 1.0 ? m2 : 1.0);
         double slack = 2.0 * tn * 2.220446049250313e-16 * 64 + 2.0 * pivmin;
-        if (i == 0) { L.scal[1] = pivmin; L.scal[2] = a - slack; L.scal[3] = b + slack; }
+        a -= slack;
+        b += slack;
+        const int s = __builtin_amdgcn_frexp_exp(fabs(a) > fabs(b) ? fabs(a) : fabs(b));
+        const double es = ldexp(eim, -s);
+        de[i] = make_double2(ldexp(L.d[i], -s), es * es);
+        if (i == 0) { L.scal[1] = pivmin; L.scal[2] = ldexp(a, -s); L.scal[3] = ldexp(b, -s); L.flag[2] = s; }
     }
     __syncthreads();
     {
-        const double pivmin = L.scal[1];
+        const int sc = L.flag[2];
         for (int r = wave; r < Rc; r += 4) { // one wave per eigenvalue: 64 shifts per pass
             const int kk = 63 - r;
             double a = L.scal[2], b = L.scal[3];
             for (int pass = 0; pass < 10; pass++) {
                 double h = (b - a) / 65.0;
                 double x = a + h * (double)(lane + 1);
-                double q = L.d[0] - x;
-                int cnt = q < 0.0;
-                for (int i = 1; i < 64; i++) {
-                    if (fabs(q) < pivmin) q = -pivmin;
-                    q = (L.d[i] - x) - L.e2[i - 1] / q;
-                    cnt += q < 0.0;
+                // Sturm count, division-free (oracle: sturm_count): one dependent fma per step.  A minor that comes out as
+                // zero needs the oracle's replacement rule: such passes (hardly ever) are redone by the loop below.
+                double p = 1.0, pp = 0.0;
+                bool zero = false;
+                unsigned sgn[2] = {0u, 0u}; // the sign bits of p_1 .. p_64, first at the top: one v_alignbit per step
+#pragma unroll
+                for (int hf = 0; hf < 2; hf++) {
+#pragma unroll 1
+                    for (int g = 4 * hf; g < 4 * hf + 4; g++) { // not unrolled: the table reads would be hoisted out of the pass loop
+#pragma unroll
+                        for (int u = 0; u < 8; u++) {
+                            const double2 q = de[8 * g + u];
+                            const double pn = fma(q.x - x, p, -(q.y * pp));
+                            zero |= (pn == 0.0);
+                            sgn[hf] = __builtin_amdgcn_alignbit(sgn[hf], (unsigned)__double2hiint(pn), 31);
+                            pp = p;
+                            p = pn;
+                        }
+                        const int ea = __builtin_amdgcn_frexp_exp(p), eb = __builtin_amdgcn_frexp_exp(pp);
+                        const int m = ea > eb ? ea : eb;
+                        p = ldexp(p, -m);
+                        pp = ldexp(pp, -m);
+                    }
+                }
+                const unsigned long long sg = ((unsigned long long)sgn[0] << 32) | sgn[1];
+                int cnt = __popcll(sg ^ (sg >> 1)); // sign changes along 1, p_1, ..., p_64
+                if (__any(zero)) { // wave-uniform
+                    p = 1.0, pp = 0.0, cnt = 0;
+                    for (int i = 0; i < 64; i++) {
+                        const double2 q = de[i];
+                        double pn = fma(q.x - x, p, -(q.y * pp));
+                        if (pn == 0.0) pn = (__double2hiint(p) < 0) ? 0x1p-200 : -0x1p-200;
+                        cnt += ((__double2hiint(pn) ^ __double2hiint(p)) < 0);
+                        pp = p;
+                        p = pn;
+                        if ((i & 7) == 7) {
+                            const int ea = __builtin_amdgcn_frexp_exp(p), eb = __builtin_amdgcn_frexp_exp(pp);
+                            const int m = ea > eb ? ea : eb;
+                            p = ldexp(p, -m);
+                            pp = ldexp(pp, -m);
+                        }
+                    }
                 }
                 unsigned long long mask = __ballot(cnt > kk);
                 int j = mask ? (int)__builtin_ctzll(mask) : 64;
@@ -481,56 +566,69 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 a = na;
                 b = nb;
             }
-            if (lane == 0) L.lam[r] = 0.5 * (a + b);
+            if (lane == 0) L.lam[r] = ldexp(0.5 * (a + b), sc);
         }
     }
     __syncthreads();
     if (debug_stop == 3) return;
 
-    // ---- eigenvectors of T by twisted factorisation: thread r (oracle: twisted_vector), scratch [i][r]
-    if (tid < Rc) {
-        const int r = tid;
-        const double lam = L.lam[r], pivmin = L.scal[1];
+    // ---- eigenvectors of T by twisted factorisation (oracle: twisted_vector), scratch [i][r].  The two pivot recurrences of
+    // vector r are independent chains of 63 divisions: thread r runs the forward one, thread 64 + r the backward one; after
+    // the barrier both find the twist index and each fills its side of the vector.
+    {
+        const int r = tid & 63;
+        const bool fwd = tid < 64, mine = tid < 128 && r < Rc;
+        const double lam = mine ? L.lam[r] : 0.0, pivmin = L.scal[1];
         double* Dp = L.D1 + r;
         double* Dm = L.D2 + r;
-        double q = L.d[0] - lam;
-        Dp[0] = q;
-        for (int i = 1; i < 64; i++) {
-            if (fabs(q) < pivmin) q = -pivmin;
-            q = (L.d[i] - lam) - L.e2[i - 1] / q;
-            Dp[i * ZR] = q;
+        if (mine && fwd) {
+            double q = L.d[0] - lam;
+            Dp[0] = q;
+            for (int i = 1; i < 64; i++) {
+                if (fabs(q) < pivmin) q = -pivmin;
+                q = (L.d[i] - lam) - L.e2[i - 1] / q;
+                Dp[i * ZR] = q;
+            }
         }
-        q = L.d[63] - lam;
-        Dm[63 * ZR] = q;
-        for (int i = 62; i >= 0; i--) {
-            if (fabs(q) < pivmin) q = -pivmin;
-            q = (L.d[i] - lam) - L.e2[i] / q;
-            Dm[i * ZR] = q;
+        if (mine && !fwd) {
+            double q = L.d[63] - lam;
+            Dm[63 * ZR] = q;
+            for (int i = 62; i >= 0; i--) {
+                if (fabs(q) < pivmin) q = -pivmin;
+                q = (L.d[i] - lam) - L.e2[i] / q;
+                Dm[i * ZR] = q;
+            }
         }
-        int kt = 0;
-        double best = 0.0;
-        for (int i = 0; i < 64; i++) {
-            double g = fabs((Dp[i * ZR] + Dm[i * ZR]) - (L.d[i] - lam));
-            if (i == 0 || g < best) { best = g; kt = i; }
-        }
-        double* x = L.Z + r * 64;
-        double xv = 1.0;
-        x[kt] = 1.0;
-        for (int i = kt - 1; i >= 0; i--) {
-            double qq = Dp[i * ZR];
-            if (fabs(qq) < pivmin) qq = -pivmin;
-            xv = -(L.e[i] / qq) * xv;
-            x[i] = xv;
-        }
-        xv = 1.0;
-        for (int i = kt; i < 63; i++) {
-            double qq = Dm[(i + 1) * ZR];
-            if (fabs(qq) < pivmin) qq = -pivmin;
-            xv = -(L.e[i] / qq) * xv;
-            x[i + 1] = xv;
+        __syncthreads();
+        if (mine) {
+            int kt = 0;
+            double best = 0.0;
+            for (int i = 0; i < 64; i++) {
+                double g = fabs((Dp[i * ZR] + Dm[i * ZR]) - (L.d[i] - lam));
+                if (i == 0 || g < best) { best = g; kt = i; }
+            }
+            double* x = L.Z + r * 64;
+            double xv = 1.0;
+            if (fwd) {
+                x[kt] = 1.0;
+                for (int i = kt - 1; i >= 0; i--) {
+                    double qq = Dp[i * ZR];
+                    if (fabs(qq) < pivmin) qq = -pivmin;
+                    xv = -(L.e[i] / qq) * xv;
+                    x[i] = xv;
+                }
+            } else {
+                for (int i = kt; i < 63; i++) {
+                    double qq = Dm[(i + 1) * ZR];
+                    if (fabs(qq) < pivmin) qq = -pivmin;
+                    xv = -(L.e[i] / qq) * xv;
+                    x[i + 1] = xv;
+                }
+            }
         }
     }
     __syncthreads();
+    if (debug_stop == 4) return;
 
     // ---- scale, modified Gram-Schmidt, normalise (sequential over r, wave 0, lane = element)
     if (wave == 0) {
@@ -564,6 +662,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }
     }
     __syncthreads();
+    if (debug_stop == 5) return;
 
     // ---- back-transformation x <- H_0 ... H_61 x, sign, scaling, output: one wave per vector
     float* Vp = Vf + (long)blockIdx.x * 64 * rp; // rp: padded rank (row pitch) of the V / W tables, a power of two
@@ -571,17 +670,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     for (int i = tid; i < 64 * rp; i += 256) {
         if ((i & (rp - 1)) >= Rc) { Vp[i] = 0.f; Wp[i] = 0.f; } // padding and the r >= min(M,N) columns
     }
-    for (int r = wave; r < Rc; r += 4) {
+    for (int r0 = wave; r0 < Rc; r0 += 8) { // two vectors per wave and pass (r0 and r0 + 4): their reduction trees interleave
         const int i = lane;
-        double x = L.Z[r * 64 + i];
+        const int r1 = r0 + 4;
+        const bool two = r1 < Rc; // wave-uniform
+        double xa = L.Z[r0 * 64 + i], xb = two ? L.Z[r1 * 64 + i] : 0.0;
         for (int k = 61; k >= 0; k--) {
             double tk = L.tau[k];
             if (tk == 0.0) continue;
             double v = (i > k) ? G[k * 64 + i] : 0.0;
-            double sc = tk * wave_tree64(v * x);
-            x = fma(-sc, v, x);
+            double sa = tk * wave_tree64(v * xa);
+            double sb = tk * wave_tree64(v * xb);
+            xa = fma(-sa, v, xa);
+            xb = fma(-sb, v, xb);
         }
-        L.Z[r * 64 + i] = x;
+        L.Z[r0 * 64 + i] = xa;
+        if (two) L.Z[r1 * 64 + i] = xb;
+      for (int half = 0; half < (two ? 2 : 1); half++) {
+        const int r = half ? r1 : r0;
+        const double x = half ? xb : xa;
         double dot = 0.0;
         for (int j = 0; j < 64; j++) dot = fma((double)(j + 1), L.Z[r * 64 + j], dot); // every lane: same chain
         double lam = L.lam[r];
@@ -593,6 +700,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         double ev = flip * x;
         Vp[i * rp + r] = (float)(ev * sr);
         Wp[i * rp + r] = (sr > 0.0) ? (float)(ev / sr) : 0.f;
+      }
     }
 }
 

@@ -535,7 +535,7 @@ int lrf_oracle_jacobi_f64(double* A, int n, double* E, int max_sweeps)
  * back-transformation.  Every reduction has a fixed shape so that the GPU kernel (one workgroup per
  * matrix) reproduces it bit for bit:
  *   tree64(s)   : for off = 32,16,...,1: s[i] += s[i+off] (i < off); result s[0]   (wave butterfly)
- *   matvec      : four partial k-ordered fma chains over column groups j>>4, combined ((c0+c1)+c2)+c3
+ *   matvec      : eight partial k-ordered fma chains over column groups j>>3, combined pairwise, then in order
  * ---------------------------------------------------------------------------------------------- */
 #define EN 64
 
@@ -566,21 +566,21 @@ static void tridiagonalize(double* A, double* d, double* e, double* Vh, double* 
         double alpha = (x0 >= 0.0) ? -nrm : nrm;
         for (int i = 0; i < EN; i++) v[i] = (i > k + 1) ? A[i * EN + k] : 0.0;
         v[k + 1] = x0 - alpha;
-        for (int i = 0; i < EN; i++) s[i] = v[i] * v[i];
-        double vn = tree64(s);
-        double t = 2.0 / vn;
+        /* |v|^2 = sigma - x0^2 + (x0 - alpha)^2 = 2 (sigma + |x0| nrm): t = 2 / |v|^2 without a second reduction */
+        double t = 1.0 / fma(fabs(x0), nrm, sigma);
         for (int i = 0; i < EN; i++) {
-            double c[4] = {0.0, 0.0, 0.0, 0.0};
+            double c[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
             if (i > k)
-                for (int j = k + 1; j < EN; j++) c[j >> 4] = fma(A[i * EN + j], v[j], c[j >> 4]);
-            p[i] = t * (((c[0] + c[1]) + c[2]) + c[3]);
+                for (int j = k + 1; j < EN; j++) c[j >> 3] = fma(A[i * EN + j], v[j], c[j >> 3]);
+            p[i] = t * ((((c[0] + c[1]) + (c[2] + c[3])) + (c[4] + c[5])) + (c[6] + c[7]));
         }
         for (int i = 0; i < EN; i++) s[i] = p[i] * v[i];
         double K = (0.5 * t) * tree64(s);
         for (int i = 0; i < EN; i++) w[i] = fma(-K, v[i], p[i]);
         for (int i = k + 1; i < EN; i++)
-            for (int j = k + 1; j <= i; j++) { /* canonical (i >= j) formula, mirrored: exactly symmetric */
-                double val = fma(-w[i], v[j], fma(-v[i], w[j], A[i * EN + j]));
+            for (int j = k + 1; j <= i; j++) { /* both products rounded, then added (commutative): exactly symmetric */
+                double m1 = v[i] * w[j], m2 = w[i] * v[j];
+                double val = A[i * EN + j] - (m1 + m2);
                 A[i * EN + j] = val;
                 A[j * EN + i] = val;
             }
@@ -592,24 +592,42 @@ static void tridiagonalize(double* A, double* d, double* e, double* Vh, double* 
     e[EN - 2] = A[(EN - 1) * EN + (EN - 2)];
 }
 
-/* number of eigenvalues of T smaller than x (Sturm count with the usual pivot guard) */
-static int sturm_count(const double* d, const double* e2, double x, double pivmin)
+/* Number of eigenvalues of T' smaller than x: sign changes along the leading principal minors
+ *   p_0 = 1, p_{i+1} = (d'_i - x) p_i - e'_{i-1}^2 p_{i-1}
+ * — the Sturm sequence in its division-free form (the kernel's inner loop is one dependent fma per step instead of an fp64
+ * division).  T' = T / 2^s is scaled so that its Gershgorin hull lies in [-1, 1]; every eighth step the pair (p_i, p_{i-1})
+ * is multiplied by the power of two that brings the larger into [0.5, 1) (exact).  A minor that comes out as zero takes a
+ * tiny value of the sign opposite to its predecessor's, which also restarts the sequence correctly behind e' = 0. */
+static int sturm_count(const double* ds, const double* e2s, double x)
 {
-    double q = d[0] - x;
-    int cnt = q < 0.0;
-    for (int i = 1; i < EN; i++) {
-        if (fabs(q) < pivmin) q = -pivmin;
-        q = (d[i] - x) - e2[i - 1] / q;
-        cnt += q < 0.0;
+    double p = 1.0, pp = 0.0;
+    int cnt = 0;
+    for (int i = 0; i < EN; i++) {
+        double dx = ds[i] - x;
+        double t = (i ? e2s[i - 1] : 0.0) * pp;
+        double pn = fma(dx, p, -t);
+        if (pn == 0.0) pn = signbit(p) ? 0x1p-200 : -0x1p-200;
+        cnt += (signbit(pn) != 0) != (signbit(p) != 0);
+        pp = p;
+        p = pn;
+        if ((i & 7) == 7) {
+            int ea, eb;
+            frexp(p, &ea);
+            frexp(pp, &eb);
+            int m = ea > eb ? ea : eb;
+            p = ldexp(p, -m);
+            pp = ldexp(pp, -m);
+        }
     }
     return cnt;
 }
 
-/* the R largest eigenvalues of T, descending: 10 passes of 64-way multisection from the Gershgorin hull */
+/* the R largest eigenvalues of T, descending: 10 passes of 64-way multisection from the Gershgorin hull, on the scaled
+ * matrix; pivmin is the pivot guard of the twisted factorisation */
 static void top_eigenvalues(const double* d, const double* e, int R, double* lam, double* pivmin_out)
 {
-    double e2[EN], lo = 0, hi = 0, e2max = 0.0;
-    for (int i = 0; i < EN - 1; i++) { e2[i] = e[i] * e[i]; if (e2[i] > e2max) e2max = e2[i]; }
+    double ds[EN], e2s[EN], lo = 0, hi = 0, e2max = 0.0;
+    for (int i = 0; i < EN - 1; i++) { double e2 = e[i] * e[i]; if (e2 > e2max) e2max = e2; }
     for (int i = 0; i < EN; i++) {
         double rad = (i > 0 ? fabs(e[i - 1]) : 0.0) + (i < EN - 1 ? fabs(e[i]) : 0.0);
         double a = d[i] - rad, b = d[i] + rad;
@@ -621,6 +639,12 @@ static void top_eigenvalues(const double* d, const double* e, int R, double* lam
     double slack = 2.0 * tn * 2.220446049250313e-16 * EN + 2.0 * pivmin;
     lo -= slack;
     hi += slack;
+    int s;
+    frexp(fabs(lo) > fabs(hi) ? fabs(lo) : fabs(hi), &s); /* hull within [-2^s, 2^s] */
+    for (int i = 0; i < EN; i++) ds[i] = ldexp(d[i], -s);
+    for (int i = 0; i < EN - 1; i++) { double es = ldexp(e[i], -s); e2s[i] = es * es; }
+    lo = ldexp(lo, -s);
+    hi = ldexp(hi, -s);
     for (int r = 0; r < R; r++) {
         int k = EN - 1 - r; /* eigenvalue with exactly k eigenvalues below it */
         double a = lo, b = hi;
@@ -630,13 +654,13 @@ static void top_eigenvalues(const double* d, const double* e, int R, double* lam
             double xs[EN];
             for (int i = 0; i < EN; i++) {
                 xs[i] = a + h * (double)(i + 1);
-                if (j == EN && sturm_count(d, e2, xs[i], pivmin) > k) j = i;
+                if (j == EN && sturm_count(ds, e2s, xs[i]) > k) j = i;
             }
             double na = (j == 0) ? a : xs[j - 1], nb = (j == EN) ? b : xs[j];
             a = na;
             b = nb;
         }
-        lam[r] = 0.5 * (a + b);
+        lam[r] = ldexp(0.5 * (a + b), s);
     }
     *pivmin_out = pivmin;
 }
