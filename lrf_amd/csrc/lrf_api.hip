@@ -870,8 +870,13 @@ int lrf_qmf_decode_rgb_u8(lrf_ctx* c, const int8_t* U, const int8_t* V, int64_t 
     Prof p(c, LRF_K_DECODE);
     static const bool no_tiled = getenv("LRF_DECODE_NO_TILED") && getenv("LRF_DECODE_NO_TILED")[0] == '1'; // developer comparison aid
     if (R[0] <= 8 && R[1] <= 8 && R[2] <= 8 && H % 16 == 0 && W % 16 == 0 && (reinterpret_cast<uintptr_t>(rgb) & 7) == 0 && !no_tiled)
-        hipLaunchKernelGGL(k_decode16, dim3((unsigned)((H / 16) * ((g.p[0].nw + 31) / 32)), (unsigned)B), dim3(256), 0, c->stream, U, V,
-                           (int)H, (int)W, g, R[0], R[1], R[2], u_img, v_img, rgb);
+    {
+        const dim3 grid((unsigned)((H / 16) * ((g.p[0].nw + 31) / 32)), (unsigned)B);
+        if (R[1] <= 4 && R[2] <= 4)
+            hipLaunchKernelGGL(k_decode16<4>, grid, dim3(256), 0, c->stream, U, V, (int)H, (int)W, g, R[0], R[1], R[2], u_img, v_img, rgb);
+        else
+            hipLaunchKernelGGL(k_decode16<8>, grid, dim3(256), 0, c->stream, U, V, (int)H, (int)W, g, R[0], R[1], R[2], u_img, v_img, rgb);
+    }
     else if (R[0] <= 8 && R[1] <= 8 && R[2] <= 8)
         hipLaunchKernelGGL(k_decode8, dim3((unsigned)((n4 + 255) / 256), (unsigned)B), dim3(256), 0, c->stream, U, V, (int)H, (int)W,
                            g, R[0], R[1], R[2], u_img, v_img, rgb);

@@ -1478,9 +1478,44 @@ __global__ __launch_bounds__(256) void k_decode8(const int8_t* __restrict__ U, c
 // up-sampling): the inverse of k_planes16's tiling.  One workgroup per 16-row strip x 32 luma patches; a thread owns a
 // 2 x 8 pixel block — two rows of one luma patch, and the four chroma samples under them, one row of one chroma patch —
 // so it loads its three u rows once (two unaligned dwords each), reads V from an LDS table laid out [plane][r][n] (a
-// ds_read_b128 per (r, row) — the lanes of a wave share two patch rows, so the reads are broadcasts) and writes six
-// 8-byte pieces; the 32 lanes of a row pair cover 256 contiguous bytes per store instruction.  Same arithmetic and
-// order as k_decode8 / k_decode (k-ordered fma chain over r from 0; "+ 0.f" / "+ -128.f"; the colour chain; clamp; truncate).
+// ds_read_b128 per (r, row)) and writes six 8-byte pieces; the 32 lanes of a row pair cover 256 contiguous bytes per store
+// instruction.  44-49 registers, eight waves per SIMD.  The kernel is bound by its vector instructions (counters, 256 x
+// 512x768: VALU busy 73 % of the 0.106 ms, 490 instructions per 16 pixels before the trimming below, 380 after; LDS 27 %);
+// tried and not kept: two patches or eight strips per thread to reuse the V values (the compiler holds them in 160
+// registers, two waves per SIMD: 1.4-2x slower), v_pk_fma_f32 for the sums (counted and paced as two instructions: no
+// gain), 64 lanes per image row (512-byte store segments, but a quarter of the lanes idle at 96 patches per row: slower).
+// Arithmetic: that of k_decode8 / k_decode (sums of products of small integers: exact in any order; "+ -128.f"; the colour
+// chain; clamp; truncate) with the steps dropped that cannot change a bit for finite values: fma(1, y, 0) = y,
+// fma(0, c, acc) = acc.  The chroma sums stop at rank 4 when both chroma ranks are <= 4 (wave-uniform).
+__device__ __forceinline__ void decode16_u_load(const int8_t* up, int R, unsigned& lo, unsigned& hi)
+{
+    hi = 0u;
+    if (R >= 4) { // bytes 0..3 and bytes R-4..R-1 of the row (overlapping): two unaligned dword loads
+        lo = *reinterpret_cast<const unsigned __attribute__((aligned(1)))*>(up);
+        const unsigned h = *reinterpret_cast<const unsigned __attribute__((aligned(1)))*>(up + R - 4);
+        hi = (R > 4) ? h >> (8 * (8 - R)) : 0u;
+    } else {
+        lo = (unsigned)(uint8_t)up[0] | ((unsigned)(uint8_t)up[R > 1 ? 1 : 0] << 8) | ((unsigned)(uint8_t)up[R > 2 ? 2 : 0] << 16);
+    }
+}
+__device__ __forceinline__ void decode16_u_unpack(unsigned lo, unsigned hi, int R, float (&u)[8])
+{
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        u[r] = (r < R) ? (float)(int)(int8_t)(lo >> (8 * r)) : 0.f;
+        u[4 + r] = (4 + r < R) ? (float)(int)(int8_t)(hi >> (8 * r)) : 0.f;
+    }
+}
+
+// clamp to [0, 255] and truncate four values, packed into one dword (values are finite)
+__device__ __forceinline__ unsigned decode16_pack4(float a, float b, float c, float d)
+{
+    const unsigned ua = (unsigned)__builtin_amdgcn_fmed3f(a, 0.f, 255.f), ub = (unsigned)__builtin_amdgcn_fmed3f(b, 0.f, 255.f);
+    const unsigned uc = (unsigned)__builtin_amdgcn_fmed3f(c, 0.f, 255.f), ud = (unsigned)__builtin_amdgcn_fmed3f(d, 0.f, 255.f);
+    return (ua | (ub << 8)) | ((uc | (ud << 8)) << 16);
+}
+
+template <int RC> // chroma rank bound: 4 or 8
 __global__ __launch_bounds__(256) void k_decode16(const int8_t* __restrict__ U, const int8_t* __restrict__ V, int H, int W,
                                                   ImageGeom g, int R0, int R1, int R2, long u_img, long v_img,
                                                   uint8_t* __restrict__ rgb)
@@ -1491,42 +1526,31 @@ __global__ __launch_bounds__(256) void k_decode16(const int8_t* __restrict__ U, 
     const int8_t* Uc[3] = {Ui, Ui + (long)g.p[0].M * R0, Ui + (long)g.p[0].M * R0 + (long)g.p[1].M * R1};
     const int8_t* Vc[3] = {Vi, Vi + 64 * R0, Vi + 64 * R0 + 64 * R1};
     const int Rc[3] = {R0, R1, R2};
+    const int nwl = g.p[0].nw, nwc = g.p[1].nw;
+    const int per_strip = (nwl + 31) / 32;
+    const int strip = blockIdx.x / per_strip;
+    const int ww = (blockIdx.x - strip * per_strip) * 32 + (threadIdx.x & 31);
+    const int wwc = ww < nwl ? ww : nwl - 1; // threads past the last patch load what the last one loads and store nothing
+    const int rp = threadIdx.x >> 5; // row pair inside the strip: image rows 16 strip + 2 rp, + 1
+    // the u rows of the luma patch and of the two chroma patches: issued before the V table is staged, so that the two
+    // memory round trips of a workgroup overlap
+    unsigned ulo[3], uhi[3];
+    const long mrow[3] = {(long)(2 * strip + (rp >> 2)) * nwl + wwc, (long)strip * nwc + (wwc >> 1), (long)strip * nwc + (wwc >> 1)};
+#pragma unroll
+    for (int c = 0; c < 3; c++) decode16_u_load(Uc[c] + mrow[c] * Rc[c], Rc[c], ulo[c], uhi[c]);
     for (int e = threadIdx.x; e < 3 * 8 * 64; e += 256) {
         const int c = e >> 9, r = (e >> 6) & 7, n = e & 63;
         Vs[c][r][n] = (r < Rc[c]) ? (float)Vc[c][n * Rc[c] + r] : 0.f;
     }
     __syncthreads();
-    const int nwl = g.p[0].nw, nwc = g.p[1].nw;
-    const int per_strip = (nwl + 31) / 32;
-    const int strip = blockIdx.x / per_strip;
-    const int ww = (blockIdx.x - strip * per_strip) * 32 + (threadIdx.x & 31);
-    const int rp = threadIdx.x >> 5; // row pair inside the strip: image rows 16 strip + 2 rp, + 1
     if (ww >= nwl) return;
-    // the u rows of the luma patch and of the two chroma patches (zero padded to 8 columns)
-    float u[3][8];
-    const long mrow[3] = {(long)(2 * strip + (rp >> 2)) * nwl + ww, (long)strip * nwc + (ww >> 1), (long)strip * nwc + (ww >> 1)};
+    float u[3][8]; // zero padded to 8 columns
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-        const int R = Rc[c];
-        const int8_t* up = Uc[c] + mrow[c] * R;
-        unsigned lo, hi = 0u;
-        if (R >= 4) { // bytes 0..3 and bytes R-4..R-1 of the row (overlapping): two unaligned dword loads
-            lo = *reinterpret_cast<const unsigned __attribute__((aligned(1)))*>(up);
-            const unsigned h = *reinterpret_cast<const unsigned __attribute__((aligned(1)))*>(up + R - 4);
-            hi = (R > 4) ? h >> (8 * (8 - R)) : 0u;
-        } else {
-            lo = (unsigned)(uint8_t)up[0] | ((unsigned)(uint8_t)up[R > 1 ? 1 : 0] << 8) | ((unsigned)(uint8_t)up[R > 2 ? 2 : 0] << 16);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            u[c][r] = (r < R) ? (float)(int)(int8_t)(lo >> (8 * r)) : 0.f;
-            u[c][4 + r] = (4 + r < R) ? (float)(int)(int8_t)(hi >> (8 * r)) : 0.f;
-        }
-    }
+    for (int c = 0; c < 3; c++) decode16_u_unpack(ulo[c], uhi[c], Rc[c], u[c]);
     // chroma: samples (row 8 strip + rp of the plane = row rp of the patch, columns 4 (ww & 1) .. + 3)
     float cb[4] = {0.f, 0.f, 0.f, 0.f}, cr[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
+    for (int r = 0; r < RC; r++) {
         const f32x4 vb = *reinterpret_cast<const f32x4*>(&Vs[1][r][rp * 8 + 4 * (ww & 1)]);
         const f32x4 vr = *reinterpret_cast<const f32x4*>(&Vs[2][r][rp * 8 + 4 * (ww & 1)]);
 #pragma unroll
@@ -1540,9 +1564,8 @@ __global__ __launch_bounds__(256) void k_decode16(const int8_t* __restrict__ U, 
         cb[i] = cb[i] + -128.f;
         cr[i] = cr[i] + -128.f;
     }
-    const float T[3][3] = {{1.0f, 0.0f, 1.402f}, {1.0f, -0.344136f, -0.714136f}, {1.0f, 1.772f, 0.0f}};
-    uint8_t* out = rgb + (long)blockIdx.y * 3 * H * W + (long)(16 * strip + 2 * rp) * W + 8 * ww;
     const long hw = (long)H * W;
+    uint8_t* out = rgb + (long)blockIdx.y * 3 * hw + (long)(16 * strip + 2 * rp) * W + 8 * ww;
 #pragma unroll
     for (int rr = 0; rr < 2; rr++) {
         float y[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1557,22 +1580,25 @@ __global__ __launch_bounds__(256) void k_decode16(const int8_t* __restrict__ U, 
                 y[4 + i] = fmaf(u[0][r], v1[i], y[4 + i]);
             }
         }
-        unsigned long long packed[3] = {0ull, 0ull, 0ull};
+        uint2 pk[3];
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const float c0 = y[i] + 0.f, c1 = cb[i >> 1], c2 = cr[i >> 1];
+        for (int h = 0; h < 2; h++) {
+            float ch[3][4];
 #pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                float acc = 0.f;
-                acc = fmaf(T[ch][0], c0, acc);
-                acc = fmaf(T[ch][1], c1, acc);
-                acc = fmaf(T[ch][2], c2, acc);
-                acc = fminf(fmaxf(acc, 0.f), 255.f);
-                packed[ch] |= (unsigned long long)(uint8_t)acc << (8 * i); // truncation (to_dtype)
+            for (int i = 0; i < 4; i++) { // the k-ordered chains without their no-op steps
+                const float c0 = y[4 * h + i], c1 = cb[2 * h + (i >> 1)], c2 = cr[2 * h + (i >> 1)];
+                ch[0][i] = fmaf(1.402f, c2, c0);
+                ch[1][i] = fmaf(-0.714136f, c2, fmaf(-0.344136f, c1, c0));
+                ch[2][i] = fmaf(1.772f, c1, c0);
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const unsigned w = decode16_pack4(ch[k][0], ch[k][1], ch[k][2], ch[k][3]);
+                if (h == 0) pk[k].x = w; else pk[k].y = w;
             }
         }
 #pragma unroll
-        for (int ch = 0; ch < 3; ch++) *reinterpret_cast<unsigned long long*>(out + ch * hw + (long)rr * W) = packed[ch];
+        for (int k = 0; k < 3; k++) *reinterpret_cast<uint2*>(out + k * hw + (long)rr * W) = pk[k];
     }
 }
 
