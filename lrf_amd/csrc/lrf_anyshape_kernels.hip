@@ -715,33 +715,87 @@ __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, 
             const double tn = fabs(lo) > fabs(hi) ? fabs(lo) : fabs(hi);
             const double pivmin = 2.2250738585072014e-300 * (e2m > 1.0 ? e2m : 1.0);
             const double slack = 2.0 * tn * 2.220446049250313e-16 * n + 2.0 * pivmin;
-            Lscal[1] = pivmin; Lscal[2] = lo - slack; Lscal[3] = hi + slack;
+            const double lo2 = lo - slack, hi2 = hi + slack;
+            const int sc = __builtin_amdgcn_frexp_exp(fabs(lo2) > fabs(hi2) ? fabs(lo2) : fabs(hi2)); // hull within [-2^sc, 2^sc]
+            Lscal[1] = pivmin; Lscal[2] = ldexp(lo2, -sc); Lscal[3] = ldexp(hi2, -sc); Lscal[4] = (double)sc;
         }
         __syncthreads();
     }
     const double pivmin = Lscal[1];
-    // ---- eigenvalues: one wave per eigenvalue, 64 shifts per pass, 10 passes (interval / 65^10)
-    for (int r = wave; r < Rc; r += 4) {
-        const int kk = n - 1 - r;
-        double a = Lscal[2], b = Lscal[3];
-        for (int pass = 0; pass < 10; pass++) {
-            const double h = (b - a) / 65.0;
-            const double x = a + h * (double)(lane + 1);
-            double q = Ld[0] - x;
-            int cnt = q < 0.0;
-            for (int j = 1; j < n; j++) {
-                if (fabs(q) < pivmin) q = -pivmin;
-                q = (Ld[j] - x) - Le2[j - 1] / q;
-                cnt += q < 0.0;
-            }
-            const unsigned long long mask = __ballot(cnt > kk);
-            const int jj = mask ? (int)__builtin_ctzll(mask) : 64;
-            const double xm = __shfl(x, jj > 0 ? jj - 1 : 0, 64), xj = __shfl(x, jj < 64 ? jj : 63, 64);
-            const double na = (jj == 0) ? a : xm, nb = (jj == 64) ? b : xj;
-            a = na;
-            b = nb;
+    // ---- eigenvalues: one wave per eigenvalue, 64 shifts per pass, 10 passes (interval / 65^10).  Sturm counts in the
+    // division-free form of k_init (lrf_kernels.hip; oracle: sturm_count): the leading principal minors of T / 2^sc - x,
+    // one dependent fma per step, the pair rescaled by a power of two every eighth step, the sign changes counted from the
+    // collected sign bits; a pass in which a minor came out as zero is redone with the replacement rule.
+    double2* de = reinterpret_cast<double2*>(Lv); // (d'_j, e'_{j-1}^2): Lv and Lw are free between the stages
+    {
+        const int sc = (int)Lscal[4];
+        for (int j = tid; j < n; j += 256) {
+            const double es = (j > 0) ? ldexp(Le[j - 1], -sc) : 0.0;
+            de[j] = make_double2(ldexp(Ld[j], -sc), es * es);
         }
-        if (lane == 0) Llam[r] = 0.5 * (a + b);
+        __syncthreads();
+        const int n8 = n & ~7;
+        for (int r = wave; r < Rc; r += 4) {
+            const int kk = n - 1 - r;
+            double a = Lscal[2], b = Lscal[3];
+            for (int pass = 0; pass < 10; pass++) {
+                const double h = (b - a) / 65.0;
+                const double x = a + h * (double)(lane + 1);
+                double p = 1.0, pp = 0.0;
+                unsigned sg = 0u;
+                int cnt = 0;
+                bool zero = false;
+#pragma unroll 1
+                for (int j0 = 0; j0 < n8; j0 += 8) { // not unrolled further: the table reads must stay inside the pass loop
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const double2 q = de[j0 + u];
+                        const double pn = fma(q.x - x, p, -(q.y * pp));
+                        zero |= (pn == 0.0);
+                        sg = __builtin_amdgcn_alignbit(sg, (unsigned)__double2hiint(pn), 31);
+                        pp = p;
+                        p = pn;
+                    }
+                    cnt += __popc((sg ^ (sg >> 1)) & 0xffu);
+                    const int ea = __builtin_amdgcn_frexp_exp(p), eb = __builtin_amdgcn_frexp_exp(pp);
+                    const int m = ea > eb ? ea : eb;
+                    p = ldexp(p, -m);
+                    pp = ldexp(pp, -m);
+                }
+                for (int j = n8; j < n; j++) {
+                    const double2 q = de[j];
+                    const double pn = fma(q.x - x, p, -(q.y * pp));
+                    zero |= (pn == 0.0);
+                    cnt += ((__double2hiint(pn) ^ __double2hiint(p)) < 0);
+                    pp = p;
+                    p = pn;
+                }
+                if (__any(zero)) { // wave-uniform
+                    p = 1.0, pp = 0.0, cnt = 0;
+                    for (int j = 0; j < n; j++) {
+                        const double2 q = de[j];
+                        double pn = fma(q.x - x, p, -(q.y * pp));
+                        if (pn == 0.0) pn = (__double2hiint(p) < 0) ? 0x1p-200 : -0x1p-200;
+                        cnt += ((__double2hiint(pn) ^ __double2hiint(p)) < 0);
+                        pp = p;
+                        p = pn;
+                        if ((j & 7) == 7) {
+                            const int ea = __builtin_amdgcn_frexp_exp(p), eb = __builtin_amdgcn_frexp_exp(pp);
+                            const int m = ea > eb ? ea : eb;
+                            p = ldexp(p, -m);
+                            pp = ldexp(pp, -m);
+                        }
+                    }
+                }
+                const unsigned long long mask = __ballot(cnt > kk);
+                const int jj = mask ? (int)__builtin_ctzll(mask) : 64;
+                const double xm = __shfl(x, jj > 0 ? jj - 1 : 0, 64), xj = __shfl(x, jj < 64 ? jj : 63, 64);
+                const double na = (jj == 0) ? a : xm, nb = (jj == 64) ? b : xj;
+                a = na;
+                b = nb;
+            }
+            if (lane == 0) Llam[r] = ldexp(0.5 * (a + b), sc);
+        }
     }
     __syncthreads();
     if (stop_after == 2) return;
