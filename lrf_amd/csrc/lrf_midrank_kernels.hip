@@ -397,32 +397,46 @@ __global__ __launch_bounds__(256) void k_vupdate_mid(const PlaneDesc* __restrict
     const PlaneDesc pd = planes[blockIdx.x];
     const int R = pd.R, tid = threadIdx.x;
     // a' = ((P0 + P1) + P2) + ... per element, b' likewise (block order); only the first 32 columns exist at these ranks
-    for (int i2 = tid; i2 < 64 * 32; i2 += 256) {
-        const int i = (i2 >> 5) * LRF_RPB + (i2 & 31);
-        const float* Pp = Ppart + (long)pd.blk0 * 64 * LRF_RPB + i;
-        const float* Qp = Qpart + (long)pd.blk0 * LRF_RPB * LRF_RPB + i;
-        const bool needq = (i2 >> 5) < 32; // b' is [R][R]
-        float acc = 0.f, q = 0.f;
-        for (int b0 = 0; b0 < pd.nblk; b0 += 8) {
-            float v[8], w[8];
+    // The eight elements of a thread advance together, eight blocks per round: 128 loads in flight per thread instead of 16
+    // (the kernel is a chain of memory round trips: 27 -> 21 us per launch at 192 matrices); per element the order stays b = 0, 1, ...
+    {
+        constexpr int NE = 64 * 32 / 256, NB = 8;
+        float acc[NE], q[NE];
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                v[k] = (b0 + k < pd.nblk) ? Pp[(long)(b0 + k) * 64 * LRF_RPB] : 0.f;
-                w[k] = (needq && b0 + k < pd.nblk) ? Qp[(long)(b0 + k) * LRF_RPB * LRF_RPB] : 0.f;
+        for (int m = 0; m < NE; m++) acc[m] = q[m] = 0.f;
+        const float* P0 = Ppart + (long)pd.blk0 * 64 * LRF_RPB;
+        const float* Q0 = Qpart + (long)pd.blk0 * LRF_RPB * LRF_RPB;
+        for (int b0 = 0; b0 < pd.nblk; b0 += NB) {
+            float v[NE][NB], w[NE][NB];
+#pragma unroll
+            for (int m = 0; m < NE; m++) {
+                const int i2 = tid + 256 * m, i = (i2 >> 5) * LRF_RPB + (i2 & 31);
+                const bool needq = (i2 >> 5) < 32; // b' is [R][R]
+#pragma unroll
+                for (int k = 0; k < NB; k++) {
+                    v[m][k] = (b0 + k < pd.nblk) ? P0[(long)(b0 + k) * 64 * LRF_RPB + i] : 0.f;
+                    w[m][k] = (needq && b0 + k < pd.nblk) ? Q0[(long)(b0 + k) * LRF_RPB * LRF_RPB + i] : 0.f;
+                }
             }
 #pragma unroll
-            for (int k = 0; k < 8; k++)
-                if (b0 + k < pd.nblk) {
-                    acc = (b0 + k == 0) ? v[k] : acc + v[k];
-                    q = (b0 + k == 0) ? w[k] : q + w[k];
-                }
+            for (int m = 0; m < NE; m++)
+#pragma unroll
+                for (int k = 0; k < NB; k++)
+                    if (b0 + k < pd.nblk) {
+                        acc[m] = (b0 + k == 0) ? v[m][k] : acc[m] + v[m][k];
+                        q[m] = (b0 + k == 0) ? w[m][k] : q[m] + w[m][k];
+                    }
         }
-        L.a_s[i] = acc;
-        L.v_s[i] = Vf[(long)blockIdx.x * 64 * LRF_RPB + i];
-        const int j = i2 >> 5, r = i2 & 31; // b' = U^T U entry (j, r)
-        if (j < R && r < R) {
-            if (j == r) L.gt_s[r * LRF_GTB_LD + LRF_GTB_DEN] = (q + 0.f) + LRF_EPS;
-            else L.gt_s[r * LRF_GTB_LD + (j < r ? j : j - 1)] = q;
+#pragma unroll
+        for (int m = 0; m < NE; m++) {
+            const int i2 = tid + 256 * m, i = (i2 >> 5) * LRF_RPB + (i2 & 31);
+            L.a_s[i] = acc[m];
+            L.v_s[i] = Vf[(long)blockIdx.x * 64 * LRF_RPB + i];
+            const int j = i2 >> 5, r = i2 & 31; // b' = U^T U entry (j, r)
+            if (j < R && r < R) {
+                if (j == r) L.gt_s[r * LRF_GTB_LD + LRF_GTB_DEN] = (q[m] + 0.f) + LRF_EPS;
+                else L.gt_s[r * LRF_GTB_LD + (j < r ? j : j - 1)] = q[m];
+            }
         }
     }
     __syncthreads();
