@@ -1141,6 +1141,15 @@ int lrf_debug_read_stamps(lrf_ctx* c, unsigned long long* out_host, int n)
 }
 #endif
 
+#ifdef LRF_GRAM_STAMPS
+int lrf_debug_read_gram_stamps(lrf_ctx* c, unsigned long long* out_host, int n)
+{
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_gram_stamps), sizeof(unsigned long long) * (size_t)n));
+    return LRF_OK;
+}
+#endif
+
 /* ---- SVD baseline (lrf.svd_encode / svd_decode, default RGB branch) ---- */
 static int svd_geom(int64_t H, int64_t W, int* hp, int* wp, int* top, int* left, int* nw, int* M)
 {

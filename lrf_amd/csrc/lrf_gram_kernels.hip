@@ -129,7 +129,7 @@ __device__ __forceinline__ void add_shifted_i128(unsigned long long& lo, long lo
 }
 
 // The five digits of four values (one packed dword per digit) for the matrices qmf_encode forms: every element is 0 or in
-// [2^-4, 2^8) and non-negative, so on the grid 2^-27 (E = 8) n = mantissa << (exponent - 123) exactly, no rounding, no sign.
+// [2^-4, 2^8) and non-negative, so on the grid 2^-27 (E = 8) n = x 2^27 is an integer below 2^35, no rounding, no sign.
 // Here the digits are BALANCED base-256 ones, d_k in [-128, 127]: n + 0x80808080 has the bytes d_k + 128, i.e. the bytes
 // of (n + 0x80808080) ^ 0x80808080 read as int8 ARE the four low digits, and the fifth is the carry-adjusted top word
 // (0..8) — no shifts or masks per digit, a 4 x 4 byte transpose (eight v_perm_b32) packs four values, and the weights become
@@ -139,11 +139,14 @@ __device__ __forceinline__ void gram_digits4_planes(const float (&x)[4], unsigne
     unsigned xb[4], d4[4];
 #pragma unroll
     for (int b = 0; b < 4; b++) {
-        const unsigned u = __float_as_uint(x[b]), e = u >> 23;
-        const unsigned long long m = e ? (unsigned long long)((u & 0x7fffffu) | 0x800000u) : 0ull;
-        const unsigned long long n = (m << ((e - 123u) & 15u)) + 0x80808080ull;
-        xb[b] = (unsigned)n ^ 0x80808080u;
-        d4[b] = (unsigned)(n >> 32);
+        // n = x 2^27 < 2^35 split without 64-bit shifts: the top word is trunc(x / 32) (0..7), the remainder x - 32 top < 32
+        // is exact in fp32 and so is its product with 2^27, an integer below 2^32
+        const float top = truncf(x[b] * 0x1p-5f);
+        const float rem = fmaf(-32.f, top, x[b]);
+        const unsigned lo = (unsigned)(rem * 0x1p27f), hi = (unsigned)top;
+        const unsigned lob = lo + 0x80808080u;
+        xb[b] = lob ^ 0x80808080u;
+        d4[b] = hi + (lob < lo ? 1u : 0u);
     }
     // v_perm_b32(s0, s1, sel): byte selectors 0-3 pick from s1, 4-7 from s0
     const unsigned t0 = __builtin_amdgcn_perm(xb[1], xb[0], 0x05010400u); // x0.b0 x1.b0 x0.b1 x1.b1
@@ -156,6 +159,21 @@ __device__ __forceinline__ void gram_digits4_planes(const float (&x)[4], unsigne
     pk[3] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
     pk[4] = d4[0] | (d4[1] << 8) | (d4[2] << 16) | (d4[3] << 24);
 }
+
+#ifdef LRF_GRAM_STAMPS // diagnostic build only (tools/dev_stamps_gram.py)
+__device__ unsigned long long g_gram_stamps[8 * 16384];
+__device__ __forceinline__ unsigned long long gram_stamp()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define GSTAMP(v) const unsigned long long v = gram_stamp()
+#else
+#define GSTAMP(v)
+#endif
 
 // PLANES: the matrices come from k_planes / k_planes16 (fixed_exp = 8, exact integer digit extraction)
 template <bool PLANES>
@@ -188,7 +206,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const float* bp = Xp + (long)(blk * 64 + 16 * kq) * 64; // one address per lane, the sixteen rows at immediate offsets
         if (blk * 64 + 64 <= nrows) {                            // wave-uniform
 #pragma unroll
+#ifndef LRF_GRAM_NO_LOADS
             for (int j = 0; j < 16; j++) vals[j] = bp[j * 64];
+#else
+            for (int j = 0; j < 16; j++) vals[j] = 1.5f * (float)(lane + j + blk); // ablation builds only (tools/dev_lib_kernels.py)
+#endif
         } else { // the last block of a matrix: rows past its end count as zeros
 #pragma unroll
             for (int j = 0; j < 16; j++) {
@@ -199,7 +221,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }
     };
     load_block(0);
+#ifdef LRF_GRAM_STAMPS
+    unsigned long long ga = 0, gb = 0, gc = 0, gd = 0;
+    const unsigned long long g_begin = gram_stamp();
+#endif
     for (int blk = 0; blk < nblk; blk++) {
+        GSTAMP(g0);
+#ifdef LRF_GRAM_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        GSTAMP(g1);
         unsigned pk[5][4];
 #pragma unroll
         for (int a = 0; a < 5; a++)
@@ -224,14 +255,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             }
         }
         __builtin_amdgcn_sched_barrier(0); // keep the phases apart: interleaved they overflow the register file
+        GSTAMP(g2);
         if (blk + 1 < nblk) load_block(blk + 1); // wave-uniform; lands under the MFMAs below
         uint4* lb = lds[blk & 1];
 #pragma unroll
         for (int a = 0; a < 5; a++) lb[(wave * 5 + a) * 64 + lane] = make_uint4(pk[a][0], pk[a][1], pk[a][2], pk[a][3]);
         __syncthreads(); // one barrier per block: the other buffer is not written before every wave has passed this point again
         __builtin_amdgcn_sched_barrier(0);
+        GSTAMP(g3);
+#ifndef LRF_GRAM_NO_MFMA
         gram_accumulate(lb, lane, pti, ptj, acc, wave < 2 ? 3 : 2);
+#else
+        acc[0][0][0] += (int)lb[lane].x; // ablation builds only
+#endif
+#ifdef LRF_GRAM_STAMPS
+        asm volatile("" ::"v"(acc[0][0]), "v"(acc[1][8]));
+        {
+            GSTAMP(g4);
+            ga += g1 - g0; gb += g2 - g1; gc += g3 - g2; gd += g4 - g3;
+        }
+#endif
     }
+#ifdef LRF_GRAM_STAMPS
+    if (lane == 0 && blockIdx.x < 4096) {
+        unsigned long long* o = g_gram_stamps + 8 * (4 * blockIdx.x + wave);
+        o[0] = gram_stamp() - g_begin; o[1] = ga; o[2] = gb; o[3] = gc; o[4] = gd;
+    }
+#endif
     // fold the nine weights into one 128-bit integer per element and write the chunk's partial: [pair][reg][lane]
     const int npairs = wave < 2 ? 3 : 2;
     const int pair0 = wave == 0 ? 0 : wave == 1 ? 3 : wave == 2 ? 6 : 8;
