@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 }
                 const unsigned long long sg = ((unsigned long long)sgn[0] << 32) | sgn[1];
                 int cnt = __popcll(sg ^ (sg >> 1)); // sign changes along 1, p_1, ..., p_64
-                if (__any(zero)) { // wave-uniform
+                if (__any(zero) || debug_stop == 100) { // wave-uniform (100: the tests force this path, LRF_DEBUG_INIT_SWEEPS)
                     p = 1.0, pp = 0.0, cnt = 0;
                     for (int i = 0; i < 64; i++) {
                         const double2 q = de[i];

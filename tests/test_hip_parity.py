@@ -108,6 +108,34 @@ def test_svd_init_matches_oracle(ctx, oracle):
         assert np.abs(ov * s - rv).max() <= 2e-4 * np.abs(rv).max()
 
 
+def test_sturm_replacement_path_equals_fast_path(ctx, oracle):
+    """k_init counts sign changes along the leading minors with a fast loop and redoes a pass with the oracle's replacement
+    rule when a minor came out as exactly zero — which regular data never produces.  LRF_DEBUG_INIT_SWEEPS=100 (read when a
+    context is created) sends every pass through that second loop: same bits as the fast loop and as the oracle."""
+    import os
+    from lrf_amd import _lib
+    rng = np.random.default_rng(11)
+    mats = [rng.random((700, 64)).astype(np.float32) * 255, np.outer(rng.random(300), rng.random(64)).astype(np.float32) * 200,
+            np.full((128, 64), 3.0, np.float32), np.zeros((64, 64), np.float32)]
+    os.environ["LRF_DEBUG_INIT_SWEEPS"] = "100"
+    try:
+        slow = _lib.Context(ctx.device)
+    finally:
+        del os.environ["LRF_DEBUG_INIT_SWEEPS"]
+    try:
+        for X in mats:
+            xd = torch.from_numpy(X).cuda().unsqueeze(0)
+            for R in (1, 7, 20):
+                u1, v1 = ctx.svd_init(xd, R)
+                u2, v2 = slow.svd_init(xd, R)
+                ou, ov = oracle.svd_init(X, R)
+                assert np.array_equal(v1[0].cpu().numpy().view(np.int32), v2[0].cpu().numpy().view(np.int32))
+                assert np.array_equal(u1[0].cpu().numpy().view(np.int32), u2[0].cpu().numpy().view(np.int32))
+                assert np.array_equal(v2[0].cpu().numpy().view(np.int32), ov.view(np.int32))
+    finally:
+        slow.close()
+
+
 def test_qmf_class_api(oracle):
     """QMF(...).decompose keeps the reference's interface: (u, v, w) fp32 on the input's device."""
     import lrf_amd

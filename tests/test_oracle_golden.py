@@ -131,3 +131,56 @@ def test_svd_baseline_oracle(name, oracle):
         assert abs(s2 / sc - 1) < 1e-4 and abs(m2 - mn) < 1e-4 * abs(mn) + 1e-4
         d = np.abs(got.astype(np.int32) - q.astype(np.int32))
         assert (d <= 1).mean() >= 0.995 and d.max() <= 2
+
+
+def _sturm_grid(d):
+    """First-pass shifts of the oracle's multisection for a DIAGONAL matrix diag(d) (oracle/lrf_oracle.c top_eigenvalues,
+    restated in numpy doubles): returns the 64 shifts in the matrix's own scale."""
+    import math
+    lo, hi = float(min(d)), float(max(d))
+    tn = max(abs(lo), abs(hi))
+    slack = 2.0 * tn * 2.220446049250313e-16 * 64 + 2.0 * 2.2250738585072014e-300
+    lo -= slack
+    hi += slack
+    s = math.frexp(max(abs(lo), abs(hi)))[1]
+    a, b = math.ldexp(lo, -s), math.ldexp(hi, -s)
+    h = (b - a) / 65.0
+    return [math.ldexp(a + h * float(i + 1), s) for i in range(64)]
+
+
+def test_tridiagonal_eigen_solver(oracle):
+    """lrf_oracle_top_eig_f64 (Householder tridiagonalisation + division-free Sturm counts + twisted factorisation; the
+    arithmetic k_init mirrors) against LAPACK, on full-rank, rank-deficient, constant and zero Gram matrices."""
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        X = rng.random((500, 64)) * 255
+        if trial == 1: X[:, 10:] = 0
+        if trial == 2: X[:] = 7.0
+        if trial == 3: X[:] = 0
+        if trial == 4: X = np.outer(rng.random(500), rng.random(64)) * 100
+        if trial == 5: X = np.diag(np.arange(64.0))
+        G = X.T @ X
+        lam, E = oracle.top_eig_f64(G, 8)
+        w = np.linalg.eigvalsh(G)[::-1][:8]
+        scale = max(w[0], 1e-300)
+        assert np.abs(lam - w).max() <= 4e-15 * scale
+        assert np.abs(E.T @ E - np.eye(8)).max() < 1e-13
+        assert np.abs(G @ E - E * lam[None, :]).max() <= 1e-13 * scale
+
+
+def test_sturm_count_zero_minor_rule(oracle):
+    """A shift of the multisection that equals a diagonal entry exactly makes a leading minor exactly zero; the count
+    must still be right (the replacement rule of sturm_count).  Diagonal matrices whose entries sit ON the first-pass grid."""
+    base = [float(64 - i) for i in range(64)]  # 64, 63, ..., 1
+    grid = _sturm_grid(base)
+    hits = 0
+    for lane in (3, 17, 40, 62):
+        d = list(base)
+        d[10] = grid[lane]  # strictly inside the hull: the hull, hence the grid, is unchanged
+        assert _sturm_grid(d) == grid
+        G = np.diag(np.array(d))
+        lam, E = oracle.top_eig_f64(G, 8)
+        w = np.sort(np.array(d))[::-1][:8]
+        assert np.abs(lam - w).max() <= 4e-15 * 64, (lane, lam, w)
+        hits += 1
+    assert hits == 4
