@@ -510,17 +510,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     __syncthreads();
     {
         const int sc = L.flag[2];
-        for (int r = wave; r < Rc; r += 4) { // one wave per eigenvalue: 64 shifts per pass
-            const int kk = 63 - r;
-            double a = L.scal[2], b = L.scal[3];
+        // A wave runs two searches at once (eigenvalues r0 and r0 + 4, 64 shifts per pass each): at three workgroups per CU the
+        // stage is paced by the LDS reads of the table, and one read now serves both.  A minor that comes out as zero needs
+        // the oracle's replacement rule: such passes (hardly ever) are redone by sturm_count_slow.
+        auto sturm_count_slow = [&](double x) {
+            double p = 1.0, pp = 0.0;
+            int cnt = 0;
+            for (int i = 0; i < 64; i++) {
+                const double2 q = de[i];
+                double pn = fma(q.x - x, p, -(q.y * pp));
+                if (pn == 0.0) pn = (__double2hiint(p) < 0) ? 0x1p-200 : -0x1p-200;
+                cnt += ((__double2hiint(pn) ^ __double2hiint(p)) < 0);
+                pp = p;
+                p = pn;
+                if ((i & 7) == 7) {
+                    const int ea = __builtin_amdgcn_frexp_exp(p), eb = __builtin_amdgcn_frexp_exp(pp);
+                    const int m = ea > eb ? ea : eb;
+                    p = ldexp(p, -m);
+                    pp = ldexp(pp, -m);
+                }
+            }
+            return cnt;
+        };
+        auto narrow = [&](double x, int cnt, int kk, double& a, double& b) {
+            unsigned long long mask = __ballot(cnt > kk);
+            int j = mask ? (int)__builtin_ctzll(mask) : 64;
+            double xm = __shfl(x, j > 0 ? j - 1 : 0, 64), xj = __shfl(x, j < 64 ? j : 63, 64);
+            double na = (j == 0) ? a : xm, nb = (j == 64) ? b : xj;
+            a = na;
+            b = nb;
+        };
+        auto search = [&](int r0, auto two_tag) {
+            constexpr bool TWO = decltype(two_tag)::value;
+            const int r1 = r0 + 4;
+            const int kk0 = 63 - r0, kk1 = 63 - r1;
+            double a0 = L.scal[2], b0 = L.scal[3], a1 = a0, b1 = b0;
             for (int pass = 0; pass < 10; pass++) {
-                double h = (b - a) / 65.0;
-                double x = a + h * (double)(lane + 1);
-                // Sturm count, division-free (oracle: sturm_count): one dependent fma per step.  A minor that comes out as
-                // zero needs the oracle's replacement rule: such passes (hardly ever) are redone by the loop below.
-                double p = 1.0, pp = 0.0;
+                const double x0 = a0 + ((b0 - a0) / 65.0) * (double)(lane + 1);
+                const double x1 = a1 + ((b1 - a1) / 65.0) * (double)(lane + 1);
+                // Sturm counts, division-free (oracle: sturm_count): one dependent fma per step and search
+                double p0 = 1.0, pp0 = 0.0, p1 = 1.0, pp1 = 0.0;
                 bool zero = false;
-                unsigned sgn[2] = {0u, 0u}; // the sign bits of p_1 .. p_64, first at the top: one v_alignbit per step
+                unsigned sg0[2] = {0u, 0u}, sg1[2] = {0u, 0u}; // the sign bits of p_1 .. p_64, first at the top: one v_alignbit per step
 #pragma unroll
                 for (int hf = 0; hf < 2; hf++) {
 #pragma unroll 1
@@ -528,45 +559,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
                         for (int u = 0; u < 8; u++) {
                             const double2 q = de[8 * g + u];
-                            const double pn = fma(q.x - x, p, -(q.y * pp));
-                            zero |= (pn == 0.0);
-                            sgn[hf] = __builtin_amdgcn_alignbit(sgn[hf], (unsigned)__double2hiint(pn), 31);
-                            pp = p;
-                            p = pn;
+                            const double n0 = fma(q.x - x0, p0, -(q.y * pp0));
+                            zero |= (n0 == 0.0);
+                            sg0[hf] = __builtin_amdgcn_alignbit(sg0[hf], (unsigned)__double2hiint(n0), 31);
+                            pp0 = p0; p0 = n0;
+                            if constexpr (TWO) {
+                                const double n1 = fma(q.x - x1, p1, -(q.y * pp1));
+                                zero |= (n1 == 0.0);
+                                sg1[hf] = __builtin_amdgcn_alignbit(sg1[hf], (unsigned)__double2hiint(n1), 31);
+                                pp1 = p1; p1 = n1;
+                            }
                         }
-                        const int ea = __builtin_amdgcn_frexp_exp(p), eb = __builtin_amdgcn_frexp_exp(pp);
-                        const int m = ea > eb ? ea : eb;
-                        p = ldexp(p, -m);
-                        pp = ldexp(pp, -m);
+                        const int ea0 = __builtin_amdgcn_frexp_exp(p0), eb0 = __builtin_amdgcn_frexp_exp(pp0);
+                        const int m0 = ea0 > eb0 ? ea0 : eb0;
+                        p0 = ldexp(p0, -m0); pp0 = ldexp(pp0, -m0);
+                        if constexpr (TWO) {
+                            const int ea1 = __builtin_amdgcn_frexp_exp(p1), eb1 = __builtin_amdgcn_frexp_exp(pp1);
+                            const int m1 = ea1 > eb1 ? ea1 : eb1;
+                            p1 = ldexp(p1, -m1); pp1 = ldexp(pp1, -m1);
+                        }
                     }
                 }
-                const unsigned long long sg = ((unsigned long long)sgn[0] << 32) | sgn[1];
-                int cnt = __popcll(sg ^ (sg >> 1)); // sign changes along 1, p_1, ..., p_64
+                const unsigned long long s0 = ((unsigned long long)sg0[0] << 32) | sg0[1], s1 = ((unsigned long long)sg1[0] << 32) | sg1[1];
+                int cnt0 = __popcll(s0 ^ (s0 >> 1)), cnt1 = __popcll(s1 ^ (s1 >> 1)); // sign changes along 1, p_1, ..., p_64
                 if (__any(zero) || debug_stop == 100) { // wave-uniform (100: the tests force this path, LRF_DEBUG_INIT_SWEEPS)
-                    p = 1.0, pp = 0.0, cnt = 0;
-                    for (int i = 0; i < 64; i++) {
-                        const double2 q = de[i];
-                        double pn = fma(q.x - x, p, -(q.y * pp));
-                        if (pn == 0.0) pn = (__double2hiint(p) < 0) ? 0x1p-200 : -0x1p-200;
-                        cnt += ((__double2hiint(pn) ^ __double2hiint(p)) < 0);
-                        pp = p;
-                        p = pn;
-                        if ((i & 7) == 7) {
-                            const int ea = __builtin_amdgcn_frexp_exp(p), eb = __builtin_amdgcn_frexp_exp(pp);
-                            const int m = ea > eb ? ea : eb;
-                            p = ldexp(p, -m);
-                            pp = ldexp(pp, -m);
-                        }
-                    }
+                    cnt0 = sturm_count_slow(x0);
+                    if constexpr (TWO) cnt1 = sturm_count_slow(x1);
                 }
-                unsigned long long mask = __ballot(cnt > kk);
-                int j = mask ? (int)__builtin_ctzll(mask) : 64;
-                double xm = __shfl(x, j > 0 ? j - 1 : 0, 64), xj = __shfl(x, j < 64 ? j : 63, 64);
-                double na = (j == 0) ? a : xm, nb = (j == 64) ? b : xj;
-                a = na;
-                b = nb;
+                narrow(x0, cnt0, kk0, a0, b0);
+                if constexpr (TWO) narrow(x1, cnt1, kk1, a1, b1);
             }
-            if (lane == 0) L.lam[r] = ldexp(0.5 * (a + b), sc);
+            if (lane == 0) {
+                L.lam[r0] = ldexp(0.5 * (a0 + b0), sc);
+                if constexpr (TWO) L.lam[r1] = ldexp(0.5 * (a1 + b1), sc);
+            }
+        };
+        for (int r0 = wave; r0 < Rc; r0 += 8) {
+            if (r0 + 4 < Rc) search(r0, std::true_type{}); // wave-uniform
+            else search(r0, std::false_type{});
         }
     }
     __syncthreads();
