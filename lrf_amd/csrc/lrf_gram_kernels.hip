@@ -78,42 +78,52 @@ __device__ __forceinline__ void gram_digits(float x, double scale, unsigned (&pk
     }
 }
 
-// The ten upper-triangle tile pairs over the four waves: three pair slots per wave, (tile row, tile column) per slot; waves 2
-// and 3 own two pairs (their third slot is skipped behind a wave-uniform test), so that all waves run the same code on
-// statically indexed accumulators and only the LDS addresses differ (four per-wave code paths spilled registers).
-__device__ __forceinline__ void gram_wave_pairs(int wave, int (&ti)[3], int (&tj)[3])
+// The ten tile pairs over the four waves.  Wave w keeps its own column tile w as the B operand of all its MFMAs ("hub":
+// five ds_read_b128 per block) and owns
+//   slot 0: tile pair (w+1, w)      A = the five digits of tile w+1                         25 MFMAs
+//   slot 1: tile pair (w, w)        A = B                                                   25 MFMAs, no loads
+//   slot 2: HALF of the pair of tiles w and w+2 (mod 4), A = the five digits of the other tile: the digit pairs (a, b) with
+//           a <= b — in waves 2 and 3 the a == b products take a zeroed A operand, because waves 0 and 1, which hold the same
+//           two tiles the other way round, cover them —                                    15 MFMAs
+// 65 MFMAs and 15 operand reads per block and wave (75 / 75 / 50 / 50 and 30 / 30 / 20 / 20 with whole pairs; on a SIMD the
+// MFMA and the VALU time of its waves add up, so the slowest wave sets the pace).  The two halves of a split pair meet once
+// per chunk: waves 2 / 3 pass their nine int32 weight sums, transposed, through LDS to waves 0 / 1.
+// All waves run the same instructions on statically indexed accumulators (branches around MFMAs cost accumulator copies and
+// spills); what differs is data: LDS addresses and the zeroed operand.
+// A tile pair may come out in either orientation: G is symmetric and k_init fills both triangles (gram_pair_tiles).
+__device__ __forceinline__ void gram_accumulate(const uint4* __restrict__ lbuf, int lane, int wave, i32x4 (&acc)[3][9])
 {
-    ti[0] = wave == 0 ? 0 : wave == 1 ? 0 : wave == 2 ? 1 : 2;  tj[0] = wave == 0 ? 0 : 3;
-    ti[1] = wave == 0 ? 0 : wave == 1 ? 1 : wave == 2 ? 2 : 3;  tj[1] = wave == 0 ? 1 : wave == 1 ? 1 : wave == 2 ? 2 : 3;
-    ti[2] = wave == 0 ? 0 : wave == 1 ? 1 : wave == 2 ? 2 : 3;  tj[2] = wave == 0 ? 2 : wave == 1 ? 2 : wave == 2 ? 2 : 3;
-}
-// pair ids of the slots: wave 0: 0 1 2, wave 1: 3 4 5, wave 2: 6 7 (7), wave 3: 8 9 (9)
-
-// One 64-row block: 25 MFMAs per pair into the nine int32 weight sums of each element, which persist over the whole chunk
-// (5 * 127^2 * LRF_GRAM_ROWS < 2^27).  Folding them into wider sums after every block instead (16 registers per pair instead of
-// 36, three waves per SIMD) was measured slower: 108 quarter-rate 64-bit multiply-adds per block and wave, 0.32 ms per 256
-// images against the 0.49 ms of the whole initialisation it was meant to shorten.
-__device__ __forceinline__ void gram_accumulate(const uint4* __restrict__ lbuf, int lane, const int (&ti)[3], const int (&tj)[3],
-                                                i32x4 (&acc)[3][9], int npairs)
-{
+    i32x4 A[5], Bv[5];
+    const uint4* lb = lbuf + wave * 5 * 64 + lane;
+    const uint4* la = lbuf + ((wave + 1) & 3) * 5 * 64 + lane;
 #pragma unroll
-    for (int p = 0; p < 3; p++) {
-        if (p >= npairs) break; // wave-uniform: waves 2 and 3 own two pairs
-        i32x4 A[5], Bv[5];
-        const uint4* la = lbuf + ti[p] * 5 * 64 + lane;
-        const uint4* lb = lbuf + tj[p] * 5 * 64 + lane;
-#pragma unroll
-        for (int a = 0; a < 5; a++) {
-            const uint4 va = la[a * 64], vb = lb[a * 64];
-            A[a] = (i32x4){(int)va.x, (int)va.y, (int)va.z, (int)va.w};
-            Bv[a] = (i32x4){(int)vb.x, (int)vb.y, (int)vb.z, (int)vb.w};
-        }
-#pragma unroll
-        for (int a = 0; a < 5; a++)
-#pragma unroll
-            for (int b = 0; b < 5; b++) acc[p][a + b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[a], Bv[b], acc[p][a + b], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+    for (int a = 0; a < 5; a++) {
+        const uint4 va = la[a * 64], vb = lb[a * 64];
+        A[a] = (i32x4){(int)va.x, (int)va.y, (int)va.z, (int)va.w};
+        Bv[a] = (i32x4){(int)vb.x, (int)vb.y, (int)vb.z, (int)vb.w};
     }
+#pragma unroll
+    for (int a = 0; a < 5; a++)
+#pragma unroll
+        for (int b = 0; b < 5; b++) acc[0][a + b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[a], Bv[b], acc[0][a + b], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int a = 0; a < 5; a++)
+#pragma unroll
+        for (int b = 0; b < 5; b++) acc[1][a + b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Bv[a], Bv[b], acc[1][a + b], 0, 0, 0);
+    // no scheduling barrier here: the operand reads of slot 2 move up under the MFMAs of slot 1 as far as the registers allow
+    const uint4* lc = lbuf + ((wave + 2) & 3) * 5 * 64 + lane;
+    const int keep = wave < 2 ? -1 : 0; // wave-uniform mask of the a == b products
+#pragma unroll
+    for (int a = 0; a < 5; a++) {
+        const uint4 va = lc[a * 64];
+        A[a] = (i32x4){(int)va.x, (int)va.y, (int)va.z, (int)va.w};
+        const i32x4 Ad = (i32x4){A[a][0] & keep, A[a][1] & keep, A[a][2] & keep, A[a][3] & keep};
+        acc[2][2 * a] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Ad, Bv[a], acc[2][2 * a], 0, 0, 0);
+#pragma unroll
+        for (int b = a + 1; b < 5; b++) acc[2][a + b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[a], Bv[b], acc[2][a + b], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // sum += (int128)v << sh  (sh <= 64), two's complement in (lo, hi)
@@ -160,6 +170,46 @@ __device__ __forceinline__ void gram_digits4_planes(const float (&x)[4], unsigne
     pk[4] = d4[0] | (d4[1] << 8) | (d4[2] << 16) | (d4[3] << 24);
 }
 
+// The epilogue of k_gram64: the halves of the split pairs meet, the nine weights fold into one 128-bit
+// integer per element, the chunk's partial goes out as [pair][reg][lane].
+template <bool PLANES>
+__device__ __forceinline__ void gram_finish(i32x4 (&acc)[3][9], uint4* lds0, int lane, int wave, ulonglong2* __restrict__ out)
+{
+    // waves 2 / 3 hold tile (w-2, w) (rows i from tile w-2), waves 0 / 1 tile (w+2, w) of the same two tiles the other way
+    // round: element [i][j] of one is element [j][i] of the other
+    __syncthreads(); // every wave is done with the operand tiles
+    int* xch = reinterpret_cast<int*>(lds0); // [half pair 0 / 1][weight][j][i]: 2 x 9 KB
+    const int li16 = lane & 15, lq4 = lane >> 4;
+    if (wave >= 2) {
+#pragma unroll
+        for (int w = 0; w < 9; w++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) xch[((wave - 2) * 9 + w) * 256 + li16 * 16 + 4 * lq4 + reg] = acc[2][w][reg];
+    }
+    __syncthreads();
+    if (wave < 2) {
+#pragma unroll
+        for (int w = 0; w < 9; w++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) acc[2][w][reg] += xch[(wave * 9 + w) * 256 + (4 * lq4 + reg) * 16 + li16];
+    }
+    const int npairs = wave < 2 ? 3 : 2;
+    const int pair0 = wave == 0 ? 0 : wave == 1 ? 3 : wave == 2 ? 6 : 8;
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+        if (p < npairs) {
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                unsigned long long lo = 0;
+                long long hi = 0;
+#pragma unroll
+                for (int w = 0; w < 9; w++) add_shifted_i128(lo, hi, acc[p][w][reg], (PLANES ? 8 : 7) * w); // digit base of the path
+                out[(pair0 + p) * 256 + reg * 64 + lane] = make_ulonglong2(lo, (unsigned long long)hi);
+            }
+        }
+    }
+}
+
 #ifdef LRF_GRAM_STAMPS // diagnostic build only (tools/dev_stamps_gram.py)
 __device__ unsigned long long g_gram_stamps[8 * 16384];
 __device__ __forceinline__ unsigned long long gram_stamp()
@@ -176,6 +226,10 @@ __device__ __forceinline__ unsigned long long gram_stamp()
 #endif
 
 // PLANES: the matrices come from k_planes / k_planes16 (fixed_exp = 8, exact integer digit extraction)
+// Tried on this kernel and not kept (all bit-identical, 0.18-0.19 ms either way): whole tile pairs per wave (75 / 75 / 50 / 50
+// MFMAs, 100 operand reads per block) against the hub assignment of gram_accumulate; workgroups de-phased by their wave slot
+// (s_sleep at entry); a software-pipelined form — the digits of block b + 1 cut into twelve pieces and placed between the
+// MFMAs of block b by scheduling group barriers, two register sets of values, 250 VGPRs, two workgroups per CU —: 0.207 ms.
 template <bool PLANES>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_gram64(const float* __restrict__ X, const PlaneDesc* __restrict__ planes,
                                                 const GramChunk* __restrict__ chunks, const int* __restrict__ gexp, int fixed_exp,
@@ -198,8 +252,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
         for (int w = 0; w < 9; w++) acc[p][w] = (i32x4){0, 0, 0, 0};
 
-    int pti[3], ptj[3];
-    gram_wave_pairs(wave, pti, ptj);
 
     float vals[16];
     auto load_block = [&](int blk) {
@@ -264,7 +316,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         __builtin_amdgcn_sched_barrier(0);
         GSTAMP(g3);
 #ifndef LRF_GRAM_NO_MFMA
-        gram_accumulate(lb, lane, pti, ptj, acc, wave < 2 ? 3 : 2);
+        gram_accumulate(lb, lane, wave, acc);
 #else
         acc[0][0][0] += (int)lb[lane].x; // ablation builds only
 #endif
@@ -282,23 +334,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         o[0] = gram_stamp() - g_begin; o[1] = ga; o[2] = gb; o[3] = gc; o[4] = gd;
     }
 #endif
-    // fold the nine weights into one 128-bit integer per element and write the chunk's partial: [pair][reg][lane]
-    const int npairs = wave < 2 ? 3 : 2;
-    const int pair0 = wave == 0 ? 0 : wave == 1 ? 3 : wave == 2 ? 6 : 8;
-    ulonglong2* out = Gpart + (long)ch.slot * LRF_GRAM_SLOT;
-#pragma unroll
-    for (int p = 0; p < 3; p++) {
-        if (p < npairs) {
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) {
-                unsigned long long lo = 0;
-                long long hi = 0;
-#pragma unroll
-                for (int w = 0; w < 9; w++) add_shifted_i128(lo, hi, acc[p][w][reg], (PLANES ? 8 : 7) * w); // digit base of the path
-                out[(pair0 + p) * 256 + reg * 64 + lane] = make_ulonglong2(lo, (unsigned long long)hi);
-            }
-        }
-    }
+    gram_finish<PLANES>(acc, lds[0], lane, wave, Gpart + (long)ch.slot * LRF_GRAM_SLOT);
 }
 
 // signed 128-bit integer (two's complement lo, hi) -> fp64, round to nearest even (oracle: u128_to_double_rne)
@@ -332,7 +368,8 @@ __device__ __forceinline__ double i128_to_double_rne(unsigned long long lo, long
 // pair id -> (tile row, tile column)
 __device__ __forceinline__ void gram_pair_tiles(int p, int& ti, int& tj)
 {
-    const int TI[10] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 3}, TJ[10] = {0, 1, 2, 3, 1, 2, 3, 2, 3, 3};
+    // pair slots of k_gram64 (gram_accumulate): wave 0: 0 1 2, wave 1: 3 4 5, wave 2: 6 7, wave 3: 8 9; rows from tile TI
+    const int TI[10] = {1, 0, 2, 2, 1, 3, 3, 2, 0, 3}, TJ[10] = {0, 0, 0, 1, 1, 1, 2, 2, 3, 3};
     ti = TI[p];
     tj = TJ[p];
 }
