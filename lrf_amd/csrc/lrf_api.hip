@@ -663,7 +663,7 @@ int lrf_qmf_planes_from_rgb_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_
         hipLaunchKernelGGL(k_planes16, dim3((unsigned)((H / 16) * ((g.p[0].nw + 31) / 32)), (unsigned)B), dim3(256), 0, c->stream, rgb, (int)H,
                            (int)W, g, X);
     else
-        hipLaunchKernelGGL(k_planes, dim3((unsigned)(g.p[2].pr0 + g.p[2].nh), (unsigned)B), dim3(256), 0, c->stream, rgb, (int)H,
+        hipLaunchKernelGGL(k_planes, dim3((unsigned)(g.p[1].pr0 + g.p[1].nh), (unsigned)B), dim3(256), 0, c->stream, rgb, (int)H,
                            (int)W, g, X);
     LAUNCH_CHECK();
     return LRF_OK;
