@@ -875,21 +875,44 @@ __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, 
                     if (i < n) Lv[i] = x[c];
                 }
                 __syncthreads();
+                // the earlier vectors live in global memory (L2): their loads are issued in batches (all 4 NCT pieces of a
+                // dot product at once, eight vectors per step of the update) instead of one per loop trip; same chains
                 for (int pr = wave; pr < r; pr += 4) {
                     const double* Zp = Z + (long)pr * n;
+                    double zv[4 * NCT];
+#pragma unroll
+                    for (int e = 0; e < 4 * NCT; e++) {
+                        const int i = lane + 64 * e;
+                        zv[e] = Zp[i < n ? i : n - 1];
+                    }
                     double dsum = 0.0;
-                    for (int i = lane; i < n; i += 64) dsum = fma(Zp[i], Lv[i], dsum);
+#pragma unroll
+                    for (int e = 0; e < 4 * NCT; e++) {
+                        const int i = lane + 64 * e;
+                        if (i < n) dsum = fma(zv[e], Lv[i], dsum);
+                    }
                     dsum = wave_sum(dsum);
                     if (lane == 0) Lw[pr] = dsum;
                 }
                 __syncthreads();
-                for (int pr = 0; pr < r; pr++) {
-                    const double cf = Lw[pr];
-                    const double* Zp = Z + (long)pr * n;
+                for (int p0 = 0; p0 < r; p0 += 8) {
+                    double zv[8][NCT];
 #pragma unroll
-                    for (int c = 0; c < NCT; c++) {
-                        const int i = tid + 256 * c;
-                        if (i < n) x[c] = fma(-cf, Zp[i], x[c]);
+                    for (int u = 0; u < 8; u++) {
+                        const double* Zp = Z + (long)(p0 + u < r ? p0 + u : r - 1) * n;
+#pragma unroll
+                        for (int c = 0; c < NCT; c++) {
+                            const int i = tid + 256 * c;
+                            zv[u][c] = Zp[i < n ? i : n - 1];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        if (p0 + u < r) {
+                            const double cf = Lw[p0 + u];
+#pragma unroll
+                            for (int c = 0; c < NCT; c++) x[c] = fma(-cf, zv[u][c], x[c]);
+                        }
                     }
                 }
                 __syncthreads();
