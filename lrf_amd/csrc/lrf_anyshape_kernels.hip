@@ -324,6 +324,127 @@ __global__ __launch_bounds__(256) void k_any_gram(const float* __restrict__ X, l
 // the diagonal tiles above compute (i,j) and (j,i) by the same chain of the same commuting products: exactly symmetric.
 
 // Top-R eigen-pairs of the n x n Gram matrix G (global, destroyed): E1 = e sqrt(sigma), E2 = e / sqrt(sigma), fp32 [n][R].
+// Householder tridiagonalisation of a symmetric n x n matrix, 64 < n <= 64 NC (NC = 2, 3), with the matrix in REGISTERS: the
+// [M,192] Gram matrices of svd_encode and of the RGB colour-space branch, 16 x 8 / 8 x 16 patches.  k_any_eig<1> walks its
+// matrix in global memory three times per step (8.3 ms per 256 matrices of 192 x 192, ~95 % of svd_encode's initialisation);
+// here 256 NC threads hold it the way k_init does for n = 64 — thread (lane i, column chunk cc, row group rg) keeps
+// A[16 NC rg + j][64 cc + i], j < 16 NC, as NC 16-double vectors, so row k is read with a register index — and a step costs
+// three barriers and ~10 KB of LDS traffic.  Arithmetic: k_init's step (one reduction for sigma, t = 1 / (sigma + |x0| nrm),
+// p = t A v from chains over the row groups, commutative rank-2 update).  Output: row k of A keeps the reflector v_k (i > k),
+// td = d[n], e[n], tau[n] for k_any_eig<1>, which then starts at its eigenvalue stage.
+template <int NC>
+__global__ __launch_bounds__(256 * NC) void k_any_tridiag_reg(double* __restrict__ G, int n, double* __restrict__ TD)
+{
+    constexpr int RPT = 16 * NC, NP = 64 * NC; // rows per thread, padded side
+    __shared__ __attribute__((aligned(16))) double xrow2[2 * NP], wrow[NP], cpart[4 * NP];
+    double* A = G + (long)blockIdx.x * n * n;
+    double* td = TD + (long)blockIdx.x * 3 * n;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cc = wave % NC, rg = wave / NC; // column chunk, row group (wave-uniform)
+    const int col = 64 * cc + lane, row0 = rg * RPT;
+    d16 Ar[NC];
+#pragma unroll
+    for (int s = 0; s < NC; s++)
+#pragma unroll
+        for (int jj = 0; jj < 16; jj++) {
+            const int r = row0 + 16 * s + jj;
+            Ar[s][jj] = (r < n && col < n) ? A[(long)r * n + col] : 0.0;
+        }
+    for (int k = 0; k < n - 2; k++) {
+        double* xrow = xrow2 + NP * (k & 1); // double-buffered: the update of step k - 1 may still be reading the other one
+        if (rg == k / RPT) { // the row group that holds row k publishes it (entries up to column k as zeros)
+            const int kl = k - row0, jj = kl & 15;
+            double xk = Ar[0][jj];
+            if (NC > 1 && (kl >> 4) == 1) xk = Ar[1][jj];
+            if (NC > 2 && (kl >> 4) == 2) xk = Ar[NC - 1][jj];
+            xrow[col] = (col > k) ? xk : 0.0;
+        }
+        __syncthreads();
+        // every wave: the reflector's scalars (same bits in all of them)
+        double xs[NC], sq = 0.0;
+#pragma unroll
+        for (int c2 = 0; c2 < NC; c2++) {
+            xs[c2] = xrow[64 * c2 + lane];
+            sq = fma(xs[c2], xs[c2], sq);
+        }
+        const double sigma = wave_sum(sq);
+        if (!(sigma > LRF_SIGMA_TINY)) { // wave-uniform, the same in every wave
+            if (tid == 0) { td[n + k] = 0.0; td[2 * n + k] = 0.0; }
+            continue; // no barrier needed: the next step writes the other buffer, and its barrier orders the step after
+        }
+        const double x0 = xrow[k + 1];
+        const double nrm = sqrt(sigma);
+        const double alpha = (x0 >= 0.0) ? -nrm : nrm;
+        const double vfix = x0 - alpha;
+        const double t = 1.0 / fma(fabs(x0), nrm, sigma);
+        double vc = xs[0];
+        if (NC > 1 && cc == 1) vc = xs[1];
+        if (NC > 2 && cc == 2) vc = xs[NC - 1];
+        if (col == k + 1) vc = vfix;
+        if (rg == k / RPT && col > k && col < n) A[(long)k * n + col] = vc; // v_k for the back-transformation
+        const bool fix_here = rg == (k + 1) / RPT; // wave-uniform: v[k+1] lies in this wave's rows
+        const int fix_j = k + 1 - row0;
+        { // matvec partial over this thread's rows: one chain per 16-row sub-block
+            double cs = 0.0;
+#pragma unroll
+            for (int s = 0; s < NC; s++) {
+                double c = 0.0;
+#pragma unroll
+                for (int jj = 0; jj < 16; jj++) {
+                    double vj = xrow[row0 + 16 * s + jj];
+                    if (fix_here && 16 * s + jj == fix_j) vj = vfix;
+                    c = fma(Ar[s][jj], vj, c);
+                }
+                cs = s ? cs + c : c;
+            }
+            cpart[rg * NP + col] = (col > k) ? cs : 0.0;
+        }
+        __syncthreads();
+        // every wave: p on all columns (NC per lane), K, w on its own column; row group 0 publishes w
+        double wc = 0.0;
+        {
+            double pk[NC], vk[NC], s2 = 0.0;
+#pragma unroll
+            for (int c2 = 0; c2 < NC; c2++) {
+                const int i = 64 * c2 + lane;
+                pk[c2] = t * (((cpart[i] + cpart[NP + i]) + cpart[2 * NP + i]) + cpart[3 * NP + i]);
+                vk[c2] = (i == k + 1) ? vfix : xs[c2];
+                s2 = fma(pk[c2], vk[c2], s2);
+            }
+            const double K = (0.5 * t) * wave_sum(s2);
+            double pc = pk[0], vv = vk[0];
+            if (NC > 1 && cc == 1) { pc = pk[1]; vv = vk[1]; }
+            if (NC > 2 && cc == 2) { pc = pk[NC - 1]; vv = vk[NC - 1]; }
+            wc = fma(-K, vv, pc);
+            if (rg == 0) wrow[col] = wc;
+            if (tid == 0) { td[n + k] = alpha; td[2 * n + k] = t; }
+        }
+        __syncthreads();
+        // rank-2 update, both products rounded and then added (k_init): v and w are zero up to index k
+#pragma unroll
+        for (int s = 0; s < NC; s++)
+#pragma unroll
+            for (int jj = 0; jj < 16; jj++) {
+                double vj = xrow[row0 + 16 * s + jj];
+                if (fix_here && 16 * s + jj == fix_j) vj = vfix;
+                const double wj = wrow[row0 + 16 * s + jj];
+                const double m1 = vj * wc, m2 = wj * vc;
+                Ar[s][jj] = Ar[s][jj] - (m1 + m2);
+            }
+    }
+    // d = diagonal, e[n-2] = A[n-1][n-2]
+#pragma unroll
+    for (int s = 0; s < NC; s++)
+#pragma unroll
+        for (int jj = 0; jj < 16; jj++) {
+            const int r = row0 + 16 * s + jj;
+            if (r == col && r < n) td[r] = Ar[s][jj];
+            if (r == n - 1 && col == n - 2) td[n + n - 2] = Ar[s][jj];
+        }
+    if (tid == 0) { td[n + n - 1] = 0.0; td[2 * n + n - 2] = 0.0; td[2 * n + n - 1] = 0.0; }
+}
+
 // One workgroup per matrix; thread t owns the columns t, t + 256, ... (NC = ceil(n/256) <= NCT of them).
 // Workspaces per matrix: Z [R][n] doubles (vectors), Dw [2][n][Rc] doubles (the two pivots sequences of the twisted
 // factorisation).  Dynamic LDS: six n-vectors, lam[R], reduction scratch.
@@ -331,7 +452,8 @@ template <int NCT>
 __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, int R, const int8_t* __restrict__ sign,
                                                  float* __restrict__ E1, float* __restrict__ E2, double* __restrict__ Zw,
                                                  double* __restrict__ Dw, int stop_after /* developer timing aid, 0 = run all */,
-                                                 int rcap /* rank of the matrix at most this: columns beyond are zero */)
+                                                 int rcap /* rank of the matrix at most this: columns beyond are zero */,
+                                                 const double* __restrict__ td_in /* d, e, tau of k_any_tridiag_reg, or NULL */)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* Lv = reinterpret_cast<double*>(smem);
@@ -353,7 +475,11 @@ __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int UB = 16 / NCT; // rows per batch and thread in the passes over the matrix (two batches in flight; 32 / NCT changed nothing)
 
-    if constexpr (NCT == 1) {
+    if (td_in) { // tridiagonalised already (k_any_tridiag_reg): row k of A holds v_k
+        const double* tdm = td_in + (long)blockIdx.x * 3 * n;
+        for (int i = tid; i < n; i += 256) { Ld[i] = tdm[i]; Le[i] = tdm[n + i]; Ltau[i] = tdm[2 * n + i]; }
+        __syncthreads();
+    } else if constexpr (NCT == 1) {
     // n <= 256 (svd_encode's and the RGB colour space's [M,192] matrices, 16x16 patches): three passes per step over a matrix
     // that sits in the L2; the fused form below costs one more exposed load round trip per step there (svd_encode of 256 images
     // 8.07 -> 8.46 ms), so these sizes keep the plain loop.
@@ -672,15 +798,17 @@ __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, 
             }
         }
     }
+    if (!td_in) {
 #pragma unroll
-    for (int c = 0; c < NCT; c++) {
-        const int i = tid + 256 * c;
-        if (i < n) Ld[i] = A[(long)i * n + i];
-    }
-    if (tid == 0) {
-        if (n >= 2) { Le[n - 2] = A[(long)(n - 1) * n + n - 2]; Ltau[n - 2] = 0.0; }
-        Le[n - 1] = 0.0;
-        Ltau[n - 1] = 0.0;
+        for (int c = 0; c < NCT; c++) {
+            const int i = tid + 256 * c;
+            if (i < n) Ld[i] = A[(long)i * n + i];
+        }
+        if (tid == 0) {
+            if (n >= 2) { Le[n - 2] = A[(long)(n - 1) * n + n - 2]; Ltau[n - 2] = 0.0; }
+            Le[n - 1] = 0.0;
+            Ltau[n - 1] = 0.0;
+        }
     }
     __syncthreads();
 

@@ -81,7 +81,7 @@ struct lrf_ctx {
     DevBuf planes, blocks, gchunks, vf, wf, bf, ppart, qpart, x, sign;
     DevBuf gpart, gexp; // exact Gram partials (128-bit integers per chunk) and per-matrix grid exponents (lrf_gram_kernels.hip)
     DevBuf sx, sg, svn, swn, suf, smm; // SVD baseline workspace
-    DevBuf any_uf, any_vf, any_a, any_b, any_p, any_e2, any_g; // any-shape path (lrf_anyshape_host.inc)
+    DevBuf any_uf, any_vf, any_a, any_b, any_p, any_e2, any_g, any_td; // any-shape path (lrf_anyshape_host.inc)
     // host staging for descriptor tables (pinned)
     void* h_stage = nullptr;
     size_t h_stage_cap = 0;
@@ -508,7 +508,7 @@ void lrf_ctx_destroy(lrf_ctx* c)
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     DevBuf* bufs[] = {&c->planes_alt, &c->blocks_alt, &c->gchunks_alt, &c->gchunks, &c->gpart, &c->gexp, &c->planes, &c->blocks, &c->vf, &c->wf, &c->bf, &c->ppart, &c->qpart, &c->x, &c->sign,
                       &c->sx, &c->sg, &c->svn, &c->swn, &c->suf, &c->smm,
-                      &c->any_uf, &c->any_vf, &c->any_a, &c->any_b, &c->any_p, &c->any_e2, &c->any_g};
+                      &c->any_uf, &c->any_vf, &c->any_a, &c->any_b, &c->any_p, &c->any_e2, &c->any_g, &c->any_td};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -548,7 +548,7 @@ size_t lrf_ctx_workspace_bytes(const lrf_ctx* c)
     if (!c) return 0;
     const DevBuf* bufs[] = {&c->planes_alt, &c->blocks_alt, &c->gchunks_alt, &c->gchunks, &c->gpart, &c->gexp, &c->planes, &c->blocks, &c->vf, &c->wf, &c->bf, &c->ppart, &c->qpart, &c->x, &c->sign,
                             &c->sx, &c->sg, &c->svn, &c->swn, &c->suf, &c->smm,
-                            &c->any_uf, &c->any_vf, &c->any_a, &c->any_b, &c->any_p, &c->any_e2, &c->any_g};
+                            &c->any_uf, &c->any_vf, &c->any_a, &c->any_b, &c->any_p, &c->any_e2, &c->any_g, &c->any_td};
     size_t total = 0;
     for (const DevBuf* b : bufs) total += b->cap;
     return total;
@@ -561,7 +561,7 @@ int lrf_ctx_trim(lrf_ctx* c)
     HIP_TRY(hipStreamSynchronize(c->stream));
     DevBuf* bufs[] = {&c->planes_alt, &c->blocks_alt, &c->gchunks_alt, &c->gchunks, &c->gpart, &c->gexp, &c->planes, &c->blocks, &c->vf,
                       &c->wf, &c->bf, &c->ppart, &c->qpart, &c->x, &c->sign, &c->sx, &c->sg, &c->svn, &c->swn, &c->suf, &c->smm,
-                      &c->any_uf, &c->any_vf, &c->any_a, &c->any_b, &c->any_p, &c->any_e2, &c->any_g};
+                      &c->any_uf, &c->any_vf, &c->any_a, &c->any_b, &c->any_p, &c->any_e2, &c->any_g, &c->any_td};
     for (DevBuf* b : bufs) {
         if (b->p) HIP_TRY(hipFree(b->p));
         b->p = nullptr;
@@ -1150,6 +1150,26 @@ int lrf_debug_read_gram_stamps(lrf_ctx* c, unsigned long long* out_host, int n)
 }
 #endif
 
+// Gram matrices of B matrices [M,192] of uint8-valued floats (svd_encode, RGB colour-space branch): exact, int8 MFMA
+static int gram192_u8(lrf_ctx* c, const float* X, long xs, int B, int M, double* G)
+{
+    static const bool use_f64 = getenv("LRF_GRAM192_F64") && getenv("LRF_GRAM192_F64")[0] == '1'; // developer comparison aid
+    if (use_f64 || M > 100000) { // int32 sums hold 128^2 x 131072 rows; longer matrices take the fp64 kernel
+        hipLaunchKernelGGL(k_gram_blk, dim3(6, (unsigned)B), dim3(256), 0, c->stream, X, xs, M, 192, 3, G);
+        LAUNCH_CHECK();
+        return LRF_OK;
+    }
+    const int nchunks = (M + LRF_G192_ROWS - 1) / LRF_G192_ROWS;
+    int rc;
+    if ((rc = ensure(c, c->any_td, (size_t)B * nchunks * (192 * 192 + 192) * sizeof(int)))) return rc;
+    int* P = (int*)c->any_td.p; // consumed by the fold before the eigen-solver reuses the buffer (same stream)
+    hipLaunchKernelGGL(k_gram192_u8, dim3((unsigned)nchunks, (unsigned)B), dim3(256), 0, c->stream, X, xs, M, P, nchunks);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_gram192_fold, dim3(144, (unsigned)B), dim3(256), 0, c->stream, (const int*)P, nchunks, M, G);
+    LAUNCH_CHECK();
+    return LRF_OK;
+}
+
 /* ---- SVD baseline (lrf.svd_encode / svd_decode, default RGB branch) ---- */
 static int svd_geom(int64_t H, int64_t W, int* hp, int* wp, int* top, int* left, int* nw, int* M)
 {
@@ -1171,7 +1191,7 @@ int lrf_svd_encode_rgb_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_t H, 
     if (R > 192) return set_err(LRF_EINVAL, "svd_encode: rank %d > 192 columns", R);
     int hp, wp, top, left, nw, M, rc;
     if ((rc = svd_geom(H, W, &hp, &wp, &top, &left, &nw, &M))) return rc;
-    const int N = 192, nc = 3;
+    const int N = 192;
     LRF_ON_DEVICE(c);
     long xs = (long)M * N;
     if ((rc = ensure(c, c->sx, (size_t)B * xs * sizeof(float)))) return rc;
@@ -1188,8 +1208,7 @@ int lrf_svd_encode_rgb_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_t H, 
     float* mm = (float*)c->smm.p;
     hipLaunchKernelGGL(k_patchify_rgb, dim3(hp / 8, (unsigned)B), dim3(256), 0, c->stream, rgb, (int)H, (int)W, top, left, nw, xs, X);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_gram_blk, dim3(nc * (nc + 1) / 2, (unsigned)B), dim3(256), 0, c->stream, (const float*)X, xs, M, N, nc, G);
-    LAUNCH_CHECK();
+    if ((rc = gram192_u8(c, X, xs, (int)B, M, G))) return rc;
     if ((rc = any_factors_from_gram(c, X, G, (int)B, M, N, R, sign, Vn, Wn, Uf))) return rc;
     hipLaunchKernelGGL(k_minmax, dim3((unsigned)B), dim3(256), 0, c->stream, (const float*)Uf, (long)M * R, (long)M * R, mm);
     LAUNCH_CHECK();
@@ -1241,7 +1260,7 @@ int lrf_qmf_rgbspace_encode_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_
     int hp, wp, top, left, nw, M, rc;
     if ((rc = svd_geom(H, W, &hp, &wp, &top, &left, &nw, &M))) return rc;
     if ((rc = rgbspace_check(B, H, W, R, K, lo, hi, M))) return rc;
-    const int N = 192, nc = 3;
+    const int N = 192;
     LRF_ON_DEVICE(c);
     const long xs = (long)M * N;
     if ((rc = ensure(c, c->sx, (size_t)B * xs * sizeof(float)))) return rc;
@@ -1265,8 +1284,7 @@ int lrf_qmf_rgbspace_encode_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_
         double* G = (double*)c->sg.p;
         float* Wn = (float*)c->swn.p;
         Prof p(c, LRF_K_INIT);
-        hipLaunchKernelGGL(k_gram_blk, dim3(nc * (nc + 1) / 2, (unsigned)B), dim3(256), 0, c->stream, (const float*)X, xs, M, N, nc, G);
-        LAUNCH_CHECK();
+        if ((rc = gram192_u8(c, X, xs, (int)B, M, G))) return rc;
         if ((rc = any_factors_from_gram(c, X, G, (int)B, M, N, R, sign, Vf, Wn, Uf))) return rc;
     }
     return any_run_bcd(c, X, (int)B, M, N, R, K, lo, hi, U, V);
