@@ -329,14 +329,20 @@ __global__ __launch_bounds__(256) void k_any_gram(const float* __restrict__ X, l
 // matrix in global memory three times per step (8.3 ms per 256 matrices of 192 x 192, ~95 % of svd_encode's initialisation);
 // here 256 NC threads hold it the way k_init does for n = 64 — thread (lane i, column chunk cc, row group rg) keeps
 // A[16 NC rg + j][64 cc + i], j < 16 NC, as NC 16-double vectors, so row k is read with a register index — and a step costs
-// three barriers and ~10 KB of LDS traffic.  Arithmetic: k_init's step (one reduction for sigma, t = 1 / (sigma + |x0| nrm),
+// two barriers.  Arithmetic: k_init's step (one reduction for sigma, t = 1 / (sigma + |x0| nrm),
 // p = t A v from chains over the row groups, commutative rank-2 update).  Output: row k of A keeps the reflector v_k (i > k),
 // td = d[n], e[n], tau[n] for k_any_eig<1>, which then starts at its eigenvalue stage.
+// lane `src_lane` of a double register, as a wave-uniform value (two v_readlane_b32: the result lives in SGPRs)
+__device__ __forceinline__ double readlane_f64(double v, int src_lane)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src_lane), __builtin_amdgcn_readlane(__double2loint(v), src_lane));
+}
+
 template <int NC>
 __global__ __launch_bounds__(256 * NC) void k_any_tridiag_reg(double* __restrict__ G, int n, double* __restrict__ TD)
 {
     constexpr int RPT = 16 * NC, NP = 64 * NC; // rows per thread, padded side
-    __shared__ __attribute__((aligned(16))) double xrow2[2 * NP], wrow[NP], cpart[4 * NP];
+    __shared__ __attribute__((aligned(16))) double xrow2[2 * NP], cpart[4 * NP];
     double* A = G + (long)blockIdx.x * n * n;
     double* td = TD + (long)blockIdx.x * 3 * n;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -351,8 +357,19 @@ __global__ __launch_bounds__(256 * NC) void k_any_tridiag_reg(double* __restrict
             const int r = row0 + 16 * s + jj;
             Ar[s][jj] = (r < n && col < n) ? A[(long)r * n + col] : 0.0;
         }
+    // Every wave holds v and w on ALL columns (NC values per lane: the scalars of a step are computed redundantly, same bits),
+    // so the values a thread needs at its ROWS come out of the wave's own registers by v_readlane (wave-uniform, in SGPRs)
+    // instead of broadcast LDS reads — twelve waves reading 144 doubles each per step had made the LDS the bottleneck
+    // (1.26 -> 0.5 ms per 256 matrices of 192 x 192) — and w needs neither LDS nor a third barrier.
+    // A 16-row sub-block lies inside one 64-column chunk: chunk and first lane of sub-block s of this wave's rows.
+    auto pick = [&](const double (&q)[NC], int chunk) __attribute__((always_inline)) {
+        double r = q[0];
+        if (NC > 1 && chunk == 1) r = q[1];
+        if (NC > 2 && chunk == 2) r = q[NC - 1];
+        return r;
+    };
     for (int k = 0; k < n - 2; k++) {
-        double* xrow = xrow2 + NP * (k & 1); // double-buffered: the update of step k - 1 may still be reading the other one
+        double* xrow = xrow2 + NP * (k & 1); // double-buffered: a slower wave may still be reading the other one
         if (rg == k / RPT) { // the row group that holds row k publishes it (entries up to column k as zeros)
             const int kl = k - row0, jj = kl & 15;
             double xk = Ar[0][jj];
@@ -371,67 +388,64 @@ __global__ __launch_bounds__(256 * NC) void k_any_tridiag_reg(double* __restrict
         const double sigma = wave_sum(sq);
         if (!(sigma > LRF_SIGMA_TINY)) { // wave-uniform, the same in every wave
             if (tid == 0) { td[n + k] = 0.0; td[2 * n + k] = 0.0; }
-            continue; // no barrier needed: the next step writes the other buffer, and its barrier orders the step after
+            continue; // the next step writes the other buffer, and its barrier orders the step after
         }
-        const double x0 = xrow[k + 1];
+        const double x0 = readlane_f64(pick(xs, (k + 1) >> 6), (k + 1) & 63);
         const double nrm = sqrt(sigma);
         const double alpha = (x0 >= 0.0) ? -nrm : nrm;
         const double vfix = x0 - alpha;
         const double t = 1.0 / fma(fabs(x0), nrm, sigma);
-        double vc = xs[0];
-        if (NC > 1 && cc == 1) vc = xs[1];
-        if (NC > 2 && cc == 2) vc = xs[NC - 1];
-        if (col == k + 1) vc = vfix;
+        double vk[NC]; // v on the columns lane, 64 + lane, ...
+#pragma unroll
+        for (int c2 = 0; c2 < NC; c2++) vk[c2] = (64 * c2 + lane == k + 1) ? vfix : xs[c2];
+        const double vc = pick(vk, cc);
         if (rg == k / RPT && col > k && col < n) A[(long)k * n + col] = vc; // v_k for the back-transformation
-        const bool fix_here = rg == (k + 1) / RPT; // wave-uniform: v[k+1] lies in this wave's rows
-        const int fix_j = k + 1 - row0;
-        { // matvec partial over this thread's rows: one chain per 16-row sub-block
+        const bool cols_live = 64 * cc + 63 > k; // wave-uniform: some column of this wave is still in the trailing matrix
+        { // matvec partial over this thread's rows: one chain per 16-row sub-block; finished sub-blocks (v = 0 there) are skipped
             double cs = 0.0;
 #pragma unroll
             for (int s = 0; s < NC; s++) {
+                const int r0 = row0 + 16 * s;
                 double c = 0.0;
+                if (cols_live && r0 + 15 > k) { // wave-uniform
+                    const double src = pick(vk, r0 >> 6);
 #pragma unroll
-                for (int jj = 0; jj < 16; jj++) {
-                    double vj = xrow[row0 + 16 * s + jj];
-                    if (fix_here && 16 * s + jj == fix_j) vj = vfix;
-                    c = fma(Ar[s][jj], vj, c);
+                    for (int jj = 0; jj < 16; jj++) c = fma(Ar[s][jj], readlane_f64(src, (r0 & 63) + jj), c);
                 }
                 cs = s ? cs + c : c;
             }
             cpart[rg * NP + col] = (col > k) ? cs : 0.0;
         }
         __syncthreads();
-        // every wave: p on all columns (NC per lane), K, w on its own column; row group 0 publishes w
-        double wc = 0.0;
+        // every wave: p, K, w on all columns
+        double wk[NC];
         {
-            double pk[NC], vk[NC], s2 = 0.0;
+            double pk[NC], s2 = 0.0;
 #pragma unroll
             for (int c2 = 0; c2 < NC; c2++) {
                 const int i = 64 * c2 + lane;
                 pk[c2] = t * (((cpart[i] + cpart[NP + i]) + cpart[2 * NP + i]) + cpart[3 * NP + i]);
-                vk[c2] = (i == k + 1) ? vfix : xs[c2];
                 s2 = fma(pk[c2], vk[c2], s2);
             }
             const double K = (0.5 * t) * wave_sum(s2);
-            double pc = pk[0], vv = vk[0];
-            if (NC > 1 && cc == 1) { pc = pk[1]; vv = vk[1]; }
-            if (NC > 2 && cc == 2) { pc = pk[NC - 1]; vv = vk[NC - 1]; }
-            wc = fma(-K, vv, pc);
-            if (rg == 0) wrow[col] = wc;
+#pragma unroll
+            for (int c2 = 0; c2 < NC; c2++) wk[c2] = fma(-K, vk[c2], pk[c2]);
             if (tid == 0) { td[n + k] = alpha; td[2 * n + k] = t; }
         }
-        __syncthreads();
+        const double wc = pick(wk, cc);
         // rank-2 update, both products rounded and then added (k_init): v and w are zero up to index k
 #pragma unroll
-        for (int s = 0; s < NC; s++)
+        for (int s = 0; s < NC; s++) {
+            const int r0 = row0 + 16 * s;
+            if (!(cols_live && r0 + 15 > k)) continue; // wave-uniform: rows and columns up to k are finished
+            const double sv = pick(vk, r0 >> 6), sw = pick(wk, r0 >> 6);
 #pragma unroll
             for (int jj = 0; jj < 16; jj++) {
-                double vj = xrow[row0 + 16 * s + jj];
-                if (fix_here && 16 * s + jj == fix_j) vj = vfix;
-                const double wj = wrow[row0 + 16 * s + jj];
+                const double vj = readlane_f64(sv, (r0 & 63) + jj), wj = readlane_f64(sw, (r0 & 63) + jj);
                 const double m1 = vj * wc, m2 = wj * vc;
                 Ar[s][jj] = Ar[s][jj] - (m1 + m2);
             }
+        }
     }
     // d = diagonal, e[n-2] = A[n-1][n-2]
 #pragma unroll
