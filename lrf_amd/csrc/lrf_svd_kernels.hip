@@ -101,15 +101,15 @@ __global__ __launch_bounds__(256) void k_gram_blk(const float* __restrict__ X, l
 // x = a + 128 with a in [-128, 127] one int8 digit: S_ij = sum_m a_mi a_mj on the int8 matrix cores
 // (v_mfma_i32_16x16x64_i8: 64 rows per instruction, where the fp64 MFMA of k_gram_blk takes 4 rows in four times the cycles),
 // column sums s_i on the VALU, and G_ij = S_ij + 128 (s_i + s_j) + 128^2 M — exact integers (< 2^53), so G is the exact Gram
-// matrix and does not depend on how the rows are grouped.  One workgroup per (1536-row chunk, matrix): wave w converts the
-// columns 48 w .. 48 w + 47 (three 16-column tiles, sixteen strided dword loads each) to int8 in MFMA operand layout, the
-// twelve tiles meet in LDS (double-buffered, one barrier per 64-row block), and wave w accumulates the 12 x 3 tile products
-// (all tiles) x (its own three) — both triangles, the same code in every wave.  k_gram192_fold adds the chunks' int32
-// partials and the offset terms.  256 x [6144,192]: 2.49 ms (k_gram_blk, fp64 MFMA at 39 % of its peak) -> 0.3 ms.
+// matrix and does not depend on how the rows are grouped.  One workgroup per (1536-row chunk, matrix): the twelve 16-column
+// tiles of a 64-row block meet in LDS as int8 in MFMA operand layout (double-buffered, one barrier per block), and wave w
+// accumulates the 12 x 3 tile products (all tiles) x (its own three) — both triangles, the same code in every wave — plus
+// the column sums of its tiles as products with a tile of ones.  k_gram192_fold adds the chunks' int32
+// partials and the offset terms.  256 x [6144,192]: 2.49 ms (k_gram_blk, fp64 MFMA at 39 % of its peak) -> 0.8 ms with strided dword loads -> see DESIGN.md.
 #define LRF_G192_ROWS 1536
 __global__ __launch_bounds__(256) void k_gram192_u8(const float* __restrict__ X, long x_stride, int M, int* __restrict__ P, int nchunks)
 {
-    __shared__ uint4 lds[2][12 * 64]; // [buffer][tile][lane]: 24 KB
+    __shared__ uint4 lds[2][12 * 64]; // [buffer][tile][lane = 16 kq + li]: rows 16 kq .. + 15 of column 16 tile + li; 24 KB
     const int chunk = blockIdx.x;
     const float* Xp = X + (long)blockIdx.y * x_stride;
     int* Pp = P + ((long)blockIdx.y * nchunks + chunk) * (192 * 192 + 192);
@@ -118,50 +118,63 @@ __global__ __launch_bounds__(256) void k_gram192_u8(const float* __restrict__ X,
     const int li = lane & 15, kq = lane >> 4;
     const int row_lo = chunk * LRF_G192_ROWS, row_hi = min(M, row_lo + LRF_G192_ROWS);
     const int nblk = (row_hi - row_lo + 63) >> 6;
-    i32x4 acc[3][12];
+    i32x4 acc[3][12], accs[3];
 #pragma unroll
-    for (int j = 0; j < 3; j++)
+    for (int j = 0; j < 3; j++) {
+        accs[j] = (i32x4){0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < 12; i++) acc[j][i] = (i32x4){0, 0, 0, 0};
-    int csum[3] = {0, 0, 0};
-    float vals[3][16];
+    }
+    // A 64 x 192 block is loaded as float4s along the rows (768 contiguous bytes per row: the strided dword loads of the
+    // operand layout ran at 1.5 TB/s): item = (row group g of 4 rows, column group c4 of 4 columns), 16 x 48 items, three
+    // per thread; its 4 x 4 values become int8, are transposed in registers (v_perm_b32) and go to LDS as four dwords, each
+    // the four rows of one column — so that an operand (sixteen rows of a column) is one ds_read_b128.
+    f32x4 vals[3][4];
     auto load_block = [&](int blk) __attribute__((always_inline)) {
-        const int r0 = row_lo + blk * 64 + 16 * kq;
 #pragma unroll
-        for (int t = 0; t < 3; t++)
+        for (int it = 0; it < 3; it++) {
+            const int item = tid + 256 * it, g = item / 48, c4 = item - 48 * g;
 #pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const int row = r0 + j;
-                const float v = Xp[(long)(row < row_hi ? row : row_hi - 1) * 192 + 48 * wave + 16 * t + li];
-                vals[t][j] = (row < row_hi) ? v : 128.f; // rows past the end: a = 0
+            for (int r = 0; r < 4; r++) {
+                const int row = row_lo + blk * 64 + 4 * g + r;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(Xp + (long)(row < row_hi ? row : row_hi - 1) * 192 + 4 * c4);
+                vals[it][r] = (row < row_hi) ? v : (f32x4){128.f, 128.f, 128.f, 128.f}; // rows past the end: a = 0
             }
+        }
     };
     load_block(0);
     for (int blk = 0; blk < nblk; blk++) {
-        uint4* lb = lds[blk & 1];
+        unsigned* lw = reinterpret_cast<unsigned*>(lds[blk & 1]);
 #pragma unroll
-        for (int t = 0; t < 3; t++) {
-            unsigned pk[4];
+        for (int it = 0; it < 3; it++) {
+            const int item = tid + 256 * it, g = item / 48, c4 = item - 48 * g;
+            unsigned rw[4]; // row r: its four columns as bytes
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                int a[4];
-#pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    a[b] = (int)vals[t][4 * q + b] - 128;
-                    csum[t] += a[b];
-                }
-                pk[q] = (unsigned)(a[0] & 255) | ((unsigned)(a[1] & 255) << 8) | ((unsigned)(a[2] & 255) << 16) | ((unsigned)(a[3] & 255) << 24);
+            for (int r = 0; r < 4; r++) {
+                const f32x4 v = vals[it][r];
+                rw[r] = ((unsigned)((int)v[0] - 128) & 255u) | (((unsigned)((int)v[1] - 128) & 255u) << 8) |
+                        (((unsigned)((int)v[2] - 128) & 255u) << 16) | (((unsigned)((int)v[3] - 128) & 255u) << 24);
             }
-            lb[(3 * wave + t) * 64 + lane] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            // 4 x 4 byte transpose: cw[i] = column i, its four rows
+            const unsigned t0 = __builtin_amdgcn_perm(rw[1], rw[0], 0x05010400u), t1 = __builtin_amdgcn_perm(rw[1], rw[0], 0x07030602u);
+            const unsigned t2 = __builtin_amdgcn_perm(rw[3], rw[2], 0x05010400u), t3 = __builtin_amdgcn_perm(rw[3], rw[2], 0x07030602u);
+            const unsigned cw[4] = {__builtin_amdgcn_perm(t2, t0, 0x05040100u), __builtin_amdgcn_perm(t2, t0, 0x07060302u),
+                                    __builtin_amdgcn_perm(t3, t1, 0x05040100u), __builtin_amdgcn_perm(t3, t1, 0x07060302u)};
+            const int tile = c4 >> 2;
+#pragma unroll
+            for (int i = 0; i < 4; i++) lw[(tile * 64 + (g >> 2) * 16 + 4 * (c4 & 3) + i) * 4 + (g & 3)] = cw[i];
         }
         __builtin_amdgcn_sched_barrier(0);
         if (blk + 1 < nblk) load_block(blk + 1); // lands under the MFMAs below
         __syncthreads(); // one barrier per block: the other buffer is not written before every wave has passed this point again
+        const uint4* lb = lds[blk & 1];
         i32x4 Bv[3];
+        const i32x4 ones = (i32x4){0x01010101, 0x01010101, 0x01010101, 0x01010101};
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             const uint4 x = lb[(3 * wave + j) * 64 + lane];
             Bv[j] = (i32x4){(int)x.x, (int)x.y, (int)x.z, (int)x.w};
+            accs[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Bv[j], ones, accs[j], 0, 0, 0); // column sums of tile 3 wave + j (every column of D)
         }
 #pragma unroll
         for (int i = 0; i < 12; i++) {
@@ -178,13 +191,12 @@ __global__ __launch_bounds__(256) void k_gram192_u8(const float* __restrict__ X,
         for (int i = 0; i < 12; i++)
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) Pp[(16 * i + 4 * kq + reg) * 192 + 48 * wave + 16 * j + li] = acc[j][i][reg];
-    // column sums: the four row quarters (kq) of a column sit in lanes li, li + 16, li + 32, li + 48
+    // column sums: D[r][c] = sum of column r of tile 3 wave + j for every c; the lanes with c = 0 write them
+    if (li == 0) {
 #pragma unroll
-    for (int t = 0; t < 3; t++) {
-        int v = csum[t];
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        if (kq == 0) Pp[192 * 192 + 48 * wave + 16 * t + li] = v;
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) Pp[192 * 192 + 48 * wave + 16 * j + 4 * kq + reg] = accs[j][reg];
     }
 }
 
