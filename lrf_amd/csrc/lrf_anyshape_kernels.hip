@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256 * NC) void k_any_tridiag_reg(double* __restrict
             xs[c2] = xrow[64 * c2 + lane];
             sq = fma(xs[c2], xs[c2], sq);
         }
-        const double sigma = wave_sum(sq);
+        const double sigma = wave_tree64(sq); // DPP / permlane tree of k_init (lrf_kernels.hip): no LDS crossbar
         if (!(sigma > LRF_SIGMA_TINY)) { // wave-uniform, the same in every wave
             if (tid == 0) { td[n + k] = 0.0; td[2 * n + k] = 0.0; }
             continue; // the next step writes the other buffer, and its barrier orders the step after
@@ -427,13 +427,15 @@ __global__ __launch_bounds__(256 * NC) void k_any_tridiag_reg(double* __restrict
                 pk[c2] = t * (((cpart[i] + cpart[NP + i]) + cpart[2 * NP + i]) + cpart[3 * NP + i]);
                 s2 = fma(pk[c2], vk[c2], s2);
             }
-            const double K = (0.5 * t) * wave_sum(s2);
+            const double K = (0.5 * t) * wave_tree64(s2);
 #pragma unroll
             for (int c2 = 0; c2 < NC; c2++) wk[c2] = fma(-K, vk[c2], pk[c2]);
             if (tid == 0) { td[n + k] = alpha; td[2 * n + k] = t; }
         }
         const double wc = pick(wk, cc);
-        // rank-2 update, both products rounded and then added (k_init): v and w are zero up to index k
+        // rank-2 update as two fmas per element (fp64 vector instructions cost 8 cycles per wave here: the four-instruction
+        // commutative form of k_init doubled the kernel's dominant term).  Element (r, c) and its mirror image may now differ
+        // in the last bit; nothing here needs exact symmetry (parity of this path is by tolerance).  v, w are zero up to k.
 #pragma unroll
         for (int s = 0; s < NC; s++) {
             const int r0 = row0 + 16 * s;
@@ -442,8 +444,7 @@ __global__ __launch_bounds__(256 * NC) void k_any_tridiag_reg(double* __restrict
 #pragma unroll
             for (int jj = 0; jj < 16; jj++) {
                 const double vj = readlane_f64(sv, (r0 & 63) + jj), wj = readlane_f64(sw, (r0 & 63) + jj);
-                const double m1 = vj * wc, m2 = wj * vc;
-                Ar[s][jj] = Ar[s][jj] - (m1 + m2);
+                Ar[s][jj] = fma(-vj, wc, fma(-wj, vc, Ar[s][jj]));
             }
         }
     }
