@@ -21,10 +21,16 @@ __global__ __launch_bounds__(256) void k_patchify_rgb(const uint8_t* __restrict_
         const int c = rem >> 4, a = (rem >> 1) & 7, b4 = (rem & 1) * 4;
         const int y = reflect_idx(hh * 8 + a - top, H);
         f32x4 out;
+        const int x0 = ww * 8 + b4 - left;
+        const uint8_t* rowp = img + (long)c * H * W + (long)y * W;
+        if (x0 >= 0 && x0 + 3 < W) { // no reflection inside these four pixels: one (unaligned) word instead of four byte loads
+            typedef uint32_t __attribute__((aligned(1))) u32u;
+            const uint32_t w4 = *reinterpret_cast<const u32u*>(rowp + x0);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            int x = reflect_idx(ww * 8 + b4 + i - left, W);
-            out[i] = (float)img[(long)c * H * W + (long)y * W + x];
+            for (int i = 0; i < 4; i++) out[i] = (float)((w4 >> (8 * i)) & 255u);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) out[i] = (float)rowp[reflect_idx(x0 + i, W)];
         }
         *reinterpret_cast<f32x4*>(Xp + ww * 192 + c * 64 + a * 8 + b4) = out;
     }
