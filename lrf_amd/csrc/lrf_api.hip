@@ -659,7 +659,8 @@ int lrf_qmf_planes_from_rgb_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_
     LRF_ON_DEVICE(c);
     Prof p(c, LRF_K_PLANES);
     if ((long)H * W * 3 >= (1L << 31)) return set_err(LRF_ENOTSUP, "image too large for 32-bit pixel indexing");
-    if (H % 16 == 0 && W % 16 == 0 && (reinterpret_cast<uintptr_t>(rgb) & 7) == 0)
+    static const bool no_tiled = getenv("LRF_PLANES_NO_TILED") && getenv("LRF_PLANES_NO_TILED")[0] == '1'; // developer comparison aid
+    if (H % 16 == 0 && W % 16 == 0 && (reinterpret_cast<uintptr_t>(rgb) & 7) == 0 && !no_tiled)
         hipLaunchKernelGGL(k_planes16, dim3((unsigned)((H / 16) * ((g.p[0].nw + 31) / 32)), (unsigned)B), dim3(256), 0, c->stream, rgb, (int)H,
                            (int)W, g, X);
     else
