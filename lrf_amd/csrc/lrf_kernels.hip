@@ -1464,7 +1464,6 @@ __global__ __launch_bounds__(256) void k_decode8(const int8_t* __restrict__ U, c
     if (o >= (long)H * w4) return;
     int y = (int)(o / w4), x0 = (int)(o - (long)y * w4) * 4;
     uint8_t* out = rgb + (long)blockIdx.y * 3 * H * W;
-    const float T[3][3] = {{1.0f, 0.0f, 1.402f}, {1.0f, -0.344136f, -0.714136f}, {1.0f, 1.772f, 0.0f}};
     float sh = (float)g.p[1].h / (float)H, sw = (float)g.p[1].w / (float)W;
     int sy = (int)floorf((float)y * sh);
     if (sy > g.p[1].h - 1) sy = g.p[1].h - 1;
@@ -1484,25 +1483,25 @@ __global__ __launch_bounds__(256) void k_decode8(const int8_t* __restrict__ U, c
     };
     uint32_t packed[3] = {0u, 0u, 0u};
     const int yyl = y + g.p[0].top_crop, yyc = sy + g.p[1].top_crop;
+    int psx = -1;
+    float c1 = 0.f, c2 = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         int x = x0 + i;
         if (x >= W) break;
         int sx = (int)floorf((float)x * sw);
         if (sx > g.p[1].w - 1) sx = g.p[1].w - 1;
-        float c[3];
-        c[0] = recon(0, yyl, x + g.p[0].left_crop) + 0.f;
-        c[1] = recon(1, yyc, sx + g.p[1].left_crop) + -128.f;
-        c[2] = recon(2, yyc, sx + g.p[2].left_crop) + -128.f;
-#pragma unroll
-        for (int ch = 0; ch < 3; ch++) {
-            float acc = 0.f;
-            acc = fmaf(T[ch][0], c[0], acc);
-            acc = fmaf(T[ch][1], c[1], acc);
-            acc = fmaf(T[ch][2], c[2], acc);
-            acc = fminf(fmaxf(acc, 0.f), 255.f);
-            packed[ch] |= (uint32_t)(uint8_t)acc << (8 * i); // truncation (to_dtype)
+        const float c0 = recon(0, yyl, x + g.p[0].left_crop) + 0.f;
+        if (sx != psx) { // neighbouring pixels mostly share their chroma sample
+            psx = sx;
+            c1 = recon(1, yyc, sx + g.p[1].left_crop) + -128.f;
+            c2 = recon(2, yyc, sx + g.p[2].left_crop) + -128.f;
         }
+        // the colour chain of k_decode (k-ordered fmas from 0) without the steps that cannot change a bit for finite values:
+        // fma(1, c0, 0) = c0, fma(0, c, acc) = acc; clamp + truncation as one v_med3 + conversion
+        const float chv[3] = {fmaf(1.402f, c2, c0), fmaf(-0.714136f, c2, fmaf(-0.344136f, c1, c0)), fmaf(1.772f, c1, c0)};
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) packed[ch] |= (uint32_t)__builtin_amdgcn_fmed3f(chv[ch], 0.f, 255.f) << (8 * i);
     }
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {
