@@ -1093,22 +1093,32 @@ __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, 
                 const int i = lane + 64 * e;
                 x[w][e] = (g0 + w < Rc && i < n) ? Z[(long)(g0 + w) * n + i] : 0.0;
             }
-        for (int k = n - 3; k >= 0; k--) {
-            const double tk = Ltau[k];
-            if (tk == 0.0) continue;
-            const double* Ak = A + (long)k * n;
-            double v[NE];
+        // the reflector of step k - 1 is requested (global memory, L2) before step k is computed; the dot products reduce
+        // through the DPP / permlane tree of k_init (wave_tree64), not the LDS crossbar
+        double vn[NE];
+        auto load_v = [&](int k, double (&v)[NE]) __attribute__((always_inline)) {
+            const double* Ak = A + (long)(k > 0 ? k : 0) * n;
 #pragma unroll
             for (int e = 0; e < NE; e++) {
                 const int i = lane + 64 * e;
-                v[e] = (i < n && i > k) ? Ak[i] : 0.0;
+                v[e] = (k >= 0 && i < n && i > k) ? Ak[i] : 0.0;
             }
+        };
+        load_v(n - 3, vn);
+        for (int k = n - 3; k >= 0; k--) {
+            double v[NE];
+#pragma unroll
+            for (int e = 0; e < NE; e++) v[e] = vn[e];
+            load_v(k - 1, vn);
+            const double tk = Ltau[k];
+            if (tk == 0.0) continue;
 #pragma unroll
             for (int w = 0; w < CW; w++) {
+                if (g0 + w >= Rc) continue; // wave-uniform
                 double dsum = 0.0;
 #pragma unroll
                 for (int e = 0; e < NE; e++) dsum = fma(v[e], x[w][e], dsum);
-                const double sc = tk * wave_sum(dsum);
+                const double sc = tk * wave_tree64(dsum);
 #pragma unroll
                 for (int e = 0; e < NE; e++) x[w][e] = fma(-sc, v[e], x[w][e]);
             }
