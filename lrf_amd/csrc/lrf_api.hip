@@ -369,6 +369,28 @@ static int run_bprep(lrf_ctx* c, int nplanes, int rp)
     return LRF_OK;
 }
 
+// A run: consecutive planes (and their blocks) of one kernel family.  In a table whose ranks are all <= 16 the planes of rank
+// <= 8 iterate on k_bcd_w and the others on k_bcd<., 16> (ranks (16, 8, 8): the chroma third of the rows runs twice as fast);
+// the planes of the fused encode are ordered by channel, so a call has at most three runs.
+struct FamRun {
+    int plane0, nplanes, block0, nblocks, rmax;
+    bool small; // every rank <= 8
+};
+static std::vector<FamRun> family_runs(const Tables& t, bool split)
+{
+    std::vector<FamRun> runs;
+    for (int p = 0; p < (int)t.planes.size(); p++) {
+        const PlaneDesc& pd = t.planes[p];
+        const bool small = split ? pd.R <= 8 : false;
+        if (runs.empty() || (split && runs.back().small != small)) runs.push_back(FamRun{p, 0, pd.blk0, 0, 1, small});
+        FamRun& r = runs.back();
+        r.nplanes++;
+        r.nblocks += pd.nblk;
+        r.rmax = pd.R > r.rmax ? pd.R : r.rmax;
+    }
+    return runs;
+}
+
 // mode: 1 = old U from X @ W0 (after run_init), 2 = old U from caller's fp32 U0
 static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, int hi, int first_mode, const float* U0,
                    int8_t* U, int8_t* V)
@@ -411,17 +433,22 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
     const long mx_b = abs(lo) > abs(hi) ? abs(lo) : abs(hi);
     static const bool exact_off = getenv("LRF_GENERIC_GS") && getenv("LRF_GENERIC_GS")[0] == '1'; // developer comparison aid
     gp.exact_int = (!exact_off && (long)(rmax - 1) * 64 * mx_b * mx_b * mx_b < (1L << 24)) ? 1 : 0;
+    // k_bcd_w has no workgroup-kernel twin switch per run: LRF_BCD_WG=1 sends every rank <= 16 plane to k_bcd
+    static const bool no_split = getenv("LRF_NO_FAMILY_SPLIT") && getenv("LRF_NO_FAMILY_SPLIT")[0] == '1'; // developer comparison aid
+    // the split pays once the launches are throughput-bound (256 x 512x768 at ranks (16,8,8): 4.05 -> 3.81 ms); small batches are
+    // latency chains per block and two launches in a row cost more than the faster kernel saves (64 images: 1.39 -> 1.51 ms)
+    const std::vector<FamRun> runs = family_runs(t, rp == 16 && wave_variant && !no_split && nb >= 3072);
     for (int it = 0; it < K; it++) {
         {
             Prof p(c, LRF_K_BCD);
             int mode = (it == 0) ? first_mode : 0;
-#define LRF_LAUNCH_BCD(MODE, RMAX)                                                                                   \
+#define LRF_LAUNCH_BCD(MODE, RMAX, B0, NB)                                                                           \
     do {                                                                                                             \
         if (wave_variant && RMAX == 8)                                                                               \
-            hipLaunchKernelGGL((k_bcd_w<MODE>), dim3((nb + LRF_BCDW_WAVES - 1) / LRF_BCDW_WAVES), dim3(64 * LRF_BCDW_WAVES), LRF_BCDW_LDS, c->stream, X, pl, bl, vf, wf, \
-                               bf, U0, U, pp, qp, gp, nb); \
+            hipLaunchKernelGGL((k_bcd_w<MODE>), dim3(((NB) + LRF_BCDW_WAVES - 1) / LRF_BCDW_WAVES), dim3(64 * LRF_BCDW_WAVES), LRF_BCDW_LDS, c->stream, X, pl, bl + (B0), vf, wf, \
+                               bf, U0, U, pp, qp, gpr, (NB)); \
         else                                                                                                         \
-            hipLaunchKernelGGL((k_bcd<MODE, RMAX>), dim3(nb), dim3(256), 0, c->stream, X, pl, bl, vf, wf, bf, U0, U, pp, qp, gp); \
+            hipLaunchKernelGGL((k_bcd<MODE, RMAX>), dim3(NB), dim3(256), 0, c->stream, X, pl, bl + (B0), vf, wf, bf, U0, U, pp, qp, gpr); \
     } while (0)
             // ranks 17..32: k_bcd_mid (lrf_midrank_kernels.hip)
 #define LRF_LAUNCH_MID(MODE)                                                                                         \
@@ -430,32 +457,44 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
                 if (mode == 1) LRF_LAUNCH_MID(1);
                 else if (mode == 2) LRF_LAUNCH_MID(2);
                 else LRF_LAUNCH_MID(0);
-            } else if (rmax <= 8) {
-                if (mode == 1) LRF_LAUNCH_BCD(1, 8);
-                else if (mode == 2) LRF_LAUNCH_BCD(2, 8);
-                else LRF_LAUNCH_BCD(0, 8);
+                LAUNCH_CHECK();
             } else {
-                if (mode == 1) LRF_LAUNCH_BCD(1, 16);
-                else if (mode == 2) LRF_LAUNCH_BCD(2, 16);
-                else LRF_LAUNCH_BCD(0, 16);
+                for (const FamRun& r : runs) {
+                    GsParams gpr = gp; // the exact-integer test per run: it depends on the largest rank of the planes it covers
+                    gpr.exact_int = (!exact_off && (long)(r.rmax - 1) * 64 * mx_b * mx_b * mx_b < (1L << 24)) ? 1 : 0;
+                    if (r.rmax <= 8) {
+                        if (mode == 1) LRF_LAUNCH_BCD(1, 8, r.block0, r.nblocks);
+                        else if (mode == 2) LRF_LAUNCH_BCD(2, 8, r.block0, r.nblocks);
+                        else LRF_LAUNCH_BCD(0, 8, r.block0, r.nblocks);
+                    } else {
+                        if (mode == 1) LRF_LAUNCH_BCD(1, 16, r.block0, r.nblocks);
+                        else if (mode == 2) LRF_LAUNCH_BCD(2, 16, r.block0, r.nblocks);
+                        else LRF_LAUNCH_BCD(0, 16, r.block0, r.nblocks);
+                    }
+                    LAUNCH_CHECK();
+                }
             }
 #undef LRF_LAUNCH_BCD
 #undef LRF_LAUNCH_MID
-            LAUNCH_CHECK();
         }
         {
             Prof p(c, LRF_K_VUPDATE);
             int last = it == K - 1 ? 1 : 0;
-            if (rp != 16)
+            if (rp != 16) {
                 hipLaunchKernelGGL(k_vupdate_mid, dim3(np), dim3(256), sizeof(BigVLds), c->stream, pl, (const float*)pp,
                                    (const float*)qp, vf, bf, V, gp.lo, gp.hi, last);
-            else if (rmax <= 8)
-                hipLaunchKernelGGL(k_vupdate<8>, dim3(np), dim3(256), 0, c->stream, pl, (const float*)pp, (const float*)qp, vf, bf,
-                                   V, gp, last);
-            else
-                hipLaunchKernelGGL(k_vupdate<16>, dim3(np), dim3(256), 0, c->stream, pl, (const float*)pp, (const float*)qp, vf,
-                                   bf, V, gp, last);
-            LAUNCH_CHECK();
+                LAUNCH_CHECK();
+            } else {
+                for (const FamRun& r : runs) {
+                    if (r.rmax <= 8)
+                        hipLaunchKernelGGL(k_vupdate<8>, dim3(r.nplanes), dim3(256), 0, c->stream, pl, (const float*)pp, (const float*)qp, vf,
+                                           bf, V, gp, last, r.plane0);
+                    else
+                        hipLaunchKernelGGL(k_vupdate<16>, dim3(r.nplanes), dim3(256), 0, c->stream, pl, (const float*)pp, (const float*)qp, vf,
+                                           bf, V, gp, last, r.plane0);
+                    LAUNCH_CHECK();
+                }
+            }
         }
     }
     return LRF_OK;

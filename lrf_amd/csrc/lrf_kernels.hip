@@ -1321,13 +1321,14 @@ template <int RMAX>
 __global__ __launch_bounds__(256) void k_vupdate(const PlaneDesc* __restrict__ planes, const float* __restrict__ Ppart,
                                                  const float* __restrict__ Qpart, float* __restrict__ Vf,
                                                  float* __restrict__ Bf, int8_t* __restrict__ V8, GsParams gp,
-                                                 int write_i8)
+                                                 int write_i8, int plane0 /* first plane of this launch's run */)
 {
+    const int pli = blockIdx.x + plane0;
     __shared__ __attribute__((aligned(16))) float gt_s[LRF_GT_STRIDE];
     __shared__ __attribute__((aligned(16))) float a_s[64 * LRF_RP];
     __shared__ __attribute__((aligned(16))) float v_s[64 * LRF_RP];
 
-    const PlaneDesc pd = planes[blockIdx.x];
+    const PlaneDesc pd = planes[pli];
     const int R = pd.R, tid = threadIdx.x;
     // a' = ((P0 + P1) + P2) + ... and b' likewise: all the partials of up to 16 blocks (4 elements of a' and one of b'
     // per thread) are requested before the first one is used — one exposed memory latency per 16 blocks — and then
@@ -1336,8 +1337,8 @@ __global__ __launch_bounds__(256) void k_vupdate(const PlaneDesc* __restrict__ p
     {
         const float* Pp = Ppart + (long)pd.blk0 * 64 * LRF_RP + tid;
         const float* Qp = Qpart + (long)pd.blk0 * LRF_RP * LRF_RP + tid;
-        const float vold[4] = {Vf[(long)blockIdx.x * 64 * LRF_RP + tid], Vf[(long)blockIdx.x * 64 * LRF_RP + 256 + tid],
-                               Vf[(long)blockIdx.x * 64 * LRF_RP + 512 + tid], Vf[(long)blockIdx.x * 64 * LRF_RP + 768 + tid]};
+        const float vold[4] = {Vf[(long)pli * 64 * LRF_RP + tid], Vf[(long)pli * 64 * LRF_RP + 256 + tid],
+                               Vf[(long)pli * 64 * LRF_RP + 512 + tid], Vf[(long)pli * 64 * LRF_RP + 768 + tid]};
         for (int b0 = 0; b0 < pd.nblk; b0 += 16) {
             float pv[4][16], qv[16];
 #pragma unroll
@@ -1379,7 +1380,7 @@ __global__ __launch_bounds__(256) void k_vupdate(const PlaneDesc* __restrict__ p
         bool native = (long)(R - 1) * 64 < 400;
         const float no_tab[17] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; // FROM_I8 = false: unused
         gs_dispatch<RMAX, false>(R, &a_s[tid * LRF_RP], &v_s[tid * LRF_RP], nullptr, 0, gt_s, native, gp, no_tab);
-        float* Vp = Vf + (long)blockIdx.x * 64 * LRF_RP + tid * LRF_RP;
+        float* Vp = Vf + (long)pli * 64 * LRF_RP + tid * LRF_RP;
         for (int r = 0; r < R; r++) Vp[r] = v_s[tid * LRF_RP + r];
         if (write_i8) {
             int8_t* vo = V8 + pd.v_off + (long)tid * R;
@@ -1387,7 +1388,7 @@ __global__ __launch_bounds__(256) void k_vupdate(const PlaneDesc* __restrict__ p
         }
     }
     __syncthreads();
-    if (!write_i8) make_gtable(v_s, 64, R, Bf + (long)blockIdx.x * LRF_GT_STRIDE, tid, 256);
+    if (!write_i8) make_gtable(v_s, 64, R, Bf + (long)pli * LRF_GT_STRIDE, tid, 256);
 }
 
 // loads caller-supplied fp32 V0 [B][64][R] into the padded Vf table (lrf_qmf_bcd_f32); rp = padded rank
