@@ -81,10 +81,17 @@ __global__ __launch_bounds__(256) void k_any_prod(const float* __restrict__ A, l
             // products to the accumulator one after the other in k order — the same chain of fmas as the scalar loop — and
             // entries past klen are zeros staged above (fma(0, 0, acc) = acc).
             const int steps = (klen + 3) >> 2;
-            for (int s4 = 0; s4 < steps; s4++) {
-                const float av = As[(4 * s4 + lq) * 65 + 16 * wave + li];
-                macc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Bs[(4 * s4 + lq) * 32 + li], macc[0], 0, 0, 0);
-                macc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Bs[(4 * s4 + lq) * 32 + 16 + li], macc[1], 0, 0, 0);
+            if (r0 + 16 < R) {
+                for (int s4 = 0; s4 < steps; s4++) {
+                    const float av = As[(4 * s4 + lq) * 65 + 16 * wave + li];
+                    macc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Bs[(4 * s4 + lq) * 32 + li], macc[0], 0, 0, 0);
+                    macc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Bs[(4 * s4 + lq) * 32 + 16 + li], macc[1], 0, 0, 0);
+                }
+            } else { // ranks up to 16 (in this rank tile): the second column tile is empty
+                for (int s4 = 0; s4 < steps; s4++) {
+                    const float av = As[(4 * s4 + lq) * 65 + 16 * wave + li];
+                    macc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Bs[(4 * s4 + lq) * 32 + li], macc[0], 0, 0, 0);
+                }
             }
         }
     }
