@@ -185,7 +185,7 @@ int lrf_qmf_decode_rgb_u8(lrf_ctx* ctx, const int8_t* U, const int8_t* V, int64_
 /*
  * svd_encode, default branch (color_space="RGB", patch 8x8, uint8 factors), everything between image.float() and the byte
  * container: pad_image(reflect) + patchify to X [M,192] (lrf/compression/svd.py:160-162), the top-R singular pairs
- * u = U sqrt(s), v = (sqrt(s) Vh)^T (:179-183; fp64 Gram + eigen-solve instead of LAPACK, tolerance-checked) and
+ * u = U sqrt(s), v = (sqrt(s) Vh)^T (:179-183; Gram matrix + eigen-solve instead of LAPACK, tolerance-checked) and
  * quantize(., uint8) of both (:185-187, lrf/compression/utils.py:185-220).
  *   U [B,M,R] uint8, V [B,192,R] uint8, qparams [B,4] float = (scale_u, min_u, scale_v, min_v), all device memory.
  *   sign optional [B,R] as in lrf_qmf_decompose_f32.

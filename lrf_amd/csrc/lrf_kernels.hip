@@ -7,7 +7,7 @@
 //
 // Reference code restated here (paths relative to the reference root):
 //   k_planes   lrf/compression/utils.py:24-47,76-95,108-132 + lrf/compression/qmf.py:43-56
-//   k_init     lrf/factorization/qmf.py:42-71 (SVDInit; LAPACK replaced by fp64 Gram + Jacobi)
+//   k_init     lrf/factorization/qmf.py:42-71 (SVDInit; LAPACK replaced by the exact Gram matrix + a tridiagonal eigen-solver)
 //   k_bcd      lrf/factorization/qmf.py:93-126 (update_u) + the a = x.mT @ u half of :128-139
 //   k_vupdate  lrf/factorization/qmf.py:128-139 (update_v), :191-195 (_project)
 //   k_decode   lrf/compression/qmf.py:329-351, lrf/compression/utils.py:50-73,98-105,135-182
@@ -261,11 +261,11 @@ __global__ __launch_bounds__(256) void k_planes16(const uint8_t* __restrict__ rg
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2: SVD initialisation = fp64 Gram (MFMA f64) + top-R eigen-pairs of the 64 x 64 Gram matrix
-// (Householder tridiagonalisation, 64-way multisection on Sturm counts, twisted factorisation,
-// Gram-Schmidt, back-transformation) + scaling to (v0, w0).  One workgroup (4 waves) per matrix.
-// Mirrors oracle/lrf_oracle.c (gram_f64, tridiagonalize, top_eigenvalues, twisted_vector,
-// lrf_oracle_top_eig_f64, init_from_gram) operation for operation.
+// K2: SVD initialisation = the exact Gram matrix (k_gram64, lrf_gram_kernels.hip: 128-bit partials per row chunk, added
+// here) + top-R eigen-pairs of the 64 x 64 Gram matrix (Householder tridiagonalisation, 64-way multisection on
+// division-free Sturm counts, twisted factorisation, Gram-Schmidt, back-transformation) + scaling to (v0, w0).
+// One workgroup (4 waves) per matrix.  Mirrors oracle/lrf_oracle.c (lrf_oracle_gram_exact, tridiagonalize, sturm_count,
+// top_eigenvalues, twisted_vector, lrf_oracle_top_eig_f64, init_from_gram) operation for operation.
 // ------------------------------------------------------------------------------------------------
 // tree64 of the oracle: lane i ends with s[i] + s[i+off] for off = 32..1; lane 0 holds the result,
 // which is broadcast.  (Lanes >= off compute unused values.)

@@ -2,7 +2,8 @@
 //
 // Reference: lrf/compression/svd.py:156-193 (encode), :310-326 (decode), lrf/compression/utils.py:185-243
 // (quantize / dequantize).  X is [M, 192] (three 8x8 colour patches per row), so the 64-wide kernels of the QMF
-// path do not apply; the top-R singular pairs come from the fp64 Gram matrix (192 x 192, k_gram_blk below) through the
+// path do not apply; the top-R singular pairs come from the Gram matrix (192 x 192: exact on the int8 matrix cores for the
+// uint8-valued matrices, k_gram192_u8, or fp64, k_gram_blk below) through the
 // eigen-solver of the any-shape path (k_any_eig<1>, lrf_anyshape_kernels.hip: Householder tridiagonalisation, multisection,
 // twisted factorisation, Gram-Schmidt, back-transformation) and its ordered product (k_any_prod) for u = X w.  Parity for
 // this path is by tolerance.
