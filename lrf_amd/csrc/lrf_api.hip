@@ -82,6 +82,7 @@ struct lrf_ctx {
     DevBuf gpart, gexp; // exact Gram partials (128-bit integers per chunk) and per-matrix grid exponents (lrf_gram_kernels.hip)
     DevBuf sx, sg, svn, swn, suf, smm; // SVD baseline workspace
     DevBuf any_uf, any_vf, any_a, any_b, any_p, any_e2, any_g, any_td; // any-shape path (lrf_anyshape_host.inc)
+    DevBuf vf16, wf16, bf16, pp16, qp16; // the pitch-16 tables of a call that mixes kernel families (plan_runs)
     // host staging for descriptor tables (pinned)
     void* h_stage = nullptr;
     size_t h_stage_cap = 0;
@@ -271,6 +272,56 @@ static int table_rmax(const Tables& t)
 }
 static int table_rp(const Tables& t) { return table_rmax(t) <= 16 ? 16 : LRF_RPB; }
 
+// ---- kernel families of a call -----------------------------------------------------------------
+// A run: consecutive planes (and their blocks) that iterate on one kernel family — 0: rank <= 8 (k_bcd_w), 1: rank <= 16
+// (k_bcd<., 16>), 2: rank <= 32 (k_bcd_mid) — with that family's table pitch (16 or LRF_RPB).  A small call takes ONE family,
+// the one its largest rank needs: its launches are latency chains per block and a second launch per iteration costs more than
+// a faster kernel saves (64 x 512x768 at (16,8,8): 1.39 -> 1.51 ms).  From 3072 blocks on (128 Kodak-sized images) every plane
+// goes to its own family (256 images: (16,8,8) 4.05 -> 3.78 ms, (20,10,10) 7.07 -> see DESIGN.md); the planes of the fused
+// encode are ordered by channel, so that is at most three runs.  Pitch-16 runs of a call whose table pitch is LRF_RPB use
+// the second table set (vf16 ...): the regions of the two pitches would overlap in one buffer.
+struct FamRun {
+    int plane0, nplanes, block0, nblocks, rmax, fam, pitch;
+};
+static int fam_of_rank(int R) { return R <= 8 ? 0 : (R <= 16 ? 1 : 2); }
+static bool bcd_wave_variant()
+{
+    static const bool v = !(getenv("LRF_BCD_WG") && getenv("LRF_BCD_WG")[0] == '1'); // LRF_BCD_WG=1: k_bcd instead of k_bcd_w
+    return v;
+}
+static std::vector<FamRun> plan_runs(const Tables& t)
+{
+    static const bool no_split = getenv("LRF_NO_FAMILY_SPLIT") && getenv("LRF_NO_FAMILY_SPLIT")[0] == '1'; // developer comparison aid
+    const int rmax_t = table_rmax(t);
+    const bool split = !no_split && bcd_wave_variant() && rmax_t <= LRF_BIG_TO_ANY_RANK && t.blocks.size() >= 3072;
+    std::vector<FamRun> runs;
+    for (int p = 0; p < (int)t.planes.size(); p++) {
+        const PlaneDesc& pd = t.planes[p];
+        const int fam = split ? fam_of_rank(pd.R) : (rmax_t > 16 ? 2 : fam_of_rank(rmax_t));
+        if (runs.empty() || runs.back().fam != fam) runs.push_back(FamRun{p, 0, pd.blk0, 0, 1, fam, fam == 2 ? LRF_RPB : 16});
+        FamRun& r = runs.back();
+        r.nplanes++;
+        r.nblocks += pd.nblk;
+        r.rmax = pd.R > r.rmax ? pd.R : r.rmax;
+    }
+    return runs;
+}
+static bool plan_is_mixed(const std::vector<FamRun>& runs)
+{
+    bool p16 = false, p64 = false;
+    for (const FamRun& r : runs) (r.pitch == 16 ? p16 : p64) = true;
+    return p16 && p64;
+}
+// the V / W / b / partial tables a run uses
+struct FamBufs {
+    float *vf, *wf, *bf, *pp, *qp;
+};
+static FamBufs run_bufs(lrf_ctx* c, const FamRun& r, bool mixed)
+{
+    if (mixed && r.pitch == 16) return FamBufs{(float*)c->vf16.p, (float*)c->wf16.p, (float*)c->bf16.p, (float*)c->pp16.p, (float*)c->qp16.p};
+    return FamBufs{(float*)c->vf.p, (float*)c->wf.p, (float*)c->bf.p, (float*)c->ppart.p, (float*)c->qpart.p};
+}
+
 static int upload_tables(lrf_ctx* c, const Tables& t)
 {
     // the tables only depend on the call's geometry: skip the (synchronising) upload when nothing changed
@@ -301,6 +352,13 @@ static int upload_tables(lrf_ctx* c, const Tables& t)
     if ((rc = ensure(c, c->bf, np * gts * sizeof(float)))) return rc;
     if ((rc = ensure(c, c->ppart, nb * 64 * rp * sizeof(float)))) return rc;
     if ((rc = ensure(c, c->qpart, nb * rp * rp * sizeof(float)))) return rc;
+    if (plan_is_mixed(plan_runs(t))) {
+        if ((rc = ensure(c, c->vf16, np * 64 * 16 * sizeof(float)))) return rc;
+        if ((rc = ensure(c, c->wf16, np * 64 * 16 * sizeof(float)))) return rc;
+        if ((rc = ensure(c, c->bf16, np * (size_t)LRF_GT_STRIDE * sizeof(float)))) return rc;
+        if ((rc = ensure(c, c->pp16, nb * 64 * 16 * sizeof(float)))) return rc;
+        if ((rc = ensure(c, c->qp16, nb * 16 * 16 * sizeof(float)))) return rc;
+    }
     c->table_key.swap(key);
     return LRF_OK;
 }
@@ -333,15 +391,22 @@ static int run_init(lrf_ctx* c, const float* X, const Tables& t, const int8_t* s
         LAUNCH_CHECK();
     }
     Prof p(c, LRF_K_INIT);
+    const std::vector<FamRun> runs = plan_runs(t);
+    const bool mixed = plan_is_mixed(runs);
+    for (const FamRun& r : runs) {
+        const FamBufs fb = run_bufs(c, r, mixed);
 #define LRF_LAUNCH_INIT(ZR)                                                                                          \
-    hipLaunchKernelGGL(k_init<ZR>, dim3(nplanes), dim3(256), sizeof(InitLds<ZR>), c->stream, (const ulonglong2*)c->gpart.p, \
-                       (const int*)c->gexp.p, gram_exp, (const PlaneDesc*)c->planes.p, sign_dev, (float*)c->vf.p, (float*)c->wf.p, \
-                       c->init_sweeps, rp)
-    if (rmax <= 8) LRF_LAUNCH_INIT(8);
-    else if (rmax <= 16) LRF_LAUNCH_INIT(16);
-    else LRF_LAUNCH_INIT(64);
+    hipLaunchKernelGGL(k_init<ZR>, dim3(r.nplanes), dim3(256), sizeof(InitLds<ZR>), c->stream, (const ulonglong2*)c->gpart.p, \
+                       (const int*)c->gexp.p, gram_exp, (const PlaneDesc*)c->planes.p, sign_dev, fb.vf, fb.wf, c->init_sweeps, r.pitch, r.plane0)
+        if (r.rmax <= 8) LRF_LAUNCH_INIT(8);
+        else if (r.rmax <= 16) LRF_LAUNCH_INIT(16);
+        else LRF_LAUNCH_INIT(64);
 #undef LRF_LAUNCH_INIT
-    LAUNCH_CHECK();
+        LAUNCH_CHECK();
+    }
+    (void)rmax;
+    (void)rp;
+    (void)nplanes;
     return LRF_OK;
 }
 
@@ -357,143 +422,101 @@ static GsParams make_gs(int lo, int hi)
     return gp;
 }
 
-static int run_bprep(lrf_ctx* c, int nplanes, int rp)
-{
-    if (rp == 16)
-        hipLaunchKernelGGL(k_bprep, dim3(nplanes), dim3(256), 0, c->stream, (const PlaneDesc*)c->planes.p, (const float*)c->vf.p,
-                           (float*)c->bf.p);
-    else
-        hipLaunchKernelGGL(k_bprep_big, dim3(nplanes), dim3(256), 0, c->stream, (const PlaneDesc*)c->planes.p,
-                           (const float*)c->vf.p, (float*)c->bf.p);
-    LAUNCH_CHECK();
-    return LRF_OK;
-}
-
-// A run: consecutive planes (and their blocks) of one kernel family.  In a table whose ranks are all <= 16 the planes of rank
-// <= 8 iterate on k_bcd_w and the others on k_bcd<., 16> (ranks (16, 8, 8): the chroma third of the rows runs twice as fast);
-// the planes of the fused encode are ordered by channel, so a call has at most three runs.
-struct FamRun {
-    int plane0, nplanes, block0, nblocks, rmax;
-    bool small; // every rank <= 8
-};
-static std::vector<FamRun> family_runs(const Tables& t, bool split)
-{
-    std::vector<FamRun> runs;
-    for (int p = 0; p < (int)t.planes.size(); p++) {
-        const PlaneDesc& pd = t.planes[p];
-        const bool small = split ? pd.R <= 8 : false;
-        if (runs.empty() || (split && runs.back().small != small)) runs.push_back(FamRun{p, 0, pd.blk0, 0, 1, small});
-        FamRun& r = runs.back();
-        r.nplanes++;
-        r.nblocks += pd.nblk;
-        r.rmax = pd.R > r.rmax ? pd.R : r.rmax;
-    }
-    return runs;
-}
-
 // mode: 1 = old U from X @ W0 (after run_init), 2 = old U from caller's fp32 U0
 static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, int hi, int first_mode, const float* U0,
                    int8_t* U, int8_t* V)
 {
     const PlaneDesc* pl = (const PlaneDesc*)c->planes.p;
     const BlockDesc* bl = (const BlockDesc*)c->blocks.p;
-    float* vf = (float*)c->vf.p;
-    float* wf = (float*)c->wf.p;
-    float* bf = (float*)c->bf.p;
-    float* pp = (float*)c->ppart.p;
-    float* qp = (float*)c->qpart.p;
-    int nb = (int)t.blocks.size(), np = (int)t.planes.size();
     GsParams gp = make_gs(lo, hi);
-    int rmax = table_rmax(t), rp = table_rp(t);
-    int rc = run_bprep(c, np, rp);
-    if (rc) return rc;
-    {
-        if (!(c->attr_done & (1u << 1))) {
-            HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_w<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LRF_BCDW_LDS));
-            HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_w<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LRF_BCDW_LDS));
-            HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_w<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LRF_BCDW_LDS));
-            c->attr_done |= 1u << 1;
-        }
+    if (table_rmax(t) > LRF_BIG_TO_ANY_RANK) return set_err(LRF_ENOTSUP, "internal: ranks above %d iterate on the any-shape kernels", LRF_BIG_TO_ANY_RANK);
+    const std::vector<FamRun> runs = plan_runs(t);
+    const bool mixed = plan_is_mixed(runs);
+    const bool wave_variant = bcd_wave_variant(); // k_bcd_w (one wave per block, no barriers) for rank <= 8 runs
+    if (!(c->attr_done & (1u << 1))) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_w<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LRF_BCDW_LDS));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_w<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LRF_BCDW_LDS));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_w<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LRF_BCDW_LDS));
+        c->attr_done |= 1u << 1;
     }
-    if (rp != 16) {
-        if (!(c->attr_done & (1u << 2))) {
-            HIP_TRY(hipFuncSetAttribute((const void*)k_vupdate_mid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BigVLds)));
-            HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_mid<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MidLds<0>)));
-            HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_mid<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MidLds<1>)));
-            HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_mid<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MidLds<2>)));
-            c->attr_done |= 1u << 2;
-        }
+    if (!(c->attr_done & (1u << 2))) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_vupdate_mid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BigVLds)));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_mid<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MidLds<0>)));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_mid<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MidLds<1>)));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_mid<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MidLds<2>)));
+        c->attr_done |= 1u << 2;
     }
-    // k_bcd_w (one wave per block, no barriers) is the default; LRF_BCD_WG=1 selects the 4-wave workgroup kernel k_bcd
-    static const bool wave_variant = !(getenv("LRF_BCD_WG") && getenv("LRF_BCD_WG")[0] == '1');
-    if (rmax > LRF_BIG_TO_ANY_RANK) return set_err(LRF_ENOTSUP, "internal: ranks above %d iterate on the any-shape kernels", LRF_BIG_TO_ANY_RANK);
+    // the b tables of the initial V
+    for (const FamRun& r : runs) {
+        const FamBufs fb = run_bufs(c, r, mixed);
+        if (r.pitch == 16)
+            hipLaunchKernelGGL(k_bprep, dim3(r.nplanes), dim3(256), 0, c->stream, pl, (const float*)fb.vf, fb.bf, r.plane0);
+        else
+            hipLaunchKernelGGL(k_bprep_big, dim3(r.nplanes), dim3(256), 0, c->stream, pl, (const float*)fb.vf, fb.bf, r.plane0);
+        LAUNCH_CHECK();
+    }
     // Iterations >= 2 with bounds where every term and partial sum of `uu @ bb` is an exact integer in fp32 for the largest
-    // rank of the call ((R - 1) 64 mx^3 < 2^24): the order of that sum is immaterial, which lets ranks 9..16 (gs_row_lds) and
+    // rank of a run ((R - 1) 64 mx^3 < 2^24): the order of that sum is immaterial, which lets ranks 9..16 (gs_row_lds) and
     // 17..32 (k_bcd_mid) replace the reference's dependent chain by independent fmas, bit for bit
     const long mx_b = abs(lo) > abs(hi) ? abs(lo) : abs(hi);
     static const bool exact_off = getenv("LRF_GENERIC_GS") && getenv("LRF_GENERIC_GS")[0] == '1'; // developer comparison aid
-    gp.exact_int = (!exact_off && (long)(rmax - 1) * 64 * mx_b * mx_b * mx_b < (1L << 24)) ? 1 : 0;
-    // k_bcd_w has no workgroup-kernel twin switch per run: LRF_BCD_WG=1 sends every rank <= 16 plane to k_bcd
-    static const bool no_split = getenv("LRF_NO_FAMILY_SPLIT") && getenv("LRF_NO_FAMILY_SPLIT")[0] == '1'; // developer comparison aid
-    // the split pays once the launches are throughput-bound (256 x 512x768 at ranks (16,8,8): 4.05 -> 3.81 ms); small batches are
-    // latency chains per block and two launches in a row cost more than the faster kernel saves (64 images: 1.39 -> 1.51 ms)
-    const std::vector<FamRun> runs = family_runs(t, rp == 16 && wave_variant && !no_split && nb >= 3072);
     for (int it = 0; it < K; it++) {
         {
             Prof p(c, LRF_K_BCD);
-            int mode = (it == 0) ? first_mode : 0;
-#define LRF_LAUNCH_BCD(MODE, RMAX, B0, NB)                                                                           \
-    do {                                                                                                             \
-        if (wave_variant && RMAX == 8)                                                                               \
-            hipLaunchKernelGGL((k_bcd_w<MODE>), dim3(((NB) + LRF_BCDW_WAVES - 1) / LRF_BCDW_WAVES), dim3(64 * LRF_BCDW_WAVES), LRF_BCDW_LDS, c->stream, X, pl, bl + (B0), vf, wf, \
-                               bf, U0, U, pp, qp, gpr, (NB)); \
-        else                                                                                                         \
-            hipLaunchKernelGGL((k_bcd<MODE, RMAX>), dim3(NB), dim3(256), 0, c->stream, X, pl, bl + (B0), vf, wf, bf, U0, U, pp, qp, gpr); \
-    } while (0)
-            // ranks 17..32: k_bcd_mid (lrf_midrank_kernels.hip)
+            const int mode = (it == 0) ? first_mode : 0;
+            for (const FamRun& r : runs) {
+                const FamBufs fb = run_bufs(c, r, mixed);
+                const BlockDesc* blr = bl + r.block0;
+                const int nbr = r.nblocks;
+                GsParams gpr = gp;
+                gpr.exact_int = (!exact_off && (long)(r.rmax - 1) * 64 * mx_b * mx_b * mx_b < (1L << 24)) ? 1 : 0;
+#define LRF_LAUNCH_W(MODE)                                                                                           \
+    hipLaunchKernelGGL((k_bcd_w<MODE>), dim3((nbr + LRF_BCDW_WAVES - 1) / LRF_BCDW_WAVES), dim3(64 * LRF_BCDW_WAVES), LRF_BCDW_LDS, c->stream, X, pl, blr, \
+                       (const float*)fb.vf, (const float*)fb.wf, (const float*)fb.bf, U0, U, fb.pp, fb.qp, gpr, nbr)
+#define LRF_LAUNCH_WG(MODE, RMAX)                                                                                    \
+    hipLaunchKernelGGL((k_bcd<MODE, RMAX>), dim3(nbr), dim3(256), 0, c->stream, X, pl, blr, (const float*)fb.vf, (const float*)fb.wf, \
+                       (const float*)fb.bf, U0, U, fb.pp, fb.qp, gpr)
 #define LRF_LAUNCH_MID(MODE)                                                                                         \
-    hipLaunchKernelGGL((k_bcd_mid<MODE>), dim3(nb), dim3(256), sizeof(MidLds<MODE>), c->stream, X, pl, bl, vf, wf, bf, U0, U, pp, qp, gp)
-            if (rp != 16) {
-                if (mode == 1) LRF_LAUNCH_MID(1);
-                else if (mode == 2) LRF_LAUNCH_MID(2);
-                else LRF_LAUNCH_MID(0);
-                LAUNCH_CHECK();
-            } else {
-                for (const FamRun& r : runs) {
-                    GsParams gpr = gp; // the exact-integer test per run: it depends on the largest rank of the planes it covers
-                    gpr.exact_int = (!exact_off && (long)(r.rmax - 1) * 64 * mx_b * mx_b * mx_b < (1L << 24)) ? 1 : 0;
-                    if (r.rmax <= 8) {
-                        if (mode == 1) LRF_LAUNCH_BCD(1, 8, r.block0, r.nblocks);
-                        else if (mode == 2) LRF_LAUNCH_BCD(2, 8, r.block0, r.nblocks);
-                        else LRF_LAUNCH_BCD(0, 8, r.block0, r.nblocks);
-                    } else {
-                        if (mode == 1) LRF_LAUNCH_BCD(1, 16, r.block0, r.nblocks);
-                        else if (mode == 2) LRF_LAUNCH_BCD(2, 16, r.block0, r.nblocks);
-                        else LRF_LAUNCH_BCD(0, 16, r.block0, r.nblocks);
-                    }
-                    LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_bcd_mid<MODE>), dim3(nbr), dim3(256), sizeof(MidLds<MODE>), c->stream, X, pl, blr, (const float*)fb.vf, \
+                       (const float*)fb.wf, (const float*)fb.bf, U0, U, fb.pp, fb.qp, gpr)
+                if (r.fam == 2) {
+                    if (mode == 1) LRF_LAUNCH_MID(1);
+                    else if (mode == 2) LRF_LAUNCH_MID(2);
+                    else LRF_LAUNCH_MID(0);
+                } else if (r.fam == 0 && wave_variant) {
+                    if (mode == 1) LRF_LAUNCH_W(1);
+                    else if (mode == 2) LRF_LAUNCH_W(2);
+                    else LRF_LAUNCH_W(0);
+                } else if (r.fam == 0) {
+                    if (mode == 1) LRF_LAUNCH_WG(1, 8);
+                    else if (mode == 2) LRF_LAUNCH_WG(2, 8);
+                    else LRF_LAUNCH_WG(0, 8);
+                } else {
+                    if (mode == 1) LRF_LAUNCH_WG(1, 16);
+                    else if (mode == 2) LRF_LAUNCH_WG(2, 16);
+                    else LRF_LAUNCH_WG(0, 16);
                 }
-            }
-#undef LRF_LAUNCH_BCD
+#undef LRF_LAUNCH_W
+#undef LRF_LAUNCH_WG
 #undef LRF_LAUNCH_MID
+                LAUNCH_CHECK();
+            }
         }
         {
             Prof p(c, LRF_K_VUPDATE);
-            int last = it == K - 1 ? 1 : 0;
-            if (rp != 16) {
-                hipLaunchKernelGGL(k_vupdate_mid, dim3(np), dim3(256), sizeof(BigVLds), c->stream, pl, (const float*)pp,
-                                   (const float*)qp, vf, bf, V, gp.lo, gp.hi, last);
+            const int last = it == K - 1 ? 1 : 0;
+            for (const FamRun& r : runs) {
+                const FamBufs fb = run_bufs(c, r, mixed);
+                if (r.fam == 2)
+                    hipLaunchKernelGGL(k_vupdate_mid, dim3(r.nplanes), dim3(256), sizeof(BigVLds), c->stream, pl, (const float*)fb.pp,
+                                       (const float*)fb.qp, fb.vf, fb.bf, V, gp.lo, gp.hi, last, r.plane0);
+                else if (r.fam == 0)
+                    hipLaunchKernelGGL(k_vupdate<8>, dim3(r.nplanes), dim3(256), 0, c->stream, pl, (const float*)fb.pp, (const float*)fb.qp,
+                                       fb.vf, fb.bf, V, gp, last, r.plane0);
+                else
+                    hipLaunchKernelGGL(k_vupdate<16>, dim3(r.nplanes), dim3(256), 0, c->stream, pl, (const float*)fb.pp, (const float*)fb.qp,
+                                       fb.vf, fb.bf, V, gp, last, r.plane0);
                 LAUNCH_CHECK();
-            } else {
-                for (const FamRun& r : runs) {
-                    if (r.rmax <= 8)
-                        hipLaunchKernelGGL(k_vupdate<8>, dim3(r.nplanes), dim3(256), 0, c->stream, pl, (const float*)pp, (const float*)qp, vf,
-                                           bf, V, gp, last, r.plane0);
-                    else
-                        hipLaunchKernelGGL(k_vupdate<16>, dim3(r.nplanes), dim3(256), 0, c->stream, pl, (const float*)pp, (const float*)qp, vf,
-                                           bf, V, gp, last, r.plane0);
-                    LAUNCH_CHECK();
-                }
             }
         }
     }
@@ -547,7 +570,8 @@ void lrf_ctx_destroy(lrf_ctx* c)
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     DevBuf* bufs[] = {&c->planes_alt, &c->blocks_alt, &c->gchunks_alt, &c->gchunks, &c->gpart, &c->gexp, &c->planes, &c->blocks, &c->vf, &c->wf, &c->bf, &c->ppart, &c->qpart, &c->x, &c->sign,
                       &c->sx, &c->sg, &c->svn, &c->swn, &c->suf, &c->smm,
-                      &c->any_uf, &c->any_vf, &c->any_a, &c->any_b, &c->any_p, &c->any_e2, &c->any_g, &c->any_td};
+                      &c->any_uf, &c->any_vf, &c->any_a, &c->any_b, &c->any_p, &c->any_e2, &c->any_g, &c->any_td,
+                      &c->vf16, &c->wf16, &c->bf16, &c->pp16, &c->qp16};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -587,7 +611,8 @@ size_t lrf_ctx_workspace_bytes(const lrf_ctx* c)
     if (!c) return 0;
     const DevBuf* bufs[] = {&c->planes_alt, &c->blocks_alt, &c->gchunks_alt, &c->gchunks, &c->gpart, &c->gexp, &c->planes, &c->blocks, &c->vf, &c->wf, &c->bf, &c->ppart, &c->qpart, &c->x, &c->sign,
                             &c->sx, &c->sg, &c->svn, &c->swn, &c->suf, &c->smm,
-                            &c->any_uf, &c->any_vf, &c->any_a, &c->any_b, &c->any_p, &c->any_e2, &c->any_g, &c->any_td};
+                            &c->any_uf, &c->any_vf, &c->any_a, &c->any_b, &c->any_p, &c->any_e2, &c->any_g, &c->any_td,
+                      &c->vf16, &c->wf16, &c->bf16, &c->pp16, &c->qp16};
     size_t total = 0;
     for (const DevBuf* b : bufs) total += b->cap;
     return total;
@@ -600,7 +625,8 @@ int lrf_ctx_trim(lrf_ctx* c)
     HIP_TRY(hipStreamSynchronize(c->stream));
     DevBuf* bufs[] = {&c->planes_alt, &c->blocks_alt, &c->gchunks_alt, &c->gchunks, &c->gpart, &c->gexp, &c->planes, &c->blocks, &c->vf,
                       &c->wf, &c->bf, &c->ppart, &c->qpart, &c->x, &c->sign, &c->sx, &c->sg, &c->svn, &c->swn, &c->suf, &c->smm,
-                      &c->any_uf, &c->any_vf, &c->any_a, &c->any_b, &c->any_p, &c->any_e2, &c->any_g, &c->any_td};
+                      &c->any_uf, &c->any_vf, &c->any_a, &c->any_b, &c->any_p, &c->any_e2, &c->any_g, &c->any_td,
+                      &c->vf16, &c->wf16, &c->bf16, &c->pp16, &c->qp16};
     for (DevBuf* b : bufs) {
         if (b->p) HIP_TRY(hipFree(b->p));
         b->p = nullptr;

@@ -74,12 +74,13 @@ __device__ __forceinline__ void make_gtable_big(const float* Vp, int depth, int 
 }
 
 __global__ __launch_bounds__(256) void k_bprep_big(const PlaneDesc* __restrict__ planes, const float* __restrict__ Vf,
-                                                   float* __restrict__ Bf)
+                                                   float* __restrict__ Bf, int plane0)
 {
     __shared__ float v_s[64 * LRF_RPB];
-    for (int i = threadIdx.x; i < 64 * LRF_RPB; i += 256) v_s[i] = Vf[(long)blockIdx.x * 64 * LRF_RPB + i];
+    const int pli = blockIdx.x + plane0;
+    for (int i = threadIdx.x; i < 64 * LRF_RPB; i += 256) v_s[i] = Vf[(long)pli * 64 * LRF_RPB + i];
     __syncthreads();
-    make_gtable_big(v_s, 64, planes[blockIdx.x].R, Bf + (long)blockIdx.x * LRF_GTB_STRIDE, threadIdx.x, 256);
+    make_gtable_big(v_s, 64, planes[pli].R, Bf + (long)pli * LRF_GTB_STRIDE, threadIdx.x, 256);
 }
 
 struct BigVLds {

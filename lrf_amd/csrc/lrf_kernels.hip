@@ -326,13 +326,14 @@ template <int ZR>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_init(const ulonglong2* __restrict__ Gpart, const int* __restrict__ gexp,
                                               int fixed_exp, const PlaneDesc* __restrict__ planes,
                                               const int8_t* __restrict__ sign, float* __restrict__ Vf,
-                                              float* __restrict__ Wf, int debug_stop, int rp)
+                                              float* __restrict__ Wf, int debug_stop, int rp, int plane0 /* first plane of this launch's run */)
 {
+    const int pli = blockIdx.x + plane0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     InitLds<ZR>& L = *reinterpret_cast<InitLds<ZR>*>(smem);
     double* G = L.A;
 
-    const PlaneDesc pd = planes[blockIdx.x];
+    const PlaneDesc pd = planes[pli];
     const int M = pd.M, R = pd.R;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     // ---- Gram matrix: the exact integer partials of k_gram64 (lrf_gram_kernels.hip), one per row chunk, are added as 128-bit
     // integers (order-free) and rounded once to fp64
     {
-        const int E = fixed_exp != LRF_GRAM_EXP_FROM_DATA ? fixed_exp : gexp[blockIdx.x];
+        const int E = fixed_exp != LRF_GRAM_EXP_FROM_DATA ? fixed_exp : gexp[pli];
         const double back = scalbn(1.0, 2 * (E - LRF_GRAM_BITS));
         const ulonglong2* gp = Gpart + (long)pd.gch0 * LRF_GRAM_SLOT;
         // chunk by chunk with the ten elements of a thread in flight together (one memory round trip per chunk, not per load)
@@ -706,8 +707,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     if (debug_stop == 5) return;
 
     // ---- back-transformation x <- H_0 ... H_61 x, sign, scaling, output: one wave per vector
-    float* Vp = Vf + (long)blockIdx.x * 64 * rp; // rp: padded rank (row pitch) of the V / W tables, a power of two
-    float* Wp = Wf + (long)blockIdx.x * 64 * rp;
+    float* Vp = Vf + (long)pli * 64 * rp; // rp: padded rank (row pitch) of the V / W tables, a power of two
+    float* Wp = Wf + (long)pli * 64 * rp;
     for (int i = tid; i < 64 * rp; i += 256) {
         if ((i & (rp - 1)) >= Rc) { Vp[i] = 0.f; Wp[i] = 0.f; } // padding and the r >= min(M,N) columns
     }
@@ -1022,12 +1023,13 @@ __device__ __forceinline__ void make_gtable(const float* Vp, int depth, int R, f
 
 // b table of the initial V (after k_init or k_load_v0): one workgroup per matrix
 __global__ __launch_bounds__(256) void k_bprep(const PlaneDesc* __restrict__ planes, const float* __restrict__ Vf,
-                                               float* __restrict__ Bf)
+                                               float* __restrict__ Bf, int plane0)
 {
     __shared__ float v_s[64 * LRF_RP];
-    for (int i = threadIdx.x; i < 64 * LRF_RP; i += 256) v_s[i] = Vf[(long)blockIdx.x * 64 * LRF_RP + i];
+    const int pli = blockIdx.x + plane0;
+    for (int i = threadIdx.x; i < 64 * LRF_RP; i += 256) v_s[i] = Vf[(long)pli * 64 * LRF_RP + i];
     __syncthreads();
-    make_gtable(v_s, 64, planes[blockIdx.x].R, Bf + (long)blockIdx.x * LRF_GT_STRIDE, threadIdx.x, 256);
+    make_gtable(v_s, 64, planes[pli].R, Bf + (long)pli * LRF_GT_STRIDE, threadIdx.x, 256);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -390,11 +390,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 __global__ __launch_bounds__(256) void k_vupdate_mid(const PlaneDesc* __restrict__ planes, const float* __restrict__ Ppart,
                                                      const float* __restrict__ Qpart, float* __restrict__ Vf,
                                                      float* __restrict__ Bf, int8_t* __restrict__ V8, float lo, float hi,
-                                                     int write_i8)
+                                                     int write_i8, int plane0)
 {
+    const int pli = blockIdx.x + plane0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     BigVLds& L = *reinterpret_cast<BigVLds*>(smem);
-    const PlaneDesc pd = planes[blockIdx.x];
+    const PlaneDesc pd = planes[pli];
     const int R = pd.R, tid = threadIdx.x;
     // a' = ((P0 + P1) + P2) + ... per element, b' likewise (block order); only the first 32 columns exist at these ranks
     // The eight elements of a thread advance together, eight blocks per round: 128 loads in flight per thread instead of 16
@@ -431,7 +432,7 @@ __global__ __launch_bounds__(256) void k_vupdate_mid(const PlaneDesc* __restrict
         for (int m = 0; m < NE; m++) {
             const int i2 = tid + 256 * m, i = (i2 >> 5) * LRF_RPB + (i2 & 31);
             L.a_s[i] = acc[m];
-            L.v_s[i] = Vf[(long)blockIdx.x * 64 * LRF_RPB + i];
+            L.v_s[i] = Vf[(long)pli * 64 * LRF_RPB + i];
             const int j = i2 >> 5, r = i2 & 31; // b' = U^T U entry (j, r)
             if (j < R && r < R) {
                 if (j == r) L.gt_s[r * LRF_GTB_LD + LRF_GTB_DEN] = (q[m] + 0.f) + LRF_EPS;
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(256) void k_vupdate_mid(const PlaneDesc* __restrict
             for (int i = 0; i < 4; i++) { a[j + i] = va4[i]; v[j + i] = vv4[i]; }
         }
         mid_ordered_row(R, a, v, L.gt_s, lo, hi, std::make_integer_sequence<int, 32>{}); // (R - 1) * 64 >= 400: never the native order
-        float* Vp = Vf + (long)blockIdx.x * 64 * LRF_RPB + tid * LRF_RPB;
+        float* Vp = Vf + (long)pli * 64 * LRF_RPB + tid * LRF_RPB;
         int8_t* vo = V8 + pd.v_off + (long)tid * R;
 #pragma unroll
         for (int r = 0; r < 32; r++)
@@ -461,5 +462,5 @@ __global__ __launch_bounds__(256) void k_vupdate_mid(const PlaneDesc* __restrict
             }
     }
     __syncthreads();
-    if (!write_i8) make_gtable_big(L.v_s, 64, R, Bf + (long)blockIdx.x * LRF_GTB_STRIDE, tid, 256);
+    if (!write_i8) make_gtable_big(L.v_s, 64, R, Bf + (long)pli * LRF_GTB_STRIDE, tid, 256);
 }

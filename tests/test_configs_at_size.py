@@ -136,17 +136,18 @@ def test_config5_svd_batch_256_images():
         assert abs(p1 - float(psnr[b])) < 0.02, (b, p1, float(psnr[b]))
 
 
-def test_mixed_rank_families_in_a_large_batch(oracle):
-    """Ranks (12, 6, 6) on 128 images of 512x768: the table is large enough (3072 blocks) for the per-family launches of
-    run_bcd — luma (rank 12) on k_bcd<., 16>, chroma (rank 6) on k_bcd_w.  A small batch of the same images takes one kernel
-    family for every plane: the factors must be the same bit for bit, and equal the oracle's on a sample."""
+@pytest.mark.parametrize("ranks", [(12, 6, 6), (20, 10, 10), (5, 18, 9)])
+def test_mixed_rank_families_in_a_large_batch(oracle, ranks):
+    """128 images of 512x768: the table is large enough (3072 blocks) for the per-family launches of run_init / run_bcd — e.g.
+    ranks (12, 6, 6): luma on k_bcd<., 16>, chroma on k_bcd_w; (20, 10, 10): luma on k_bcd_mid with the 64-wide tables, chroma
+    on k_bcd<., 16> with the second, 16-wide table set; (5, 18, 9): three runs.  A small batch of the same images takes one
+    kernel family for every plane: the factors must be the same bit for bit, and equal the oracle's on a sample."""
     import lrf_amd
     from lrf_amd.codec import split_factors
     g = torch.Generator().manual_seed(77)
     base = torch.rand(128, 3, 32, 48, generator=g) * 255
     imgs = (torch.nn.functional.interpolate(base, size=(512, 768), mode="bilinear", align_corners=False)
             + torch.randn(128, 3, 512, 768, generator=g) * 4).clamp(0, 255).to(torch.uint8)
-    ranks = (12, 6, 6)
     U, V = lrf_amd.qmf_factorize_batch(imgs.cuda(), ranks)
     Us, Vs = lrf_amd.qmf_factorize_batch(imgs[:3].cuda(), ranks)
     assert torch.equal(U[:3].cpu(), Us.cpu()) and torch.equal(V[:3].cpu(), Vs.cpu())
