@@ -293,7 +293,8 @@ static std::vector<FamRun> plan_runs(const Tables& t)
 {
     static const bool no_split = getenv("LRF_NO_FAMILY_SPLIT") && getenv("LRF_NO_FAMILY_SPLIT")[0] == '1'; // developer comparison aid
     const int rmax_t = table_rmax(t);
-    const bool split = !no_split && bcd_wave_variant() && rmax_t <= LRF_BIG_TO_ANY_RANK && t.blocks.size() >= 3072;
+    static const long min_blocks = getenv("LRF_FAMILY_SPLIT_BLOCKS") ? atol(getenv("LRF_FAMILY_SPLIT_BLOCKS")) : 3072; // developer aid
+    const bool split = !no_split && bcd_wave_variant() && rmax_t <= LRF_BIG_TO_ANY_RANK && (long)t.blocks.size() >= min_blocks;
     std::vector<FamRun> runs;
     for (int p = 0; p < (int)t.planes.size(); p++) {
         const PlaneDesc& pd = t.planes[p];
