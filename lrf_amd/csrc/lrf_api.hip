@@ -239,12 +239,8 @@ static void add_plane(Tables& t, long x_off, long u_off, long v_off, long u0_off
     pd.sign_off = sign_off;
     int pi = (int)t.planes.size();
     for (int b = 0; b < pd.nblk; b++) t.blocks.push_back(BlockDesc{pi, b * LRF_KC, b, 0});
-    pd.gch0 = (int)t.gchunks.size();
-    pd.ngch = (M + LRF_GRAM_ROWS - 1) / LRF_GRAM_ROWS;
-    for (int g = 0; g < pd.ngch; g++) {
-        const int row0 = g * LRF_GRAM_ROWS;
-        t.gchunks.push_back(GramChunk{pi, row0, pd.gch0 + g, M - row0 < LRF_GRAM_ROWS ? M - row0 : LRF_GRAM_ROWS});
-    }
+    pd.gch0 = 0; // the Gram chunks are cut when the table is complete (finish_gram_chunks)
+    pd.ngch = 0;
     t.planes.push_back(pd);
 }
 
@@ -323,8 +319,30 @@ static FamBufs run_bufs(lrf_ctx* c, const FamRun& r, bool mixed)
     return FamBufs{(float*)c->vf.p, (float*)c->wf.p, (float*)c->bf.p, (float*)c->ppart.p, (float*)c->qpart.p};
 }
 
-static int upload_tables(lrf_ctx* c, const Tables& t)
+// Row chunks of the exact Gram pass (k_gram64: one workgroup per chunk, one 128-bit partial per chunk for k_init to add):
+// LRF_GRAM_ROWS rows each — fewer for small calls, so that the pass still has a few workgroups per CU (a chunk is a latency
+// chain of 64-row blocks: one 512x768 image 38 -> 14 us, 64 images 57 -> 44 us).  Exact integer sums: the cut does not change a bit.
+static void finish_gram_chunks(Tables& t)
 {
+    long rows = 0;
+    for (const PlaneDesc& pd : t.planes) rows += pd.M;
+    int per = LRF_GRAM_ROWS;
+    while (per > 384 && rows / per < 768) per >>= 1;
+    t.gchunks.clear();
+    for (int pi = 0; pi < (int)t.planes.size(); pi++) {
+        PlaneDesc& pd = t.planes[pi];
+        pd.gch0 = (int)t.gchunks.size();
+        pd.ngch = (pd.M + per - 1) / per;
+        for (int g = 0; g < pd.ngch; g++) {
+            const int row0 = g * per;
+            t.gchunks.push_back(GramChunk{pi, row0, pd.gch0 + g, pd.M - row0 < per ? pd.M - row0 : per});
+        }
+    }
+}
+
+static int upload_tables(lrf_ctx* c, Tables& t)
+{
+    finish_gram_chunks(t);
     // the tables only depend on the call's geometry: skip the (synchronising) upload when nothing changed
     // (the Gram chunk table follows from the plane table: it is not part of the key)
     size_t pb = t.planes.size() * sizeof(PlaneDesc), bb = t.blocks.size() * sizeof(BlockDesc);
