@@ -24,6 +24,7 @@
 #define LRF_PLANES_GRAM_EXP 8
 // largest rank of the 64-column BCD kernels (k_bcd_w <= 8, k_bcd <= 16, k_bcd_mid <= 32); above it the any-shape kernels iterate
 #define LRF_BIG_TO_ANY_RANK 32
+#define LRF_BCDW_MIN_BLOCKS 1024 // smaller rank <= 8 runs iterate on the workgroup kernel k_bcd (run_bcd)
 
 static thread_local char g_err[512] = "";
 
@@ -451,7 +452,10 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
     if (table_rmax(t) > LRF_BIG_TO_ANY_RANK) return set_err(LRF_ENOTSUP, "internal: ranks above %d iterate on the any-shape kernels", LRF_BIG_TO_ANY_RANK);
     const std::vector<FamRun> runs = plan_runs(t);
     const bool mixed = plan_is_mixed(runs);
-    const bool wave_variant = bcd_wave_variant(); // k_bcd_w (one wave per block, no barriers) for rank <= 8 runs
+    // k_bcd_w (one wave per block, no barriers) for rank <= 8 runs — of LRF_BCDW_MIN_BLOCKS blocks or more: with fewer than a
+    // wave per SIMD what counts is the latency of ONE block, and there the four waves of the workgroup kernel k_bcd share a
+    // block's sub-tile (one 512x768 image: 27.9 -> 17.0 us per launch, 8 images 28.5 -> 18.2, 32 images 31.7 -> 27.6; equal at 48)
+    const bool wave_variant = bcd_wave_variant();
     if (!(c->attr_done & (1u << 1))) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_w<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LRF_BCDW_LDS));
         HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_w<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LRF_BCDW_LDS));
@@ -502,7 +506,7 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
                     if (mode == 1) LRF_LAUNCH_MID(1);
                     else if (mode == 2) LRF_LAUNCH_MID(2);
                     else LRF_LAUNCH_MID(0);
-                } else if (r.fam == 0 && wave_variant) {
+                } else if (r.fam == 0 && wave_variant && nbr >= LRF_BCDW_MIN_BLOCKS) {
                     if (mode == 1) LRF_LAUNCH_W(1);
                     else if (mode == 2) LRF_LAUNCH_W(2);
                     else LRF_LAUNCH_W(0);
