@@ -3,15 +3,86 @@
 
 #include <zlib.h>
 
+#include <unistd.h>
+
 #include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
 
 namespace {
+
+// Worker threads that outlive the call: one image per call is the reference's own usage pattern, and creating and joining
+// fifteen threads per call cost more than compressing its sixteen columns (0.55 -> ~0.2 ms per 512x768 image).  The threads
+// are detached and sleep on a condition variable between jobs; a forked child (no threads there) starts a pool of its own.
+class WorkerPool {
+public:
+    // runs job() on `helpers` pool threads and on the calling thread; returns when all of them have returned
+    void run(int helpers, const std::function<void()>& job)
+    {
+        std::unique_lock<std::mutex> call(call_mutex_); // one job at a time
+        {
+            std::unique_lock<std::mutex> lk(m_);
+            if (pid_ != getpid()) { // first use, or a forked child
+                pid_ = getpid();
+                nthreads_ = 0;
+            }
+            while (nthreads_ < helpers) {
+                std::thread(&WorkerPool::loop, this, pid_).detach();
+                nthreads_++;
+            }
+            job_ = &job;
+            slots_ = helpers;
+            running_ = helpers;
+            generation_++;
+        }
+        work_cv_.notify_all();
+        job();
+        std::unique_lock<std::mutex> lk(m_);
+        done_cv_.wait(lk, [&] { return running_ == 0; });
+        job_ = nullptr;
+    }
+
+private:
+    void loop(pid_t owner)
+    {
+        unsigned long long seen = 0;
+        for (;;) {
+            const std::function<void()>* job = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                work_cv_.wait(lk, [&] { return pid_ != owner || (generation_ != seen && slots_ > 0); });
+                if (pid_ != owner) return; // cannot happen in the process that created it; kept for symmetry
+                seen = generation_;
+                slots_--;
+                job = job_;
+            }
+            (*job)();
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                if (--running_ == 0) done_cv_.notify_all();
+            }
+        }
+    }
+    std::mutex call_mutex_, m_;
+    std::condition_variable work_cv_, done_cv_;
+    const std::function<void()>* job_ = nullptr;
+    unsigned long long generation_ = 0;
+    int nthreads_ = 0, slots_ = 0, running_ = 0;
+    pid_t pid_ = -1;
+};
+
+WorkerPool& worker_pool()
+{
+    static WorkerPool* p = new WorkerPool(); // never destroyed: its threads may be asleep on it when the process exits
+    return *p;
+}
 
 void append_be32(std::string& s, size_t n)
 {
@@ -98,12 +169,8 @@ int lrf_pack_qmf_streams(const int8_t* U, int64_t u_stride, const int8_t* V, int
         }
     };
     for (int64_t b = 0; b < B; b++) out[b] = nullptr;
-    {
-        std::vector<std::thread> pool;
-        for (int t = 1; t < nt; t++) pool.emplace_back(work);
-        work();
-        for (auto& th : pool) th.join();
-    }
+    if (nt > 1) worker_pool().run(nt - 1, work);
+    else work();
     if (status.load() != 0) return status.load();
     const std::string meta(metadata, (size_t)metadata_len);
     for (int64_t b = 0; b < B; b++) {
