@@ -24,6 +24,17 @@ int lrf_pack_qmf_streams(const int8_t* U, int64_t u_stride, const int8_t* V, int
                          const int64_t M[3], const int R[3], const char* metadata, int64_t metadata_len,
                          int threads, uint8_t** out, int64_t* out_len);
 void lrf_pack_free(uint8_t* p);
+
+/*
+ * The reverse for decoding (lrf/compression/utils.py:393-426, decode_matrix; qmf.py:306-327): factor_blobs[b] is the second
+ * payload of stream b — combine_bytes of the six encoded matrices u_Y, v_Y, u_Cb, v_Cb, u_Cr, v_Cr — of blob_len[b] bytes.
+ * Writes image b's factors to U + b*u_stride ([M0,R0] [M1,R1] [M2,R2] int8 row-major back to back) and V + b*v_stride
+ * (three [64,R_c]), the layout lrf_qmf_decode_rgb_u8 reads.  Every length is checked against the blob and against (M, R).
+ * Returns 0; -1 bad argument; -6 when a blob is not exactly that layout (another dtype or mode, other shapes, truncated or
+ * corrupt data): the caller then parses the stream itself to say what is wrong.
+ */
+int lrf_pack_unpack_qmf_factors(const uint8_t* const* factor_blobs, const int64_t* blob_len, int64_t B, const int64_t M[3],
+                                const int R[3], int threads, int8_t* U, int64_t u_stride, int8_t* V, int64_t v_stride);
 const char* lrf_pack_zlib_version(void);
 
 #ifdef __cplusplus

@@ -194,4 +194,105 @@ int lrf_pack_qmf_streams(const int8_t* U, int64_t u_stride, const int8_t* V, int
     return 0;
 }
 
+/* ---- the reverse: streams -> factor matrices (decode_matrix, utils.py:393-426) ---- */
+
+namespace {
+struct Span {
+    const uint8_t* p;
+    size_t n;
+};
+// _split2 (utils.py:268-287): len32_be(first) || first || second
+bool split2(Span in, Span& first, Span& second)
+{
+    if (in.n < 4) return false;
+    const size_t n = ((size_t)in.p[0] << 24) | ((size_t)in.p[1] << 16) | ((size_t)in.p[2] << 8) | (size_t)in.p[3];
+    if (n > in.n - 4) return false;
+    first = Span{in.p + 4, n};
+    second = Span{in.p + 4 + n, in.n - 4 - n};
+    return true;
+}
+// separate_bytes(combined, k): the payloads are peeled off the END of the left fold
+bool separate(Span in, int k, std::vector<Span>& out)
+{
+    out.assign((size_t)k, Span{nullptr, 0});
+    Span head = in;
+    for (int i = k - 1; i >= 1; i--) {
+        Span h, t;
+        if (!split2(head, h, t)) return false;
+        out[(size_t)i] = t;
+        head = h;
+    }
+    out[0] = head;
+    return true;
+}
+// the header json.dumps writes for an int8 matrix packed column by column, and nothing else
+bool header_is(Span h, int num_fibers)
+{
+    char want[96];
+    const int n = snprintf(want, sizeof(want), "{\"num_fibers\": %d, \"mode\": \"col\", \"dtype\": \"int8\"}", num_fibers);
+    return n > 0 && (size_t)n == h.n && memcmp(want, h.p, h.n) == 0;
+}
+} // namespace
+
+int lrf_pack_unpack_qmf_factors(const uint8_t* const* factor_blobs, const int64_t* blob_len, int64_t B, const int64_t M[3],
+                                const int R[3], int threads, int8_t* U, int64_t u_stride, int8_t* V, int64_t v_stride)
+{
+    if (!factor_blobs || !blob_len || !M || !R || !U || !V || B < 1) return -1;
+    int64_t usz = 0, vsz = 0;
+    for (int c = 0; c < 3; c++) {
+        if (M[c] < 1 || R[c] < 1) return -1;
+        usz += M[c] * R[c];
+        vsz += 64 * (int64_t)R[c];
+    }
+    if (u_stride < usz || v_stride < vsz) return -1;
+    // pass 1 (serial, cheap): locate every compressed column; anything that is not exactly the layout described above is
+    // refused (-6) and left to the caller's own parser and its error messages
+    struct Item {
+        Span z;
+        int8_t* dst; // first element of the column in the row-major destination
+        int64_t rows;
+        int cols;
+    };
+    std::vector<Item> items;
+    std::vector<Span> mats, parts, fibers;
+    for (int64_t b = 0; b < B; b++) {
+        if (!factor_blobs[b] || blob_len[b] < 0) return -1;
+        if (!separate(Span{factor_blobs[b], (size_t)blob_len[b]}, 6, mats)) return -6;
+        int8_t* u = U + b * u_stride;
+        int8_t* v = V + b * v_stride;
+        for (int c = 0; c < 3; c++) {
+            for (int f = 0; f < 2; f++) {
+                const int64_t rows = f ? 64 : M[c];
+                int8_t* dst = f ? v : u;
+                if (!separate(mats[(size_t)(2 * c + f)], 2, parts) || !header_is(parts[0], R[c])) return -6;
+                if (!separate(parts[1], R[c], fibers)) return -6;
+                for (int r = 0; r < R[c]; r++) items.push_back(Item{fibers[(size_t)r], dst + r, rows, R[c]});
+            }
+            u += M[c] * R[c];
+            v += 64 * R[c];
+        }
+    }
+    std::atomic<int64_t> next(0);
+    std::atomic<int> status(0);
+    const int64_t nitems = (int64_t)items.size();
+    auto work = [&]() {
+        std::vector<unsigned char> col;
+        for (;;) {
+            const int64_t it = next.fetch_add(1);
+            if (it >= nitems || status.load() != 0) return;
+            const Item& w = items[(size_t)it];
+            col.resize((size_t)w.rows);
+            uLongf n = (uLongf)w.rows;
+            if (uncompress(col.data(), &n, w.z.p, (uLong)w.z.n) != Z_OK || (int64_t)n != w.rows) { status.store(-6); return; }
+            for (int64_t i = 0; i < w.rows; i++) w.dst[i * w.cols] = (int8_t)col[(size_t)i];
+        }
+    };
+    unsigned hw = std::thread::hardware_concurrency();
+    int nt = threads > 0 ? threads : (int)(hw ? (hw > 64 ? 64 : hw) : 1);
+    if (nt > nitems) nt = (int)nitems;
+    if (nt > 1) worker_pool().run(nt - 1, work);
+    else work();
+    return status.load();
+}
+
 } // extern "C"

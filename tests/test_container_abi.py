@@ -102,7 +102,7 @@ def test_native_packer_matches_reference_streams():
     header = open(os.path.join(ROOT, "include", "lrf_pack.h")).read()
     declared = set(re.findall(r"\b(lrf_pack_[a-z0-9_]+)\s*\(", header))
     lib = ctypes.CDLL(os.path.join(ROOT, "lrf_amd", "liblrf_pack.so"))
-    assert declared == {"lrf_pack_qmf_streams", "lrf_pack_free", "lrf_pack_zlib_version"}
+    assert declared == {"lrf_pack_qmf_streams", "lrf_pack_free", "lrf_pack_zlib_version", "lrf_pack_unpack_qmf_factors"}
     for name in declared:
         assert hasattr(lib, name)
     for name in ("s1_r7", "odd_q7", "tiny_rank1", "tiny_q20", "zero_q7", "nat_q7"):
@@ -113,6 +113,37 @@ def test_native_packer_matches_reference_streams():
         U3, V3 = np.repeat(U, 3, 0), np.repeat(V, 3, 0)
         out = pack_streams_native(U3, V3, case.image.shape[-2:], meta["rank"], meta["bounds"], meta["patch size"], threads=2)
         assert out == [case.encoded] * 3
+
+
+def test_native_unpacker_matches_python_parser_and_refuses_crafted_streams():
+    """lrf_pack_unpack_qmf_factors (the decode side of liblrf_pack.so): the factors it inflates from the reference's own
+    streams equal this module's Python container code; a stream that is not exactly the int8 / column layout its metadata
+    describes — truncated, corrupt, another rank — is refused (the Python path then raises its error)."""
+    from lrf_amd import codec
+    from lrf_amd.container import combine_bytes, dict_to_bytes, encode_matrix, separate_bytes
+    for name in ("s1_r7", "odd_q7", "tiny_rank1", "tiny_q20", "zero_q7", "nat_q7"):
+        case = Case(name)
+        streams = [case.encoded] * 3
+        got = codec._factors_native(streams)
+        assert got is not None, name
+        metas, U, V = got
+        pm, PU, PV = codec._factors_python(streams)
+        assert metas == pm and np.array_equal(U, PU) and np.array_equal(V, PV)
+    case = Case("s1_r7")
+    meta_b, fac_b = separate_bytes(case.encoded, 2)
+    assert codec._factors_native([combine_bytes([meta_b, fac_b[:-7]])]) is None          # truncated
+    broken = bytearray(fac_b)
+    broken[len(broken) // 2] ^= 0x55
+    assert codec._factors_native([combine_bytes([meta_b, bytes(broken)])]) is None       # corrupt deflate data
+    meta, fac = codec.parse_stream(case.encoded)
+    wrong = [f if i else f[:, :-1] for i, f in enumerate(fac)]                           # u_Y with one column less
+    crafted = combine_bytes([dict_to_bytes(meta), combine_bytes([encode_matrix(np.ascontiguousarray(f)) for f in wrong])])
+    assert codec._factors_native([crafted]) is None
+    with pytest.raises(ValueError):
+        codec._factors_python([crafted])
+    wide = [f.astype(np.int16) for f in fac]                                             # another dtype
+    crafted = combine_bytes([dict_to_bytes(meta), combine_bytes([encode_matrix(np.ascontiguousarray(f)) for f in wide])])
+    assert codec._factors_native([crafted]) is None
 
 
 def test_ssim_matches_direct_window_statistics():
