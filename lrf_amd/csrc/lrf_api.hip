@@ -967,8 +967,13 @@ int lrf_qmf_decode_rgb_u8(lrf_ctx* c, const int8_t* U, const int8_t* V, int64_t 
             hipLaunchKernelGGL(k_decode16<8>, grid, dim3(256), 0, c->stream, U, V, (int)H, (int)W, g, R[0], R[1], R[2], u_img, v_img, rgb);
     }
     else if (R[0] <= 8 && R[1] <= 8 && R[2] <= 8)
-        hipLaunchKernelGGL(k_decode8, dim3((unsigned)((n4 + 255) / 256), (unsigned)B), dim3(256), 0, c->stream, U, V, (int)H, (int)W,
-                           g, R[0], R[1], R[2], u_img, v_img, rgb);
+{
+        // groups of four pixels per thread: as many as leave the call ~2048 workgroups (small calls keep one group per thread)
+        long reps = (long)B * ((n4 + 255) / 256) / 2048;
+        reps = reps < 1 ? 1 : (reps > 16 ? 16 : reps);
+        hipLaunchKernelGGL(k_decode8, dim3((unsigned)((n4 + 256 * reps - 1) / (256 * reps)), (unsigned)B), dim3(256), 0, c->stream, U, V, (int)H, (int)W,
+                           g, R[0], R[1], R[2], u_img, v_img, rgb, (int)reps);
+    }
     else
         hipLaunchKernelGGL(k_decode, dim3((unsigned)((n4 + 255) / 256), (unsigned)B), dim3(256), 0, c->stream, U, V, (int)H, (int)W,
                            g, R[0], R[1], R[2], u_img, v_img, rgb);
