@@ -21,7 +21,7 @@
 // order (tiny products): scalar loop, each thread 8 rows x 1 column.
 __global__ __launch_bounds__(256) void k_any_prod(const float* __restrict__ A, long a_batch, long sai, long sak,
                                                   const float* __restrict__ Bm, long b_batch, float* __restrict__ P,
-                                                  int I, int D, int R, int nblk, int native)
+                                                  int I, int D, int R, int nblk, int native, int tiles /* 64-row tiles per workgroup */)
 {
     __shared__ float As[64 * 65];
     __shared__ float Bs[64 * 32];
@@ -29,12 +29,17 @@ __global__ __launch_bounds__(256) void k_any_prod(const float* __restrict__ A, l
     const int lane = tid & 63, li = lane & 15, lq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rt = blockIdx.y / nblk, blk = blockIdx.y - rt * nblk;
-    const int i0 = blockIdx.x * 64, r0 = rt * 32;
+    const int r0 = rt * 32;
     const float* Ab = A + (long)blockIdx.z * a_batch;
-    f32x4 macc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     const float* Bb = Bm + (long)blockIdx.z * b_batch;
     const int kbeg = blk * LRF_KC;
     const int kend = (kbeg + LRF_KC < D) ? kbeg + LRF_KC : D;
+    // a workgroup takes `tiles` consecutive 64-row tiles (tall matrices with a short contraction — [24576,16] for 4x4 patches —
+    // are otherwise hundreds of thousands of workgroups with a few hundred multiply-adds each)
+    for (int tile = 0; tile < tiles; tile++) {
+    const int i0 = (blockIdx.x * tiles + tile) * 64;
+    if (i0 >= I) break; // workgroup-uniform
+    f32x4 macc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) acc[j] = 0.f;
@@ -114,6 +119,7 @@ __global__ __launch_bounds__(256) void k_any_prod(const float* __restrict__ A, l
                 if (i < I && r < R) Pb[(long)i * R + r] = macc[ct][reg];
             }
         }
+    }
     }
 }
 
