@@ -8,6 +8,9 @@
 #include <string.h>
 
 #include <string>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/lrf_hip.h"
@@ -1126,8 +1129,6 @@ int lrf_pipe_qmf_encode_submit(lrf_pipe* p, const uint8_t* rgb_host, int64_t B, 
     auto enqueue_upload = [&](size_t i) -> int {
         PipeSlot& s = p->slots[i % p->slots.size()];
         const int64_t b0 = (int64_t)i * sb, nb = (b0 + sb <= B) ? sb : B - b0;
-        int rc2;
-        if ((rc2 = pipe_ensure(p, s, s.rgb, (size_t)sb * img_bytes))) return rc2;
         HIP_TRY(hipStreamWaitEvent(p->h2d, s.rgb_free, 0));
         HIP_TRY(hipMemcpyAsync(s.rgb.p, rgb_host + (size_t)b0 * img_bytes, (size_t)nb * img_bytes, hipMemcpyHostToDevice, p->h2d));
         HIP_TRY(hipEventRecord(s.h2d_done, p->h2d));
@@ -1139,26 +1140,104 @@ int lrf_pipe_qmf_encode_submit(lrf_pipe* p, const uint8_t* rgb_host, int64_t B, 
         if ((rc = ensure(p->slots[0].ctx, p->sign, (size_t)B * s_img))) return rc;
         HIP_TRY(hipMemcpyAsync(p->sign.p, sign_host, (size_t)B * s_img, hipMemcpyHostToDevice, p->h2d));
     }
-    if ((rc = enqueue_upload(0))) return rc;
-    for (size_t i = 0; i < nsub; i++) {
+    // kernels and downloads of sub-batch i on its slot's stream, behind its upload
+    auto enqueue_kernels = [&](size_t i) -> int {
         PipeSlot& s = p->slots[i % p->slots.size()];
         const int64_t b0 = (int64_t)i * sb, nb = (b0 + sb <= B) ? sb : B - b0;
-        if ((rc = pipe_ensure(p, s, s.u, (size_t)sb * u_img))) return rc;
-        if ((rc = pipe_ensure(p, s, s.v, (size_t)sb * v_img))) return rc;
         hipStream_t st = s.ctx->stream;
+        int rc2;
         HIP_TRY(hipStreamWaitEvent(st, s.h2d_done, 0));
-        // With one slot the next upload overwrites the buffer this sub-batch still has to read: it is enqueued after the
-        // kernels (which record rgb_free); with more slots it goes first, so that the link never waits for this thread.
-        if (i + 1 < nsub && p->slots.size() > 1 && (rc = enqueue_upload(i + 1))) return rc;
-        if ((rc = lrf_qmf_encode_rgb_u8(s.ctx, (const uint8_t*)s.rgb.p, nb, H, W, R, K, lo, hi, sign_host ? (const int8_t*)p->sign.p + (size_t)b0 * s_img : nullptr,
-                                        (int8_t*)s.u.p, (int8_t*)s.v.p)))
-            return rc;
-        if (i + 1 < nsub && p->slots.size() == 1 && (rc = enqueue_upload(i + 1))) return rc;
+        if ((rc2 = lrf_qmf_encode_rgb_u8(s.ctx, (const uint8_t*)s.rgb.p, nb, H, W, R, K, lo, hi, sign_host ? (const int8_t*)p->sign.p + (size_t)b0 * s_img : nullptr,
+                                         (int8_t*)s.u.p, (int8_t*)s.v.p)))
+            return rc2;
+        return LRF_OK;
+    };
+    auto enqueue_download = [&](size_t i) -> int {
+        PipeSlot& s = p->slots[i % p->slots.size()];
+        const int64_t b0 = (int64_t)i * sb, nb = (b0 + sb <= B) ? sb : B - b0;
+        hipStream_t st = s.ctx->stream;
         HIP_TRY(hipMemcpyAsync(U_host + (size_t)b0 * u_img, s.u.p, (size_t)nb * u_img, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(V_host + (size_t)b0 * v_img, s.v.p, (size_t)nb * v_img, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipEventRecord(p->done[i], st));
         p->first.push_back(b0);
         p->count.push_back(nb);
+        return LRF_OK;
+    };
+    for (auto& s : p->slots) { // all allocations up front: none may happen while two threads work on the pipe (below)
+        if ((rc = pipe_ensure(p, s, s.rgb, (size_t)sb * img_bytes))) return rc;
+        if ((rc = pipe_ensure(p, s, s.u, (size_t)sb * u_img))) return rc;
+        if ((rc = pipe_ensure(p, s, s.v, (size_t)sb * v_img))) return rc;
+    }
+    // Pageable source memory (what a torch tensor is unless it was pinned): hipMemcpyAsync from it returns when the transfer is
+    // over, so a single submitting thread enqueues the kernels of sub-batch i only after upload i + 1 and the pipeline drains
+    // (256 x 512x768: 9.7 ms against 6.1 ms from page-locked memory).  Then a second thread issues the uploads, in order;
+    // the two threads hand over through two counters: the kernels of sub-batch i wait for upload i to have been issued (its
+    // event must be RECORDED before a stream can wait for it), upload i + S for the kernels of sub-batch i (which record
+    // rgb_free, the event that says the slot's input buffer may be overwritten).
+    bool pageable = false;
+    {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, rgb_host) == hipSuccess) pageable = attr.type == hipMemoryTypeUnregistered;
+        else { (void)hipGetLastError(); pageable = true; } // some runtimes report an error for an unregistered pointer
+    }
+    const size_t S = p->slots.size();
+    if (pageable && S > 1 && nsub > 1) {
+        struct Handover {
+            std::mutex m;
+            std::condition_variable cv;
+            size_t uploaded = 0, enqueued = 0;
+            int err = 0;
+            char msg[512] = "";
+        } ho;
+        std::thread uploader([&]() {
+            DevGuard guard(p->device);
+            for (size_t i = 0; i < nsub; i++) {
+                {
+                    std::unique_lock<std::mutex> lk(ho.m);
+                    ho.cv.wait(lk, [&] { return ho.err != 0 || i < S || ho.enqueued + S > i; });
+                    if (ho.err) return;
+                }
+                const int rcu = enqueue_upload(i);
+                std::unique_lock<std::mutex> lk(ho.m);
+                if (rcu) {
+                    ho.err = rcu;
+                    snprintf(ho.msg, sizeof(ho.msg), "%s", lrf_last_error()); // this thread's message, for the caller's thread
+                } else {
+                    ho.uploaded = i + 1;
+                }
+                ho.cv.notify_all();
+                if (rcu) return;
+            }
+        });
+        int rcm = LRF_OK;
+        for (size_t i = 0; i < nsub && rcm == LRF_OK; i++) {
+            {
+                std::unique_lock<std::mutex> lk(ho.m);
+                ho.cv.wait(lk, [&] { return ho.err != 0 || ho.uploaded > i; });
+                if (ho.err) break;
+            }
+            rcm = enqueue_kernels(i);
+            if (rcm == LRF_OK) rcm = enqueue_download(i);
+            std::unique_lock<std::mutex> lk(ho.m);
+            if (rcm) ho.err = rcm;
+            else ho.enqueued = i + 1;
+            ho.cv.notify_all();
+        }
+        uploader.join();
+        if (rcm) return rcm;
+        if (ho.err) return set_err(ho.err, "%s", ho.msg);
+    } else {
+        if ((rc = enqueue_upload(0))) return rc;
+        for (size_t i = 0; i < nsub; i++) {
+            // With one slot the next upload overwrites the buffer this sub-batch still has to read: it is enqueued after the
+            // kernels (which record rgb_free); with more slots it goes first, so that the link never waits for this thread.
+            PipeSlot& s = p->slots[i % S];
+            HIP_TRY(hipStreamWaitEvent(s.ctx->stream, s.h2d_done, 0));
+            if (i + 1 < nsub && S > 1 && (rc = enqueue_upload(i + 1))) return rc;
+            if ((rc = enqueue_kernels(i))) return rc;
+            if (i + 1 < nsub && S == 1 && (rc = enqueue_upload(i + 1))) return rc;
+            if ((rc = enqueue_download(i))) return rc;
+        }
     }
     if (n_sub) *n_sub = (int)nsub;
     return LRF_OK;
