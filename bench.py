@@ -13,8 +13,13 @@ Next to `value` (inputs and outputs in HBM) the line carries SURVEY 8(d)'s host-
 `pcie_frac`), the decoder (`decode_mpix_s`), the oracle timed on this box's host cores (`cpu_baseline`).
 
   python bench.py --gpus 1 --steps 5 --warmup 2
+  python bench.py --gpus N ...          # no launcher: bench.py starts its own N ranks (fresh child processes, before
+                                        # this process has imported torch or touched a GPU) and exits with their code
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
+Either way rank 0 refuses to print a line unless the process group really has --gpus ranks (`rccl_ranks` in the line).
+`value` is the HBM-resident rate (`value_definition`); the timed region of K steps is repeated `timed_regions` times and
+`ms_per_step` / `value` are the MEDIAN region's (min / max beside it).
 """
 import argparse
 import json
@@ -41,6 +46,17 @@ CONFIGS = {
     "svd": {"H": 512, "W": 768, "ranks": None, "batch": 256, "svd_rank": 5,
             "label": "{B} x 512x768x3 uint8 per GPU, svd_encode default branch (RGB, X [6144,192], quality 2.5 -> R = 5, "
                      "uint8-quantised factors) (BASELINE configs[4])"},
+}
+
+# The reference's own torch CPU path, as measured in the build container (it cannot travel to the
+# GPU box): quoted in the line so that the ">= 100x the reference" target can be read off it.
+REFERENCE_TORCH_CPU = {
+    "kodak": {"value": 4.36, "unit": "Mpix/s", "threads": 8, "one_thread": 3.86, "ms_per_image": 90.1,
+              "where": "build container, 8-vCPU Xeon 2.1 GHz, torch 2.10 CPU, qmf_encode rank=7 on one 512x768 image "
+                       "(BASELINE.md section 2) — a quoted figure, not measured by this run"},
+    "clic": {"value": 8.03, "unit": "Mpix/s", "threads": 8, "one_thread": 4.75, "ms_per_image": 348.0,
+             "where": "build container, qmf_encode quality=7 on one 1365x2048 image (BASELINE.md section 2; ranks (4,2,2), "
+                      "the only CLIC-sized figure measured there) — quoted, not measured by this run"},
 }
 
 
@@ -120,9 +136,11 @@ def cpu_baseline(images_u8, H, W, ranks, budget_s=12.0, budget_all_s=10.0):
             "cpu": _cpu_model(), "host_cores": os.cpu_count()}
 
 
-def host_to_host(torch, _lib, dev_index, images, H, W, ranks, steps, warmup):
+def host_to_host(torch, dist, _lib, dev_index, images, H, W, ranks, steps, warmup, world, cdev, repeats=5):
     """SURVEY 8(d)'s metric: uint8 batch in page-locked host memory -> int8 factors back in host memory, through the
-    pipelined encoder (lrf_pipe: sub-batches on an upload stream and two kernel streams, H2D / kernels / D2H overlapped)."""
+    pipelined encoder (lrf_pipe: sub-batches on an upload stream and two kernel streams, H2D / kernels / D2H overlapped).
+    With N > 1 every rank runs the leg on its own page-locked buffers (allocated by this rank's thread, the one bound
+    to its GPU) between two barriers; the whole-job rate is all ranks' pixels over the slowest rank's time."""
     B = images.shape[0]
     host = images.cpu().pin_memory()
     dims = _lib.plane_dims(H, W)
@@ -131,31 +149,56 @@ def host_to_host(torch, _lib, dev_index, images, H, W, ranks, steps, warmup):
     slots = int(os.environ.get("LRF_PIPE_SLOTS", "2"))
     sub = int(os.environ.get("LRF_PIPE_SUB", "0"))
     pipe = _lib.Pipe(dev_index, slots=slots, sub_batch=sub)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    def region(fn):
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt / steps
+
+    def encode():
+        pipe.encode_rgb_host(host, ranks, NUM_ITERS, BOUNDS[0], BOUNDS[1], out=(Uh, Vh))
+
     for _ in range(max(warmup, 2)):
-        pipe.encode_rgb_host(host, ranks, NUM_ITERS, BOUNDS[0], BOUNDS[1], out=(Uh, Vh))
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        pipe.encode_rgb_host(host, ranks, NUM_ITERS, BOUNDS[0], BOUNDS[1], out=(Uh, Vh))
-    dt = (time.perf_counter() - t0) / steps
+        encode()
+    samples = [region(encode) for _ in range(repeats)]
+    lo_s, dt, hi_s = timed_stats(samples)
     # the link itself: the same pinned buffer copied to the device with nothing else going on
     dst = torch.empty_like(images)
     for _ in range(2):
         dst.copy_(host, non_blocking=True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        dst.copy_(host, non_blocking=True)
-    torch.cuda.synchronize()
-    dt_copy = (time.perf_counter() - t0) / steps
+    copies = [region(lambda: dst.copy_(host, non_blocking=True)) for _ in range(3)]
+    dt_copy = timed_stats(copies)[1]
     nbytes = host.numel()
     pipe.close()
-    return {"host_to_host_mpix_s": round(B * H * W / dt / 1e6, 1), "host_to_host_ms_per_step": round(dt * 1e3, 3),
+    del dst
+    px = float(B * H * W)
+    if world > 1:
+        t = torch.tensor([px], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        px = float(t.item())
+    return {"host_to_host_mpix_s": round(px / dt / 1e6, 1), "host_to_host_ms_per_step": round(dt * 1e3, 3),
+            "host_to_host_ms_min_median_max": [round(x * 1e3, 3) for x in (lo_s, dt, hi_s)],
+            "host_to_host_regions": repeats,
             "pcie_frac": round(nbytes / dt / 63e9, 4),
-            "pcie_note": "input bytes (3 B/pixel, page-locked host memory) / wall time of the whole host->host encode, over "
-                         "63 GB/s (PCIe Gen5 x16); the 0.14 B/pixel of factors return on the other direction of the link",
+            "pcie_note": "per GPU: input bytes (3 B/pixel, page-locked host memory) / wall time of the whole host->host encode "
+                         "(median region, slowest rank), over 63 GB/s (PCIe Gen5 x16); the 0.14 B/pixel of factors return on "
+                         "the other direction of the link",
             "h2d_copy_alone_gbs": round(nbytes / dt_copy / 1e9, 2),
             "frac_of_h2d_copy_alone": round(dt_copy / dt, 4),
-            "pipe": {"slots": slots, "sub_batch": sub or "auto (~40 MB of input)",
+            "pipe": {"slots": slots, "sub_batch": sub or "auto",
                      "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}}, (Uh, Vh)
 
 
@@ -181,18 +224,81 @@ def decode_leg(torch, _lib, ctx, U, V, H, W, ranks, steps):
                                 "frac": round(alg / (k * 1e-3) / 1e9 / 8000.0, 4), "algorithmic_bytes_per_launch": alg}}
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n_ranks, argv):
+    """`bench.py --gpus N` without a launcher's environment: start the N ranks ourselves, one fresh child process per GPU
+    with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, exactly what `python -m torch.distributed.run` would give them.
+    Called before this process has imported torch or made any GPU call (a GPU-initialised process must neither fork
+    workers nor exec); the parent only waits, forwards rank 0's line (the children inherit stdout) and returns the
+    first non-zero exit code, ending the other ranks (by their exact pids) when one fails."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LRF_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.05)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:  # a rank died: the others would wait in a collective for ever
+                    q.terminate()
+    return rc
+
+
+def timed_stats(samples_ms):
+    s = sorted(samples_ms)
+    n = len(s)
+    med = s[n // 2] if n % 2 else 0.5 * (s[n // 2 - 1] + s[n // 2])
+    return s[0], med, s[-1]
+
+
+def synthetic_batch(torch, dev, lo, count, H, W, base_seed=1234):
+    """Images lo .. lo+count-1 of the synthetic dataset, drawn straight into this rank's own batch buffer: image i is
+    `randint(0, 256, (3, H, W))` from a generator seeded with base_seed + i, so a rank's block does not depend on the
+    number of ranks and no rank ever materialises more than its block (+ nothing: randint writes in place)."""
+    images = torch.empty((count, 3, H, W), dtype=torch.uint8, device=dev)
+    g = torch.Generator(device=dev)
+    for i in range(count):
+        g.manual_seed(base_seed + lo + i)
+        torch.randint(0, 256, (3, H, W), dtype=torch.uint8, device=dev, generator=g, out=images[i])
+    return images
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="kodak")
     ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (0 = the config's: 256 / 512); with "
                                                          "--scaling strong, the GLOBAL batch sharded over the ranks")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--regions", type=int, default=5, help="how many times the timed region of --steps steps is repeated")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the host->host, decode and CPU legs")
     args = ap.parse_args()
+    assert args.gpus >= 1 and args.steps >= 1 and args.regions >= 1
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: start the ranks ourselves, BEFORE torch is imported or a GPU touched in this process
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
     cfg = CONFIGS[args.config]
     H, W, RANKS = cfg["H"], cfg["W"], cfg["ranks"]
 
@@ -202,21 +308,26 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}: the launcher's rank count and --gpus must agree"
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     # LRF_BENCH_REHEARSAL=1: development aid for boxes with fewer GPUs than ranks — ranks share the visible GPUs and the
     # (tiny) collectives run over gloo, because RCCL refuses two ranks on one device.  Never set by the driver.
     rehearsal = os.environ.get("LRF_BENCH_REHEARSAL") == "1"
-    dev_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
+    n_dev = torch.cuda.device_count()
+    assert rehearsal or local_rank < n_dev, f"rank {rank}: LOCAL_RANK {local_rank} but only {n_dev} GPU(s) visible"
+    dev_index = local_rank % n_dev if rehearsal else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     cdev = torch.device("cpu") if rehearsal else dev  # where the collective payloads live
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "gloo" if rehearsal else "nccl"
         if rehearsal:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+        assert dist.get_world_size() == args.gpus, f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus}"
 
     import lrf_amd
     from lrf_amd import _lib
@@ -226,17 +337,12 @@ def main():
     if args.scaling == "strong":  # one global batch, contiguous per-rank blocks (lrf_amd/sharding.py)
         lo, hi = shard_range(B_cfg, rank, world)
         B = hi - lo
-        seed = 1234
-    else:
-        lo, B, seed = 0, B_cfg, 1234 + rank
+    else:  # weak: every rank its own B_cfg images; the dataset is the concatenation of the ranks' blocks
+        lo, B = rank * B_cfg, B_cfg
     assert B >= 1, "a rank got no images: --batch must be at least the number of GPUs"
-    g = torch.Generator(device=dev).manual_seed(seed)
-    if args.scaling == "strong":  # every rank draws the same global batch and keeps its block: results independent of N
-        full = torch.randint(0, 256, (B_cfg, 3, H, W), dtype=torch.uint8, device=dev, generator=g)
-        images = full[lo:lo + B].clone()
-        del full
-    else:
-        images = torch.randint(0, 256, (B, 3, H, W), dtype=torch.uint8, device=dev, generator=g)
+    torch.cuda.reset_peak_memory_stats(dev)
+    images = synthetic_batch(torch, dev, lo, B, H, W)
+    gen_peak = int(torch.cuda.max_memory_allocated(dev))
     ctx = _lib.context(dev_index)
     dims = _lib.plane_dims(H, W)
     if args.config == "svd":
@@ -265,17 +371,23 @@ def main():
         step()
     for _ in range(args.warmup):
         step()
-    barrier()
-    # Inside the timed region only the dominant kernel (the BCD pass, K launches per step) carries HIP event pairs on
+    # Inside the timed regions only the dominant kernel (the BCD pass, K launches per step) carries HIP event pairs on
     # the launching stream: an event pair costs stream time (0.15 ms per step when all 22 launches are bracketed).
     ctx.profile_kernels([_lib.LRF_K_BCD])
     ctx.profile_reset()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
+    region_s = []
+    for _ in range(args.regions):  # each region: barrier + synchronize, EXACTLY --steps steps, synchronize + barrier
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt_r = time.perf_counter() - t0
+        if world > 1:  # the slowest rank's time is the job's time
+            t = torch.tensor([dt_r], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_r = float(t.item())
+        region_s.append(dt_r)
     ctx.profile(False)
     bcd_total_ms, bcd_launches = ctx.kernel_time(_lib.LRF_K_BCD)
     # per-kernel breakdown: a separate, untimed pass with every launch bracketed
@@ -285,16 +397,25 @@ def main():
         step()
     torch.cuda.synchronize()
     ctx.profile(False)
+    dt_min, dt, dt_max = timed_stats(region_s)
+    rank_stats = None
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        stats = torch.tensor([float(B * H * W * args.steps), dt], dtype=torch.float64, device=cdev)
+        stats = torch.tensor([float(B * H * W * args.steps), float(dev_index)], dtype=torch.float64, device=cdev)
         gathered = [torch.zeros_like(stats) for _ in range(world)]
         dist.all_gather(gathered, stats)  # final metrics gather (the only payload collective)
         total_px = sum(float(s[0]) for s in gathered)
+        rank_stats = [{"rank": r, "device": int(s[1]), "pixels_per_region": float(s[0])} for r, s in enumerate(gathered)]
     else:
         total_px = float(B * H * W * args.steps)
+
+    extras = {}
+    h2h_pair = None
+    if not args.no_extras and args.config != "svd":  # every rank takes part in the (collective-timed) host->host leg
+        Ud, Vd = U.cpu(), V.cpu()
+        h2h, h2h_pair = host_to_host(torch, dist, _lib, dev_index, images, H, W, RANKS, min(args.steps, 10), args.warmup,
+                                     world, cdev)
+        assert torch.equal(h2h_pair[0], Ud) and torch.equal(h2h_pair[1], Vd), "pipelined factors differ from the one-shot ones"
+        extras.update(h2h)
 
     if rank == 0:
         value = total_px / dt / 1e6
@@ -318,7 +439,7 @@ def main():
             # dominant kernel: one BCD pass (k_bcd_w).  Algorithmic bytes per launch (DESIGN.md "Roofline"):
             # X read once (4 B per patch element) + int8 U written once.
             alg_bytes = B * (sum(d[4] for d in dims) * 64 * 4 + sum(d[4] * r for d, r in zip(dims, RANKS)))
-            bcd_ms = bcd_total_ms / bcd_launches  # live, from the timed region
+            bcd_ms = bcd_total_ms / bcd_launches  # live, from the timed regions (rank 0's GPU)
             achieved = alg_bytes / (bcd_ms * 1e-3) / 1e9
             traffic = None
             tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -329,7 +450,8 @@ def main():
                     traffic = None
             roof = {"bound": "hbm", "kernel": "k_bcd_w", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                     "frac": round(achieved / 8000.0, 4), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(bcd_ms, 5)}
+                    "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(bcd_ms, 5),
+                    "launches_measured": bcd_launches}
         out = {
             "metric": metric,
             "value": round(value, 2),
@@ -345,22 +467,33 @@ def main():
             "data": "synthetic",
             "config": {"workload": cfg["label"].format(B=B), "priming_steps": PRIMING,
                        "global_batch": B_cfg if args.scaling == "strong" else B * world,
+                       "images_this_rank": [lo, lo + B], "rank_input_bytes": images.numel(),
+                       "input_generation_peak_bytes": gen_peak,
                        "parallelism": f"images sharded over {world} GPU(s), no data-path collective"},
+            "value_definition": "hbm_resident: uint8 batch and int8 factors stay in HBM across the timed region "
+                                "(SURVEY 8(d)'s pinned-host -> host rate is host_to_host_mpix_s)",
+            "timed_regions": args.regions,
+            "ms_per_step_min": round(dt_min / args.steps * 1e3, 4),
+            "ms_per_step_median": round(ms_step, 4),
+            "ms_per_step_max": round(dt_max / args.steps * 1e3, 4),
+            "timing_note": "each region = barrier + synchronize, exactly `steps` steps, synchronize + barrier, max over ranks; "
+                           "value / ms_per_step are the median region's",
+            "rccl_ranks": world, "collective_backend": backend, "self_launched": os.environ.get("LRF_BENCH_SELF_LAUNCHED") == "1",
             "roofline": roof,
             # 75.1 algorithmic bytes per input pixel for the whole encode at K = 10
             "whole_encode_frac_of_hbm_peak": round(75.1 * total_px / world / dt / 8e12, 4) if args.config != "svd" else None,
             "kernels": {k: {a: round(b, 5) for a, b in v.items()} for k, v in kern.items()},
             "kernels_note": "per-kernel breakdown from a separate untimed pass with every launch bracketed by events; "
-                            "roofline.avg_launch_ms is measured inside the timed region (events on the BCD launches only)",
+                            "roofline.avg_launch_ms is measured inside the timed regions (events on the BCD launches only)",
         }
+        if rank_stats:
+            out["ranks"] = rank_stats
+        out.update(extras)
         if world == 1 and not args.no_extras and args.config != "svd":
             out.update(decode_leg(torch, _lib, ctx, U, V, H, W, RANKS, args.steps))
-            Ud, Vd = U.cpu(), V.cpu()
-            h2h, (Uh, Vh) = host_to_host(torch, _lib, dev_index, images, H, W, RANKS, args.steps, args.warmup)
-            assert torch.equal(Uh, Ud) and torch.equal(Vh, Vd), "pipelined factors differ from the one-shot ones"
-            out.update(h2h)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(images[:min(B, 256)].cpu().numpy(), H, W, RANKS)
+                out["cpu_baseline"]["reference_torch_cpu"] = REFERENCE_TORCH_CPU.get(args.config)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -3,6 +3,7 @@
 
 #include <zlib.h>
 
+#include <pthread.h>
 #include <unistd.h>
 
 #include <atomic>
@@ -20,7 +21,10 @@ namespace {
 
 // Worker threads that outlive the call: one image per call is the reference's own usage pattern, and creating and joining
 // fifteen threads per call cost more than compressing its sixteen columns (0.55 -> ~0.2 ms per 512x768 image).  The threads
-// are detached and sleep on a condition variable between jobs; a forked child (no threads there) starts a pool of its own.
+// are detached and sleep on a condition variable between jobs.  A forked child has none of these threads, and the pool's
+// mutexes and condition variables were copied in whatever state the parent's sleeping workers had left them (a condition
+// variable still counts them as waiters: the child's second notify_all would wait for them for ever), so the child never
+// touches the inherited pool: worker_pool() below hands it a brand-new one (pthread_atfork child handler).
 class WorkerPool {
 public:
     // runs job() on `helpers` pool threads and on the calling thread; returns when all of them have returned
@@ -29,10 +33,7 @@ public:
         std::unique_lock<std::mutex> call(call_mutex_); // one job at a time
         {
             std::unique_lock<std::mutex> lk(m_);
-            if (pid_ != getpid()) { // first use, or a forked child
-                pid_ = getpid();
-                nthreads_ = 0;
-            }
+            if (pid_ < 0) pid_ = getpid(); // first use (a forked child gets a new pool, never this one)
             while (nthreads_ < helpers) {
                 std::thread(&WorkerPool::loop, this, pid_).detach();
                 nthreads_++;
@@ -78,9 +79,24 @@ private:
     pid_t pid_ = -1;
 };
 
+std::atomic<WorkerPool*> g_pool{nullptr};
+
+// runs in the child of a fork(): forget the parent's pool (leaked on purpose: its synchronisation objects are unusable,
+// see above); the next call allocates a fresh one with mutexes and condition variables of its own
+void forget_pool_after_fork() { g_pool.store(nullptr, std::memory_order_release); }
+
 WorkerPool& worker_pool()
 {
-    static WorkerPool* p = new WorkerPool(); // never destroyed: its threads may be asleep on it when the process exits
+    static const int registered = pthread_atfork(nullptr, nullptr, forget_pool_after_fork);
+    (void)registered;
+    WorkerPool* p = g_pool.load(std::memory_order_acquire);
+    if (!p) {
+        WorkerPool* fresh = new WorkerPool(); // never destroyed: its threads may be asleep on it when the process exits
+        if (g_pool.compare_exchange_strong(p, fresh, std::memory_order_acq_rel))
+            p = fresh;
+        else
+            delete fresh; // another thread was first; `fresh` has started no thread yet
+    }
     return *p;
 }
 

@@ -115,6 +115,40 @@ def test_native_packer_matches_reference_streams():
         assert out == [case.encoded] * 3
 
 
+def test_native_packer_survives_fork():
+    """the packer's worker threads outlive a call; a forked child must not reuse the parent's pool (its
+    condition variables still count the parent's sleeping workers as waiters: the child's SECOND call used to hang)."""
+    import signal
+
+    from lrf_amd.codec import pack_streams_native
+    rng = np.random.default_rng(5)
+    H, W, ranks = 64, 96, (4, 2, 2)
+    from lrf_amd import _lib
+    dims = _lib.plane_dims(H, W)
+    U = rng.integers(-16, 16, (6, sum(d[4] * r for d, r in zip(dims, ranks))), dtype=np.int8)
+    V = rng.integers(-16, 16, (6, 64 * sum(ranks)), dtype=np.int8)
+    want = pack_streams_native(U, V, (H, W), ranks, (-16, 15), threads=4)
+    assert pack_streams_native(U, V, (H, W), ranks, (-16, 15), threads=4) == want  # the pool's threads exist and sleep
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:  # child: three calls (the second one used to dead-lock), then report through the pipe
+        code = 1
+        try:
+            signal.alarm(60)
+            ok = all(pack_streams_native(U, V, (H, W), ranks, (-16, 15), threads=4) == want for _ in range(3))
+            os.write(w, b"ok" if ok else b"bad")
+            code = 0
+        finally:
+            os._exit(code)
+    os.close(w)
+    status = os.waitpid(pid, 0)[1]
+    got = os.read(r, 16)
+    os.close(r)
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0, f"child ended with status {status:#x} (SIGALRM = hang)"
+    assert got == b"ok"
+    assert pack_streams_native(U, V, (H, W), ranks, (-16, 15), threads=4) == want  # the parent's pool still works
+
+
 def test_native_unpacker_matches_python_parser_and_refuses_crafted_streams():
     """lrf_pack_unpack_qmf_factors (the decode side of liblrf_pack.so): the factors it inflates from the reference's own
     streams equal this module's Python container code; a stream that is not exactly the int8 / column layout its metadata

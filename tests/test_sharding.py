@@ -75,3 +75,29 @@ def test_shard_range_properties():
             spans = [shard_range(n, r, w) for r in range(w)]
             assert sum(hi - lo for lo, hi in spans) == n
             assert all(0 <= lo <= hi <= n for lo, hi in spans)
+
+
+def test_bench_without_a_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no RANK / WORLD_SIZE in the environment starts two child ranks before it imports
+    torch.  Without a GPU each rank stops at its "needs a GPU" assertion: two of them must show,
+    and the parent must return their failure."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["HIP_VISIBLE_DEVICES"] = ""  # also on a GPU box this test runs the no-GPU branch
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    err = p.stderr.decode(errors="replace")
+    assert p.returncode != 0
+    assert err.count("AssertionError: bench.py needs a GPU") == 2, err[-2000:]
+    assert p.stdout.decode().strip() == ""
+
+
+def test_bench_refuses_a_rank_count_that_differs_from_gpus():
+    import subprocess
+    import sys
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode != 0 and "WORLD_SIZE=1 but --gpus 2" in p.stderr.decode(errors="replace")
