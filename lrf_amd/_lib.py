@@ -616,14 +616,18 @@ _pipes = {}
 
 
 def pipe(device=None, slots=2, sub_batch=0) -> Pipe:
-    """The cached per-(device, slots, sub_batch) pipe of the calling process."""
+    """The cached pipe of the calling THREAD for (device, slots, sub_batch).  A Pipe is a per-(host thread, device) object
+    (its slot buffers, submission cursor and sign table are not locked, and ctypes releases the GIL inside its calls), so
+    two Python threads encoding at once each get a pipe of their own."""
+    import threading
+
     import torch
     if not torch.cuda.is_available():
         raise LrfError("lrf_amd needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU fallback")
     if device is None:
         device = torch.cuda.current_device()
     device = torch.device("cuda", device).index if not isinstance(device, int) else device
-    key = (device, int(slots), int(sub_batch))
+    key = (threading.get_ident(), device, int(slots), int(sub_batch))
     with _lock:
         p = _pipes.get(key)
     if p is None:

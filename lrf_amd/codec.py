@@ -497,6 +497,14 @@ def _factors_native(streams: Sequence[bytes]):
         return None
     dims = _lib.plane_dims(int(H), int(W))
     B = len(streams)
+    # the metadata is untrusted and nothing of the payload has been validated yet: a deflate stream expands by at most
+    # ~1032x, so a stream that claims more factor bytes than its payload could inflate to is refused before the buffers
+    # it asks for are allocated (the Python parser then names the defect, or raises the same way)
+    need = sum(d[4] * r for d, r in zip(dims, ranks)) + 64 * sum(ranks)
+    if any(need > 1040 * len(b) + 4096 for b in blobs):
+        return None
+    for m in metas:  # what reaches the kernels is the validated integer form, not the raw JSON values
+        m["rank"] = list(ranks)
     U = np.empty((B, sum(d[4] * r for d, r in zip(dims, ranks))), dtype=np.int8)
     V = np.empty((B, 64 * sum(ranks)), dtype=np.int8)
     ptrs = (ctypes.c_char_p * B)(*blobs)

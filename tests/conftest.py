@@ -16,12 +16,28 @@ def pytest_configure(config):
 
 
 def _gpu_usable():
+    """Is there an AMD GPU to run the gpu-marked tests on?  Asked WITHOUT any HIP / torch.cuda call: the two-rank tests
+    start child processes from a parent that must not have initialised the GPU runtime, and torch.cuda.device_count()
+    may fall back to hipGetDeviceCount (which does).  The kernel driver's device node and its topology say enough."""
     try:
-        import torch
         from lrf_amd import _lib
-        # device_count() does not initialise the GPU in this process (is_available() would): the two-rank test starts its
-        # child processes from a parent that has not touched the GPU yet
-        return torch.cuda.device_count() > 0 and os.path.exists(_lib.LIB_PATH)
+        if not os.path.exists(_lib.LIB_PATH) or not os.path.exists("/dev/kfd"):
+            return False
+        if os.environ.get("HIP_VISIBLE_DEVICES") == "" or os.environ.get("CUDA_VISIBLE_DEVICES") == "":
+            return False
+        if not os.access("/dev/kfd", os.R_OK | os.W_OK):
+            return False
+        nodes = "/sys/class/kfd/kfd/topology/nodes"
+        if not os.path.isdir(nodes):
+            return True  # a driver without the topology tree: the device node is all there is to ask
+        for n in os.listdir(nodes):
+            try:
+                props = dict(ln.split(None, 1) for ln in open(os.path.join(nodes, n, "properties")).read().splitlines() if " " in ln)
+            except OSError:
+                continue
+            if int(props.get("simd_count", "0")) > 0:  # CPU nodes have simd_count 0
+                return True
+        return False
     except Exception:
         return False
 
