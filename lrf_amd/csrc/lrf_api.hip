@@ -20,6 +20,7 @@
 #include "lrf_bigrank_kernels.hip"
 #include "lrf_midrank_kernels.hip"
 #include "lrf_bcdw_kernel.hip"
+#include "lrf_bcdw16_kernel.hip"
 #include "lrf_anyshape_kernels.hip"
 
 // the planes qmf_encode forms hold YCbCr samples, 0 or in [0.114, 255.5]: all below 2^8 and exact on the grid 2^(8-35)
@@ -28,6 +29,7 @@
 // largest rank of the 64-column BCD kernels (k_bcd_w <= 8, k_bcd <= 16, k_bcd_mid <= 32); above it the any-shape kernels iterate
 #define LRF_BIG_TO_ANY_RANK 32
 #define LRF_BCDW_MIN_BLOCKS 1024 // smaller rank <= 8 runs iterate on the workgroup kernel k_bcd (run_bcd)
+#define LRF_BCDW16_MIN_BLOCKS 1024 // likewise for rank <= 16 runs and k_bcd_w16
 
 static thread_local char g_err[512] = "";
 
@@ -463,6 +465,7 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
         HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_w<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LRF_BCDW_LDS));
         HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_w<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LRF_BCDW_LDS));
         HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_w<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LRF_BCDW_LDS));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_w16, hipFuncAttributeMaxDynamicSharedMemorySize, LRF_BCDW16_LDS));
         c->attr_done |= 1u << 1;
     }
     if (!(c->attr_done & (1u << 2))) {
@@ -486,6 +489,7 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
     // 17..32 (k_bcd_mid) replace the reference's dependent chain by independent fmas, bit for bit
     const long mx_b = abs(lo) > abs(hi) ? abs(lo) : abs(hi);
     static const bool exact_off = getenv("LRF_GENERIC_GS") && getenv("LRF_GENERIC_GS")[0] == '1'; // developer comparison aid
+    static const long w16_min = getenv("LRF_BCDW16_MIN_BLOCKS") ? atol(getenv("LRF_BCDW16_MIN_BLOCKS")) : LRF_BCDW16_MIN_BLOCKS; // developer aid
     for (int it = 0; it < K; it++) {
         {
             Prof p(c, LRF_K_BCD);
@@ -517,6 +521,10 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
                     if (mode == 1) LRF_LAUNCH_WG(1, 8);
                     else if (mode == 2) LRF_LAUNCH_WG(2, 8);
                     else LRF_LAUNCH_WG(0, 8);
+                } else if (mode == 0 && wave_variant && gpr.exact_int && nbr >= w16_min) {
+                    // ranks 9..16 (and the lower-rank planes of such a run), iterations >= 2, exact-integer bounds
+                    hipLaunchKernelGGL(k_bcd_w16, dim3((nbr + LRF_BCDW16_WAVES - 1) / LRF_BCDW16_WAVES), dim3(64 * LRF_BCDW16_WAVES),
+                                       LRF_BCDW16_LDS, c->stream, X, pl, blr, (const float*)fb.vf, (const float*)fb.bf, U, fb.pp, fb.qp, gpr, nbr);
                 } else {
                     if (mode == 1) LRF_LAUNCH_WG(1, 16);
                     else if (mode == 2) LRF_LAUNCH_WG(2, 16);

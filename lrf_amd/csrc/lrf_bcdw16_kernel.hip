@@ -1,0 +1,309 @@
+// lrf_bcdw16_kernel.hip — k_bcd_w16: the BCD half-iteration (U update + partials of the V update) of iterations >= 2 for
+// ranks up to 16 with one *wave* per (matrix, 384-row block) and no workgroup barrier — k_bcd_w's shape for the rank
+// family 9..16 (lrf/factorization/qmf.py:93-126, 128-139).  Included by lrf_api.hip after lrf_bcdw_kernel.hip.
+//
+// What differs from k_bcd_w (ranks <= 8):
+//   * a = x V runs on the matrix cores: at ranks above 8 the 16-wide f32 MFMA tile is mostly used, and 64 fmas per row and
+//     rank column on the VALU (1024 at R = 16) would make the vector ALU the bound.  a^T = V^T X^T: V is the A operand,
+//     resident in 16 VGPRs; the B operand X[16T + li][4s + lq] is read from the wave's LDS tile with one ds_read_b32 per
+//     MFMA (conflict-free in the tile's XOR swizzle); four independent chains (one per 16 rows) of 16 MFMAs, each the
+//     k-ordered fma chain of the reference's sgemm.  The four D tiles become lane = row with 16 v_permlane swaps.
+//   * the Gauss-Seidel is the EXACT-INTEGER form (gsx_s / gsx_p, lrf_kernels.hip): from the second iteration on u and b
+//     are integers and every partial sum of `uu @ bb` stays below 2^24 for the bounds this kernel is launched with (host
+//     check (R-1) 64 mx^3 < 2^24), so the order of that sum is immaterial and the reference's dependent chain per column
+//     becomes R (R-1) independent fmas; the symmetric b table sits in 17 VGPRs behind DPP row_newbcast.  Bit-identical.
+//   * the new row is kept as int8 in LDS (1 KB per wave; the packed dwords are what goes to global memory anyway) and
+//     widened by the reads of the MFMA operand (ds_read_i8 + v_cvt): 17 KB of LDS per wave, two waves per SIMD.
+//   * b' = u^T u is a full 16 x 16 tile (16 MFMAs per sub-tile).
+// The first iteration (float old U, the reference's ordered chain) and bounds outside the exact range stay on k_bcd<., 16>.
+
+#define LRF_BCDW16_WAVES 4
+#define LRF_BCDW16_WAVE_LDS (64 * 64 * 4 + 64 * 16)
+#define LRF_BCDW16_LDS (LRF_BCDW16_WAVES * LRF_BCDW16_WAVE_LDS)
+
+// acc[T][i] (lane (li, lq)) = a[16T + li][4lq + i]  ->  out[4j + i] (lane L) = a[L][4j + i]
+__device__ __forceinline__ void w16_tiles_to_rows(const f32x4 (&acc)[4], float (&out)[16])
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        unsigned t0 = __float_as_uint(acc[0][i]), t1 = __float_as_uint(acc[1][i]);
+        unsigned t2 = __float_as_uint(acc[2][i]), t3 = __float_as_uint(acc[3][i]);
+        auto s01 = __builtin_amdgcn_permlane16_swap(t0, t1, false, false);
+        auto s23 = __builtin_amdgcn_permlane16_swap(t2, t3, false, false);
+        auto s02 = __builtin_amdgcn_permlane32_swap(s01[0], s23[0], false, false);
+        auto s13 = __builtin_amdgcn_permlane32_swap(s01[1], s23[1], false, false);
+        out[i] = __uint_as_float(s02[0]);
+        out[4 + i] = __uint_as_float(s13[0]);
+        out[8 + i] = __uint_as_float(s02[1]);
+        out[12 + i] = __uint_as_float(s13[1]);
+    }
+}
+
+// The int8 row of R bytes as ceil(R/4) dwords (bytes past R are zero), all in registers (uint4 by value: arrays of
+// dwords merged through the rank switch ended up in scratch memory).  R >= 4: dword d comes from offset min(4d, R-4)
+// (unaligned, the last one overlapping its predecessor); R < 4: byte loads (a dword would leave the row's allocation).
+template <int R>
+__device__ __forceinline__ uint4 w16_load_row(const int8_t* up)
+{
+    uint4 w = make_uint4(0u, 0u, 0u, 0u);
+    if constexpr (R < 4) {
+        unsigned v = (uint8_t)up[0];
+        if constexpr (R > 1) v |= (unsigned)(uint8_t)up[R > 1 ? 1 : 0] << 8;
+        if constexpr (R > 2) v |= (unsigned)(uint8_t)up[R > 2 ? 2 : 0] << 16;
+        w.x = v;
+    } else {
+        w.x = *reinterpret_cast<const u32_unaligned*>(up);
+        if constexpr (R > 4) w.y = *reinterpret_cast<const u32_unaligned*>(up + (R >= 8 ? 4 : R - 4));
+        if constexpr (R > 8) w.z = *reinterpret_cast<const u32_unaligned*>(up + (R >= 12 ? 8 : R - 4));
+        if constexpr (R > 12) w.w = *reinterpret_cast<const u32_unaligned*>(up + (R >= 16 ? 12 : R - 4));
+    }
+    return w;
+}
+// what w16_load_row fetched -> bytes 4d .. 4d+3 of the row in dword d, zero past the row's end: the partial last dword
+// was loaded from offset R - 4, so byte 4d of the row sits at index 4 - (R & 3) of it
+template <int R>
+__device__ __forceinline__ uint4 w16_align_row(uint4 w)
+{
+    if constexpr (R >= 4 && (R & 3) != 0) {
+        constexpr int sh = 8 * (4 - (R & 3));
+        if constexpr (R / 4 == 1) w.y >>= sh;
+        if constexpr (R / 4 == 2) w.z >>= sh;
+        if constexpr (R / 4 == 3) w.w >>= sh;
+    }
+    return w;
+}
+template <int R>
+__device__ __forceinline__ void w16_store_row(int8_t* uo, const uint4 w)
+{
+    if constexpr (R < 4) {
+        uo[0] = (int8_t)w.x;
+        if constexpr (R > 1) uo[1] = (int8_t)(w.x >> 8);
+        if constexpr (R > 2) uo[2] = (int8_t)(w.x >> 16);
+    } else {
+        *reinterpret_cast<u32_unaligned*>(uo) = w.x;
+        if constexpr (R >= 8) *reinterpret_cast<u32_unaligned*>(uo + 4) = w.y;
+        if constexpr (R >= 12) *reinterpret_cast<u32_unaligned*>(uo + 8) = w.z;
+        if constexpr (R >= 16) *reinterpret_cast<u32_unaligned*>(uo + 12) = w.w;
+        if constexpr ((R & 3) != 0) { // bytes R-4 .. R-1: the tail of the last full dword and the head of the partial one
+            const unsigned lo = R / 4 == 1 ? w.x : (R / 4 == 2 ? w.y : w.z), hi = R / 4 == 1 ? w.y : (R / 4 == 2 ? w.z : w.w);
+            *reinterpret_cast<u32_unaligned*>(uo + R - 4) = __builtin_amdgcn_alignbyte(hi, lo, R & 3);
+        }
+    }
+}
+
+// One row: old int8 row (as loaded) and a = x V -> new int8 row (bytes past R zero).  Every lane of the wave must be
+// active (the table operands are DPP broadcasts out of other lanes' registers).
+template <int R>
+__device__ __forceinline__ uint4 w16_row(const float (&a16)[16], const uint4 wload, const float (&tabv)[17], const GsParams& gp)
+{
+    const uint4 wo = w16_align_row<R>(wload);
+    float a[R], u0[R], u[R], T[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const unsigned word = (r >> 2) == 0 ? wo.x : ((r >> 2) == 1 ? wo.y : ((r >> 2) == 2 ? wo.z : wo.w));
+        a[r] = a16[r];
+        u0[r] = (float)(int)(int8_t)(word >> (8 * (r & 3)));
+        u[r] = u0[r];
+        T[r] = 0.f;
+    }
+    gsx_s<R, 1>(T, tabv, u0);
+    const float rdenv = tabv[16]; // lane l: 1 / den[l & 15]
+    if (__any(gsx_p<R, 0, true>(T, tabv, rdenv, a, u, gp))) { // rare: repeat with the reference's IEEE division
+#pragma unroll
+        for (int r = 0; r < R; r++) T[r] = 0.f;
+        gsx_s<R, 1>(T, tabv, u0);
+        gsx_p<R, 0, false>(T, tabv, rdenv, a, u, gp);
+    }
+    unsigned o[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int r = 0; r < R; r++) o[r >> 2] |= ((unsigned)(int)u[r] & 0xffu) << (8 * (r & 3));
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+__global__ __launch_bounds__(64 * LRF_BCDW16_WAVES) void k_bcd_w16(const float* __restrict__ X, const PlaneDesc* __restrict__ planes,
+                                                                  const BlockDesc* __restrict__ blocks, const float* __restrict__ Vf,
+                                                                  const float* __restrict__ Bf, int8_t* __restrict__ U,
+                                                                  float* __restrict__ Ppart, float* __restrict__ Qpart, GsParams gp,
+                                                                  int nblocks)
+{
+    extern __shared__ __attribute__((aligned(16))) float bcdw16_lds[]; // LRF_BCDW16_LDS bytes, per wave: X tile, then int8 u
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int blk = blockIdx.x * LRF_BCDW16_WAVES + wave;
+    if (blk >= nblocks) return; // the waves of a workgroup never synchronise with each other
+    float* Xs = reinterpret_cast<float*>(reinterpret_cast<char*>(bcdw16_lds) + wave * LRF_BCDW16_WAVE_LDS);
+    int8_t* us8 = reinterpret_cast<int8_t*>(Xs + 64 * 64);
+    const BlockDesc bd = blocks[blk];
+    const PlaneDesc pd = planes[bd.plane];
+    const int R = pd.R;
+    const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
+    const float* Xp = X + pd.x_off + (long)bd.row0 * 64;
+    const float* Vp = Vf + (long)bd.plane * 64 * LRF_RP;
+    const float* gt = Bf + (long)bd.plane * LRF_GT_STRIDE;
+    int8_t* Ub = U + pd.u_off + (long)bd.row0 * R;
+    int nrows = pd.M - bd.row0;
+    if (nrows > LRF_KC) nrows = LRF_KC;
+    const int nsub = (nrows + 63) >> 6;
+
+    // A operand of a^T = V^T X^T, resident: va[s] = V[4s + lq][li] (columns >= R of the table are zero)
+    float va[16];
+#pragma unroll
+    for (int s = 0; s < 16; s++) va[s] = Vp[(4 * s + lq) * LRF_RP + li];
+    // the symmetric b table of the exact Gauss-Seidel: tabv[j], lane l = b[j][l & 15] (diagonal: den); [16]: 1 / den
+    float tabv[17];
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+        tabv[j] = (j < R && li < R) ? ((j == li) ? gt[li * LRF_GT_LD + LRF_GT_DEN] : gt[li * LRF_GT_LD + (j < li ? j : j - 1)]) : 0.f;
+    tabv[16] = (li < R) ? gt[li * LRF_GT_LD + LRF_GT_RDEN] : 0.f;
+
+    // prefetch registers: xq[T][q] = X[r0 + 16T + 4q + lq][4li .. +3] (each load instruction: four whole rows, 1 KB);
+    // upre = the old int8 row of this lane (w16_load_row).  Rows past the end of the block are clamped to its last row.
+    f32x4 xq[4][4];
+    uint4 upre;
+    auto issue_x = [&](int t, int T0, int T1) {
+        const int r0 = t * 64;
+#pragma unroll
+        for (int T = T0; T < T1; T++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                int row = r0 + 16 * T + 4 * q + lq;
+                row = row < nrows ? row : nrows - 1;
+                xq[T][q] = *reinterpret_cast<const f32x4*>(Xp + (long)row * 64 + 4 * li);
+            }
+        }
+    };
+    auto issue_u = [&](int t) {
+        int row = t * 64 + lane;
+        row = row < nrows ? row : nrows - 1;
+        const int8_t* up = Ub + (long)row * R;
+        switch (R) {
+#define LRF_CASE(r) case r: upre = w16_load_row<r>(up); break;
+            LRF_CASE(1) LRF_CASE(2) LRF_CASE(3) LRF_CASE(4) LRF_CASE(5) LRF_CASE(6) LRF_CASE(7) LRF_CASE(8)
+            LRF_CASE(9) LRF_CASE(10) LRF_CASE(11) LRF_CASE(12) LRF_CASE(13) LRF_CASE(14) LRF_CASE(15)
+#undef LRF_CASE
+        default: upre = w16_load_row<16>(up); break;
+        }
+    };
+
+    // B operand of a^T: X[16T + li][4s + lq] lives at byte (16T + li) * 256 + ((16 s) ^ (16 li)) + 4 lq of the tile
+    const char* xrow_b = reinterpret_cast<const char*>(Xs) + li * 256 + 4 * lq;
+    const int g16 = 16 * li;
+    // A operand of a' = X^T u, all four column tiles at once: chunk li of row 4s + lq (k_bcd_w)
+    const float* xp[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) xp[e] = &Xs[lq * 64 + 4 * (li ^ (4 * e + lq))];
+    // B operand of a' = X^T u and both operands of b' = u^T u: u[4s + lq][li], a byte of the int8 tile
+    const int8_t* ub8 = us8 + lq * 16 + li;
+
+    f32x4 accP[4], accQ = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; c++) accP[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    issue_x(0, 0, 4);
+    issue_u(0);
+    for (int t = 0; t < nsub; t++) {
+        const int r0 = t * 64;
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- 1. sub-tile -> LDS, next sub-tile's loads into the same registers (three bursts, as in k_bcd_w)
+#pragma unroll
+        for (int T = 0; T < 4; T++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int m = 16 * T + 4 * q + lq;
+                *reinterpret_cast<f32x4*>(&Xs[m * 64 + 4 * (li ^ (4 * q + lq))]) = xq[T][q];
+            }
+        uint4 w = upre;
+        const int tn = t + 1;
+        const bool more = tn < nsub;
+        if (more) {
+            issue_x(tn, 0, 2);
+            issue_u(tn);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- 2. a^T = V^T X^T: four independent chains of 16 MFMAs
+        float a[16];
+        {
+            f32x4 acc[4];
+#pragma unroll
+            for (int T = 0; T < 4; T++) acc[T] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int h = 0; h < 2; h++) { // the operand reads in two halves of 32 registers
+                float bx[8][4];
+#pragma unroll
+                for (int s = 0; s < 8; s++)
+#pragma unroll
+                    for (int T = 0; T < 4; T++)
+                        bx[s][T] = *reinterpret_cast<const float*>(xrow_b + T * 16 * 256 + ((16 * (8 * h + s)) ^ g16));
+#pragma unroll
+                for (int s = 0; s < 8; s++)
+#pragma unroll
+                    for (int T = 0; T < 4; T++) acc[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[8 * h + s], bx[s][T], acc[T], 0, 0, 0);
+            }
+            w16_tiles_to_rows(acc, a);
+        }
+        if (more) issue_x(tn, 2, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- 3. exact-integer Gauss-Seidel in registers: w = old int8 row in, new int8 row out
+        switch (R) {
+#define LRF_CASE(r) case r: w = w16_row<r>(a, w, tabv, gp); break;
+            LRF_CASE(1) LRF_CASE(2) LRF_CASE(3) LRF_CASE(4) LRF_CASE(5) LRF_CASE(6) LRF_CASE(7) LRF_CASE(8)
+            LRF_CASE(9) LRF_CASE(10) LRF_CASE(11) LRF_CASE(12) LRF_CASE(13) LRF_CASE(14) LRF_CASE(15)
+#undef LRF_CASE
+        default: w = w16_row<16>(a, w, tabv, gp); break;
+        }
+        const int row = r0 + lane;
+        if (row >= nrows) w = make_uint4(0u, 0u, 0u, 0u);
+        if (more) issue_x(tn, 3, 4);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- 4. the int8 row to LDS (operand of the partial products) and to global memory
+        *reinterpret_cast<uint4*>(us8 + lane * 16) = w;
+        if (row < nrows) {
+            int8_t* uo = Ub + (long)row * R;
+            switch (R) {
+#define LRF_CASE(r) case r: w16_store_row<r>(uo, w); break;
+                LRF_CASE(1) LRF_CASE(2) LRF_CASE(3) LRF_CASE(4) LRF_CASE(5) LRF_CASE(6) LRF_CASE(7) LRF_CASE(8)
+                LRF_CASE(9) LRF_CASE(10) LRF_CASE(11) LRF_CASE(12) LRF_CASE(13) LRF_CASE(14) LRF_CASE(15)
+#undef LRF_CASE
+            default: w16_store_row<16>(uo, w); break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- 5. a' += X^T u (four strided column tiles per LDS read), b' += u^T u
+        float pu[16];
+#pragma unroll
+        for (int s = 0; s < 16; s++) pu[s] = (float)(int)ub8[64 * s];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            f32x4 px[8];
+#pragma unroll
+            for (int s = 0; s < 8; s++) px[s] = *reinterpret_cast<const f32x4*>(xp[s & 3] + 256 * (8 * h + s));
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) accP[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(px[s][c], pu[8 * h + s], accP[c], 0, 0, 0);
+                accQ = __builtin_amdgcn_mfma_f32_16x16x4f32(pu[8 * h + s], pu[8 * h + s], accQ, 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // a' partial: tile c holds the columns 4 i + c: D[i = 4*lq + reg][j = li (r)] -> a'[4 i + c][r]
+    const long slot = (long)pd.blk0 + bd.blk;
+    float* Pp = Ppart + slot * 64 * LRF_RP;
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) Pp[(4 * (4 * lq + reg) + c) * LRF_RP + li] = accP[c][reg];
+    // b' partial: D[i = 4*lq + reg][j = li], exact integers
+    float* Qp = Qpart + slot * LRF_RP * LRF_RP;
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) Qp[(4 * lq + reg) * LRF_RP + li] = accQ[reg];
+}
