@@ -284,6 +284,7 @@ static int table_rp(const Tables& t) { return table_rmax(t) <= 16 ? 16 : LRF_RPB
 // the second table set (vf16 ...): the regions of the two pitches would overlap in one buffer.
 struct FamRun {
     int plane0, nplanes, block0, nblocks, rmax, fam, pitch;
+    bool any_native; // some plane of the run is small enough for ATen's native order of `uu @ bb` ((R-1) M < 400)
 };
 static int fam_of_rank(int R) { return R <= 8 ? 0 : (R <= 16 ? 1 : 2); }
 static bool bcd_wave_variant()
@@ -301,8 +302,9 @@ static std::vector<FamRun> plan_runs(const Tables& t)
     for (int p = 0; p < (int)t.planes.size(); p++) {
         const PlaneDesc& pd = t.planes[p];
         const int fam = split ? fam_of_rank(pd.R) : (rmax_t > 16 ? 2 : fam_of_rank(rmax_t));
-        if (runs.empty() || runs.back().fam != fam) runs.push_back(FamRun{p, 0, pd.blk0, 0, 1, fam, fam == 2 ? LRF_RPB : 16});
+        if (runs.empty() || runs.back().fam != fam) runs.push_back(FamRun{p, 0, pd.blk0, 0, 1, fam, fam == 2 ? LRF_RPB : 16, false});
         FamRun& r = runs.back();
+        r.any_native = r.any_native || pd.native_t2_u != 0;
         r.nplanes++;
         r.nblocks += pd.nblk;
         r.rmax = pd.R > r.rmax ? pd.R : r.rmax;
@@ -465,7 +467,8 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
         HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_w<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LRF_BCDW_LDS));
         HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_w<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LRF_BCDW_LDS));
         HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_w<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LRF_BCDW_LDS));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_w16, hipFuncAttributeMaxDynamicSharedMemorySize, LRF_BCDW16_LDS));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_w16<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LRF_BCDW16_LDS));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_w16<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LRF_BCDW16_LDS));
         c->attr_done |= 1u << 1;
     }
     if (!(c->attr_done & (1u << 2))) {
@@ -521,10 +524,15 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
                     if (mode == 1) LRF_LAUNCH_WG(1, 8);
                     else if (mode == 2) LRF_LAUNCH_WG(2, 8);
                     else LRF_LAUNCH_WG(0, 8);
-                } else if (mode == 0 && wave_variant && gpr.exact_int && nbr >= w16_min) {
-                    // ranks 9..16 (and the lower-rank planes of such a run), iterations >= 2, exact-integer bounds
-                    hipLaunchKernelGGL(k_bcd_w16, dim3((nbr + LRF_BCDW16_WAVES - 1) / LRF_BCDW16_WAVES), dim3(64 * LRF_BCDW16_WAVES),
-                                       LRF_BCDW16_LDS, c->stream, X, pl, blr, (const float*)fb.vf, (const float*)fb.bf, U, fb.pp, fb.qp, gpr, nbr);
+                } else if (wave_variant && nbr >= w16_min && ((mode == 0 && gpr.exact_int) || (mode == 1 && !r.any_native))) {
+                    // ranks 9..16 (and the lower-rank planes of such a run): iterations >= 2 with exact-integer bounds, and
+                    // the first iteration from the initialisation's W0 unless a plane is small enough for ATen's native order
+#define LRF_LAUNCH_W16(MODE)                                                                                         \
+    hipLaunchKernelGGL((k_bcd_w16<MODE>), dim3((nbr + LRF_BCDW16_WAVES - 1) / LRF_BCDW16_WAVES), dim3(64 * LRF_BCDW16_WAVES), LRF_BCDW16_LDS, \
+                       c->stream, X, pl, blr, (const float*)fb.vf, (const float*)fb.wf, (const float*)fb.bf, U, fb.pp, fb.qp, gpr, nbr)
+                    if (mode == 1) LRF_LAUNCH_W16(1);
+                    else LRF_LAUNCH_W16(0);
+#undef LRF_LAUNCH_W16
                 } else {
                     if (mode == 1) LRF_LAUNCH_WG(1, 16);
                     else if (mode == 2) LRF_LAUNCH_WG(2, 16);

@@ -15,7 +15,11 @@
 //   * the new row is kept as int8 in LDS (1 KB per wave; the packed dwords are what goes to global memory anyway) and
 //     widened by the reads of the MFMA operand (ds_read_i8 + v_cvt): 17 KB of LDS per wave, two waves per SIMD.
 //   * b' = u^T u is a full 16 x 16 tile (16 MFMAs per sub-tile).
-// The first iteration (float old U, the reference's ordered chain) and bounds outside the exact range stay on k_bcd<., 16>.
+// MODE 0: iterations >= 2 (old U from int8, exact-integer Gauss-Seidel: launched only for bounds inside the exact range).
+// MODE 1: the first iteration — old U = X @ W0 computed here by a second set of MFMA chains (float values, so the
+// Gauss-Seidel is the reference's ordered chain, gs16_* below: `uu @ bb` in MKL's single-column order with the table
+// operands broadcast from the same 17 VGPRs); any bounds.  Runs with a plane small enough for ATen's native order
+// ((R-1) M < 400) and MODE 2 (caller's fp32 U0) stay on the workgroup kernel k_bcd<., 16>.
 
 #define LRF_BCDW16_WAVES 4
 #define LRF_BCDW16_WAVE_LDS (64 * 64 * 4 + 64 * 16)
@@ -120,9 +124,89 @@ __device__ __forceinline__ uint4 w16_row(const float (&a16)[16], const uint4 wlo
     return make_uint4(o[0], o[1], o[2], o[3]);
 }
 
+// ---- the reference's ordered Gauss-Seidel (first iteration: float old U) on the symmetric table in VGPRs ----------
+// tabv[j], lane l = b[j][l & 15] (diagonal: den), so b[j][RR] is lane RR of tabv[j]: a DPP row_newbcast operand.
+template <int RR>
+__device__ __forceinline__ float gs16_mul(float tab, float x)
+{
+    float out;
+    asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(out) : "v"(tab), "v"(x), "n"(RR));
+    return out;
+}
+// column index of the k-th "other" column of column RR (increasing order, RR skipped)
+template <int RR>
+__device__ __forceinline__ constexpr int gs16_col(int k) { return k < RR ? k : k + 1; }
+// uu . bb for column RR in the order of oracle/lrf_oracle.c dot_mkl_n1 (K = R - 1 >= 2 terms):
+// ((fma(u1, b1, u0 b0) + p_last_odd + ... + p3) + (p2 + p4 + ...)); K == 1: the product; K == 0: nothing
+template <int R, int RR>
+__device__ __forceinline__ float gs16_term2(const float (&u)[R], const float (&tabv)[17])
+{
+    constexpr int K = R - 1;
+    if constexpr (K == 0) return 0.f;
+    else if constexpr (K == 1) return gs16_mul<RR>(tabv[gs16_col<RR>(0)], u[gs16_col<RR>(0)]);
+    else {
+        float odd = gs16_mul<RR>(tabv[gs16_col<RR>(0)], u[gs16_col<RR>(0)]);
+        asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+            : "+v"(odd) : "v"(tabv[gs16_col<RR>(1)]), "v"(u[gs16_col<RR>(1)]), "n"(RR));
+        constexpr int last_odd = ((K - 1) & 1) ? K - 1 : K - 2;
+#pragma unroll
+        for (int k = last_odd; k >= 3; k -= 2) odd = odd + gs16_mul<RR>(tabv[gs16_col<RR>(k)], u[gs16_col<RR>(k)]);
+        if constexpr (K < 3) return odd;
+        else {
+            float even = gs16_mul<RR>(tabv[gs16_col<RR>(2)], u[gs16_col<RR>(2)]);
+#pragma unroll
+            for (int k = 4; k < K; k += 2) even = even + gs16_mul<RR>(tabv[gs16_col<RR>(k)], u[gs16_col<RR>(k)]);
+            return odd + even;
+        }
+    }
+}
+template <int R, int RR, bool EXACT>
+__device__ __forceinline__ bool gs16_cols(const float (&a)[R], float (&u)[R], const float (&tabv)[17], const GsParams& gp)
+{
+    if constexpr (RR < R) {
+        const float num = (a[RR] - gs16_term2<R, RR>(u, tabv)) + LRF_EPS;
+        float val;
+        bool unsafe = false;
+        if (EXACT) {
+            val = rintf(num / get_bc16<RR>(tabv[RR]));
+        } else {
+            const float q = gs16_mul<RR>(tabv[16], num);
+            const float nq = rintf(q);
+            const bool inside = fabsf(q) < gp.flimit;
+            unsafe = inside && !(fabsf(q - nq) <= gp.fthr);
+            val = inside ? nq : q;
+        }
+        u[RR] = fminf(fmaxf(val, gp.lo), gp.hi);
+        return gs16_cols<R, RR + 1, EXACT>(a, u, tabv, gp) || unsafe;
+    } else {
+        return false;
+    }
+}
+// first iteration of one row: a = x V, old u = x W0 (floats) -> new int8 row
+template <int R>
+__device__ __forceinline__ uint4 w16_row_first(const float (&a16)[16], const float (&u16)[16], const float (&tabv)[17], const GsParams& gp)
+{
+    float a[R], u[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        a[r] = a16[r];
+        u[r] = u16[r];
+    }
+    if (__any(gs16_cols<R, 0, false>(a, u, tabv, gp))) { // rare: repeat with the reference's IEEE division
+#pragma unroll
+        for (int r = 0; r < R; r++) u[r] = u16[r];
+        gs16_cols<R, 0, true>(a, u, tabv, gp);
+    }
+    unsigned o[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int r = 0; r < R; r++) o[r >> 2] |= ((unsigned)(int)u[r] & 0xffu) << (8 * (r & 3));
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+template <int MODE>
 __global__ __launch_bounds__(64 * LRF_BCDW16_WAVES) void k_bcd_w16(const float* __restrict__ X, const PlaneDesc* __restrict__ planes,
                                                                   const BlockDesc* __restrict__ blocks, const float* __restrict__ Vf,
-                                                                  const float* __restrict__ Bf, int8_t* __restrict__ U,
+                                                                  const float* __restrict__ Wf, const float* __restrict__ Bf, int8_t* __restrict__ U,
                                                                   float* __restrict__ Ppart, float* __restrict__ Qpart, GsParams gp,
                                                                   int nblocks)
 {
@@ -146,9 +230,12 @@ __global__ __launch_bounds__(64 * LRF_BCDW16_WAVES) void k_bcd_w16(const float* 
     const int nsub = (nrows + 63) >> 6;
 
     // A operand of a^T = V^T X^T, resident: va[s] = V[4s + lq][li] (columns >= R of the table are zero)
-    float va[16];
+    float va[16], wa[MODE == 1 ? 16 : 1];
 #pragma unroll
-    for (int s = 0; s < 16; s++) va[s] = Vp[(4 * s + lq) * LRF_RP + li];
+    for (int s = 0; s < 16; s++) {
+        va[s] = Vp[(4 * s + lq) * LRF_RP + li];
+        if (MODE == 1) wa[s] = Wf[(long)bd.plane * 64 * LRF_RP + (4 * s + lq) * LRF_RP + li];
+    }
     // the symmetric b table of the exact Gauss-Seidel: tabv[j], lane l = b[j][l & 15] (diagonal: den); [16]: 1 / den
     float tabv[17];
 #pragma unroll
@@ -159,7 +246,7 @@ __global__ __launch_bounds__(64 * LRF_BCDW16_WAVES) void k_bcd_w16(const float* 
     // prefetch registers: xq[T][q] = X[r0 + 16T + 4q + lq][4li .. +3] (each load instruction: four whole rows, 1 KB);
     // upre = the old int8 row of this lane (w16_load_row).  Rows past the end of the block are clamped to its last row.
     f32x4 xq[4][4];
-    uint4 upre;
+    uint4 upre = make_uint4(0u, 0u, 0u, 0u);
     auto issue_x = [&](int t, int T0, int T1) {
         const int r0 = t * 64;
 #pragma unroll
@@ -173,6 +260,7 @@ __global__ __launch_bounds__(64 * LRF_BCDW16_WAVES) void k_bcd_w16(const float* 
         }
     };
     auto issue_u = [&](int t) {
+        if (MODE != 0) return;
         int row = t * 64 + lane;
         row = row < nrows ? row : nrows - 1;
         const int8_t* up = Ub + (long)row * R;
@@ -224,11 +312,14 @@ __global__ __launch_bounds__(64 * LRF_BCDW16_WAVES) void k_bcd_w16(const float* 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_sched_barrier(0);
         // ---- 2. a^T = V^T X^T: four independent chains of 16 MFMAs
-        float a[16];
+        float a[16], uf[MODE == 1 ? 16 : 1];
         {
-            f32x4 acc[4];
+            f32x4 acc[4], accw[MODE == 1 ? 4 : 1];
 #pragma unroll
-            for (int T = 0; T < 4; T++) acc[T] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int T = 0; T < 4; T++) {
+                acc[T] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (MODE == 1) accw[T] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
             for (int h = 0; h < 2; h++) { // the operand reads in two halves of 32 registers
                 float bx[8][4];
@@ -240,19 +331,23 @@ __global__ __launch_bounds__(64 * LRF_BCDW16_WAVES) void k_bcd_w16(const float* 
 #pragma unroll
                 for (int s = 0; s < 8; s++)
 #pragma unroll
-                    for (int T = 0; T < 4; T++) acc[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[8 * h + s], bx[s][T], acc[T], 0, 0, 0);
+                    for (int T = 0; T < 4; T++) {
+                        acc[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[8 * h + s], bx[s][T], acc[T], 0, 0, 0);
+                        if constexpr (MODE == 1) accw[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[8 * h + s], bx[s][T], accw[T], 0, 0, 0);
+                    }
             }
             w16_tiles_to_rows(acc, a);
+            if constexpr (MODE == 1) w16_tiles_to_rows(accw, uf);
         }
         if (more) issue_x(tn, 2, 3);
         __builtin_amdgcn_sched_barrier(0);
-        // ---- 3. exact-integer Gauss-Seidel in registers: w = old int8 row in, new int8 row out
+        // ---- 3. Gauss-Seidel in registers: w = old int8 row in (MODE 0, exact-integer form), new int8 row out
         switch (R) {
-#define LRF_CASE(r) case r: w = w16_row<r>(a, w, tabv, gp); break;
+#define LRF_CASE(r) case r: if constexpr (MODE == 1) w = w16_row_first<r>(a, uf, tabv, gp); else w = w16_row<r>(a, w, tabv, gp); break;
             LRF_CASE(1) LRF_CASE(2) LRF_CASE(3) LRF_CASE(4) LRF_CASE(5) LRF_CASE(6) LRF_CASE(7) LRF_CASE(8)
             LRF_CASE(9) LRF_CASE(10) LRF_CASE(11) LRF_CASE(12) LRF_CASE(13) LRF_CASE(14) LRF_CASE(15)
 #undef LRF_CASE
-        default: w = w16_row<16>(a, w, tabv, gp); break;
+        default: if constexpr (MODE == 1) w = w16_row_first<16>(a, uf, tabv, gp); else w = w16_row<16>(a, w, tabv, gp); break;
         }
         const int row = r0 + lane;
         if (row >= nrows) w = make_uint4(0u, 0u, 0u, 0u);

@@ -157,3 +157,29 @@ def test_mixed_rank_families_in_a_large_batch(oracle, ranks):
     got = split_factors(U[1].cpu().numpy(), V[1].cpu().numpy(), (512, 768), ranks)
     for a, b in zip(got, want):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("hw_b", [(173, 264, 272), (512, 768, 48)])
+def test_wave_kernel_for_ranks_9_to_16_equals_workgroup_kernel_and_oracle(oracle, hw_b):
+    """k_bcd_w16 (one wave per 384-row block; lrf_bcdw16_kernel.hip) takes a run of planes of ranks <= 16 once a call has 1024
+    blocks, the workgroup kernel k_bcd<., 16> below that: 272 ragged 173x264 images (4 blocks each, the last sub-tile of a
+    block 22 rows) and 48 images of 512x768 (24 blocks each) against chunks of 8 of the same images, bit for bit, and
+    against the oracle on one image; every rank 1..16 appears in some plane, with the default and a narrow asymmetric bound."""
+    import lrf_amd
+    from lrf_amd.codec import split_factors
+    H, W, B = hw_b
+    g = torch.Generator().manual_seed(5)
+    base = torch.rand(B, 3, H // 8, W // 8, generator=g) * 255
+    imgs = (torch.nn.functional.interpolate(base, size=(H, W), mode="bilinear", align_corners=False)
+            + torch.randn(B, 3, H, W, generator=g) * 6).clamp(0, 255).to(torch.uint8).cuda()
+    for ranks, bounds in (((9, 1, 2), (-16, 15)), ((10, 3, 4), (-3, 5)), ((11, 5, 6), (-16, 15)), ((12, 7, 8), (-16, 15)),
+                          ((13, 14, 15), (-16, 15)), ((16, 16, 9), (-3, 5)), ((16, 8, 8), (-16, 15))):
+        U, V = lrf_amd.qmf_factorize_batch(imgs, ranks, num_iters=4, bounds=bounds)
+        for b0 in (0, B - 8):
+            Us, Vs = lrf_amd.qmf_factorize_batch(imgs[b0:b0 + 8].clone(), ranks, num_iters=4, bounds=bounds)
+            assert torch.equal(U[b0:b0 + 8], Us) and torch.equal(V[b0:b0 + 8], Vs), (ranks, bounds, b0)
+        X = oracle.rgb_to_planes(imgs[B - 1].cpu().numpy())
+        got = split_factors(U[B - 1].cpu().numpy(), V[B - 1].cpu().numpy(), (H, W), ranks)
+        for c in range(3):
+            u, v = oracle.qmf_decompose(X[c], ranks[c], 4, bounds)
+            assert np.array_equal(got[2 * c], u.astype(np.int8)) and np.array_equal(got[2 * c + 1], v.astype(np.int8)), (ranks, bounds, c)
