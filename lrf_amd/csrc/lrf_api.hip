@@ -770,7 +770,27 @@ int lrf_qmf_planes_from_rgb_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_
     if (H % 16 == 0 && W % 16 == 0 && (reinterpret_cast<uintptr_t>(rgb) & 7) == 0 && !no_tiled)
         hipLaunchKernelGGL(k_planes16, dim3((unsigned)((H / 16) * ((g.p[0].nw + 31) / 32)), (unsigned)B), dim3(256), 0, c->stream, rgb, (int)H,
                            (int)W, g, X);
-    else
+    else if (!no_tiled) {
+        // any other size: the same tiling over the padded planes (k_planes_strip); blocks dealt so that the strips of an image
+        // stay on one XCD (block index mod 8 is the XCD when the grid's x extent is a multiple of 8)
+        static const bool no_xcd = getenv("LRF_PLANES_NO_XCD") && getenv("LRF_PLANES_NO_XCD")[0] == '1'; // developer comparison aid
+        const int ncols = g.p[0].nw > 2 * g.p[1].nw ? g.p[0].nw : 2 * g.p[1].nw;
+        const int per_strip = (ncols + 31) / 32;
+        const int nstrips = (g.p[0].nh + 1) / 2 > g.p[1].nh ? (g.p[0].nh + 1) / 2 : g.p[1].nh;
+        const int nblk = nstrips * per_strip;
+        const int chunk = no_xcd ? 0 : (nblk + 7) / 8;
+        const dim3 grid((unsigned)(chunk ? 8 * chunk : nblk), (unsigned)B);
+#define LRF_LAUNCH_STRIP(KH, KW) \
+    hipLaunchKernelGGL((k_planes_strip<KH, KW>), grid, dim3(256), 0, c->stream, rgb, (int)H, (int)W, g, X, per_strip, nblk, chunk)
+        if (H & 1) {
+            if (W & 1) LRF_LAUNCH_STRIP(3, 3);
+            else LRF_LAUNCH_STRIP(3, 2);
+        } else {
+            if (W & 1) LRF_LAUNCH_STRIP(2, 3);
+            else LRF_LAUNCH_STRIP(2, 2);
+        }
+#undef LRF_LAUNCH_STRIP
+    } else
         hipLaunchKernelGGL(k_planes, dim3((unsigned)(g.p[1].pr0 + g.p[1].nh), (unsigned)B), dim3(256), 0, c->stream, rgb, (int)H,
                            (int)W, g, X);
     LAUNCH_CHECK();

@@ -260,6 +260,234 @@ __global__ __launch_bounds__(256) void k_planes16(const uint8_t* __restrict__ rg
     }
 }
 
+// K1 for every other size, in one pass over the image (CLIC-sized 1365 x 2048: the odd height means 3-row pooling windows,
+// one reflected luma row on top, two below, three reflected chroma rows on either side): k_planes16's tiling laid over the
+// PADDED planes.  A workgroup owns padded luma rows 16 s .. 16 s + 15 (two luma patch rows) and padded chroma rows
+// 8 s .. 8 s + 7 (one patch row of Cb and of Cr) of 32 luma patches' width; a thread takes a 2 x 8 block of padded luma
+// pixels and four padded chroma samples per plane, maps them to source rows / columns with the reflect rule and loads whole
+// 8-byte words wherever the eight source columns are not reflected (always, away from the left / right border).  The luma
+// and chroma windows of a workgroup overlap in all but the halo rows, so every source byte comes from HBM once and from
+// the cache otherwise; consecutive strips of an image run on the same XCD (lrf_api.hip maps the block index), which keeps
+// the halo rows in that XCD's L2.  Arithmetic and orders are k_planes' (ycc_of; row-major window sums from 0, / kh / kw).
+// k_planes (one workgroup per patch row, four-pixel items) read every byte twice with 4-byte loads and stays as the
+// reference implementation of the geometry (LRF_PLANES_NO_TILED=1).
+// x / 3 for 0 <= x < 2^14, correctly rounded (= the IEEE division the reference performs) in three instructions: with
+// c = RN(1/3), q0 = RN(x c), r = x - 3 q0 (exact, one fma), q = RN(q0 + r c) (Markstein).  Checked against x / 3.0f for
+// every float in [2^-20, 2^14) (285 M values, none differs; 0 maps to 0).  The generic division costs ten instructions.
+__device__ __forceinline__ float div3_exact(float x)
+{
+    const float c = 1.0f / 3.0f;
+    const float q0 = x * c;
+    const float r = fmaf(-3.0f, q0, x);
+    return fmaf(r, c, q0);
+}
+template <int K>
+__device__ __forceinline__ float div_win(float x) { return K == 2 ? x * 0.5f : div3_exact(x); }
+// byte j (0..7) of an 8-byte word held as two dwords -> float
+template <int J>
+__device__ __forceinline__ float byte_f(uint32_t lo, uint32_t hi) { return (float)(((J < 4 ? lo : hi) >> (8 * (J & 3))) & 255u); }
+// luma of one pixel: ycc_of(.., 0) without its `0.f + acc` (acc >= +0: the same bits)
+__device__ __forceinline__ float luma_of(float r, float g, float b)
+{
+    float acc = 0.299f * r; // = fmaf(0.299f, r, 0.f)
+    acc = fmaf(0.587f, g, acc);
+    return fmaf(0.114f, b, acc);
+}
+
+// sixteen luma samples of a 2 x 8 pixel block (channel words lo / hi = bytes 0..3 / 4..7 of each row) into the staging tile
+__device__ __forceinline__ void strip_luma(const uint32_t (&lo)[2][3], const uint32_t (&hi)[2][3], float* Lp, int rp)
+{
+    const int swz = (rp >> 1) & 3;
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+        const uint32_t r0 = lo[rr][0], g0 = lo[rr][1], b0 = lo[rr][2], r1 = hi[rr][0], g1 = hi[rr][1], b1 = hi[rr][2];
+        const f32x4 o0 = (f32x4){luma_of(byte_f<0>(r0, r1), byte_f<0>(g0, g1), byte_f<0>(b0, b1)),
+                                 luma_of(byte_f<1>(r0, r1), byte_f<1>(g0, g1), byte_f<1>(b0, b1)),
+                                 luma_of(byte_f<2>(r0, r1), byte_f<2>(g0, g1), byte_f<2>(b0, b1)),
+                                 luma_of(byte_f<3>(r0, r1), byte_f<3>(g0, g1), byte_f<3>(b0, b1))};
+        const f32x4 o1 = (f32x4){luma_of(byte_f<4>(r0, r1), byte_f<4>(g0, g1), byte_f<4>(b0, b1)),
+                                 luma_of(byte_f<5>(r0, r1), byte_f<5>(g0, g1), byte_f<5>(b0, b1)),
+                                 luma_of(byte_f<6>(r0, r1), byte_f<6>(g0, g1), byte_f<6>(b0, b1)),
+                                 luma_of(byte_f<7>(r0, r1), byte_f<7>(g0, g1), byte_f<7>(b0, b1))};
+        const int q = 4 * (rp & 3) + 2 * rr; // float4 slot of (row a + rr, left half) in the patch
+        *reinterpret_cast<f32x4*>(Lp + 4 * (q ^ swz)) = o0;
+        *reinterpret_cast<f32x4*>(Lp + 4 * ((q + 1) ^ swz)) = o1;
+    }
+}
+// four Cb and four Cr samples from their KH x (8 + [KW == 3]) source bytes per channel: row-major window sums from 0, / kh / kw
+template <int KH, int KW>
+__device__ __forceinline__ void strip_chroma(const uint32_t (&lo)[KH][3], const uint32_t (&hi)[KH][3], const uint32_t (&ex)[KH][3],
+                                             f32x4& o, f32x4& o2)
+{
+    float sum[4] = {0.f, 0.f, 0.f, 0.f}, sum2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dy = 0; dy < KH; dy++) {
+        float rf[9], gf[9], bf[9];
+#define LRF_CVT(J) rf[J] = byte_f<J>(lo[dy][0], hi[dy][0]); gf[J] = byte_f<J>(lo[dy][1], hi[dy][1]); bf[J] = byte_f<J>(lo[dy][2], hi[dy][2]);
+        LRF_CVT(0) LRF_CVT(1) LRF_CVT(2) LRF_CVT(3) LRF_CVT(4) LRF_CVT(5) LRF_CVT(6) LRF_CVT(7)
+#undef LRF_CVT
+        rf[8] = (float)ex[dy][0]; gf[8] = (float)ex[dy][1]; bf[8] = (float)ex[dy][2];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int dx = 0; dx < KW; dx++) {
+                const int col = 2 * i + dx; // 0..8
+                sum[i] = sum[i] + ycc_of(rf[col], gf[col], bf[col], 1);
+                sum2[i] = sum2[i] + ycc_of(rf[col], gf[col], bf[col], 2);
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) { // sum / kh / kw
+        o[i] = div_win<KW>(div_win<KH>(sum[i]));
+        o2[i] = div_win<KW>(div_win<KH>(sum2[i]));
+    }
+}
+
+template <int KH, int KW>
+__global__ __launch_bounds__(256) void k_planes_strip(const uint8_t* __restrict__ rgb, int H, int W, ImageGeom g,
+                                                      float* __restrict__ X, int per_strip, int nblk, int xcd_chunk)
+{
+    __shared__ __attribute__((aligned(16))) float Ls[2 * 32 * 64]; // luma staging, as in k_planes16
+    typedef uint64_t __attribute__((aligned(1))) u64u;
+    // blocks are dealt to the XCDs round-robin: XCD j gets the contiguous range [j chunk, (j + 1) chunk) of (strip, column group)
+    const int bid = xcd_chunk ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (bid >= nblk) return;
+    const int hw = H * W;
+    const PlaneGeom pl = g.p[0], pc = g.p[1];
+    const int nwl = pl.nw, nwc = pc.nw;
+    const int strip = bid / per_strip;
+    const int ww0 = (bid - strip * per_strip) * 32;
+    const uint8_t* img = rgb + (long)blockIdx.y * 3 * H * W;
+    float* Xi = X + (long)blockIdx.y * g.img_floats;
+    const int tid = threadIdx.x;
+    const int wwl = tid >> 3, ww = ww0 + wwl, rp = tid & 7; // 8-column block of padded luma pixels, row pair inside the strip
+    float* Lp = Ls + ((rp >> 2) * 32 + wwl) * 64;
+    const bool luma_row = 2 * strip + (rp >> 2) < pl.nh, chroma_row = strip < pc.nh;
+    const long coff = ((long)strip * nwc + (ww >> 1)) * 64 + rp * 8 + 4 * (ww & 1);
+    // Workgroups whose 256 padded columns need no reflection and hold whole patches (all of them, away from the left / right
+    // border): every load of the thread — two luma rows, KH chroma window rows, three channels each — is issued before the
+    // first use, without a branch in between (rows past the last patch row are clamped into the image and not stored).
+    const int xl = 8 * ww0 - pl.left, xc = 4 * ww0 - pc.left;
+    if (xl >= 0 && xl + 256 <= pl.w && ww0 + 32 <= nwl && xc >= 0 && xc + 128 <= pc.w && (ww0 >> 1) + 16 <= nwc) {
+        uint32_t lo[2][3], hi[2][3], clo[KH][3], chi[KH][3], cex[KH][3];
+        const int x0 = 8 * ww - pl.left, cx0 = 4 * ww - pc.left;
+        int yl = 16 * strip + 2 * rp - pl.top, cy = 8 * strip + rp - pc.top;
+        yl = yl < pl.hp - pl.top - 1 ? yl : pl.hp - pl.top - 2; // (only rows that are not stored)
+        cy = cy < pc.hp - pc.top ? cy : pc.hp - pc.top - 1;
+        cy = reflect_idx(cy, pc.h);
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            const uint8_t* row = img + (long)reflect_idx(yl + rr, pl.h) * W + x0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const uint64_t v = *reinterpret_cast<const u64u*>(row + (long)k * hw);
+                lo[rr][k] = (uint32_t)v;
+                hi[rr][k] = (uint32_t)(v >> 32);
+            }
+        }
+#pragma unroll
+        for (int dy = 0; dy < KH; dy++) {
+            const uint8_t* p0 = img + (long)(2 * cy + dy) * W + 2 * cx0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const uint64_t v = *reinterpret_cast<const u64u*>(p0 + (long)k * hw);
+                clo[dy][k] = (uint32_t)v;
+                chi[dy][k] = (uint32_t)(v >> 32);
+                cex[dy][k] = KW == 3 ? p0[(long)k * hw + 8] : 0u;
+            }
+        }
+        strip_luma(lo, hi, Lp, rp);
+        f32x4 o, o2;
+        strip_chroma<KH, KW>(clo, chi, cex, o, o2);
+        if (chroma_row) {
+            *reinterpret_cast<f32x4*>(Xi + g.p[1].xoff + coff) = o;
+            *reinterpret_cast<f32x4*>(Xi + g.p[2].xoff + coff) = o2;
+        }
+    } else {
+        // ---- luma: padded rows 16 strip + 2 rp (+ 1), padded columns 8 ww .. 8 ww + 7
+        if (ww < nwl && luma_row) {
+            const int x0 = 8 * ww - pl.left;
+            const bool xin = x0 >= 0 && x0 + 7 < pl.w;
+            uint32_t lo[2][3], hi[2][3];
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++) {
+                const int y = reflect_idx(16 * strip + 2 * rp + rr - pl.top, pl.h);
+                const uint8_t* row = img + (long)y * W;
+                if (xin) {
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        const uint64_t v = *reinterpret_cast<const u64u*>(row + (long)k * hw + x0);
+                        lo[rr][k] = (uint32_t)v;
+                        hi[rr][k] = (uint32_t)(v >> 32);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        uint32_t a = 0, b = 0;
+                        for (int j = 0; j < 4; j++) {
+                            a |= (uint32_t)row[(long)k * hw + reflect_idx(x0 + j, pl.w)] << (8 * j);
+                            b |= (uint32_t)row[(long)k * hw + reflect_idx(x0 + 4 + j, pl.w)] << (8 * j);
+                        }
+                        lo[rr][k] = a;
+                        hi[rr][k] = b;
+                    }
+                }
+            }
+            strip_luma(lo, hi, Lp, rp);
+        }
+        // ---- chroma: padded row 8 strip + rp, padded columns 4 ww .. 4 ww + 3 of both planes -> patch (strip, ww >> 1).
+        // F.interpolate(scale 0.5, "area"): the window of sample (y, x) starts at (2y, 2x), KH x KW = 2 for an even side, 3 for an odd one
+        if ((ww >> 1) < nwc && chroma_row) {
+            const int cy = reflect_idx(8 * strip + rp - pc.top, pc.h);
+            const int cx0 = 4 * ww - pc.left;
+            f32x4 o, o2;
+            if (cx0 >= 0 && cx0 + 3 < pc.w) { // source columns 2 cx0 .. 2 cx0 + 7 (+ 1): one word (+ the ninth byte) per channel and row
+                uint32_t clo[KH][3], chi[KH][3], cex[KH][3];
+#pragma unroll
+                for (int dy = 0; dy < KH; dy++) {
+                    const uint8_t* p0 = img + (long)(2 * cy + dy) * W + 2 * cx0;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        const uint64_t v = *reinterpret_cast<const u64u*>(p0 + (long)k * hw);
+                        clo[dy][k] = (uint32_t)v;
+                        chi[dy][k] = (uint32_t)(v >> 32);
+                        cex[dy][k] = KW == 3 ? p0[(long)k * hw + 8] : 0u;
+                    }
+                }
+                strip_chroma<KH, KW>(clo, chi, cex, o, o2);
+            } else { // reflected columns: sample by sample
+                float sum[4] = {0.f, 0.f, 0.f, 0.f}, sum2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int x = reflect_idx(cx0 + i, pc.w);
+                    for (int dy = 0; dy < KH; dy++)
+                        for (int dx = 0; dx < KW; dx++) {
+                            const uint8_t* p0 = img + (long)(2 * cy + dy) * W + 2 * x + dx;
+                            const float r_ = (float)p0[0], g_ = (float)p0[hw], b_ = (float)p0[2 * hw];
+                            sum[i] = sum[i] + ycc_of(r_, g_, b_, 1);
+                            sum2[i] = sum2[i] + ycc_of(r_, g_, b_, 2);
+                        }
+                    o[i] = div_win<KW>(div_win<KH>(sum[i]));
+                    o2[i] = div_win<KW>(div_win<KH>(sum2[i]));
+                }
+            }
+            *reinterpret_cast<f32x4*>(Xi + g.p[1].xoff + coff) = o;
+            *reinterpret_cast<f32x4*>(Xi + g.p[2].xoff + coff) = o2;
+        }
+    }
+    __syncthreads();
+    const int npw = nwl - ww0 < 32 ? nwl - ww0 : 32; // luma patches this workgroup holds per patch row
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int f = k * 256 + tid, h = f >> 9, rem = f & 511, pw = rem >> 4, q = rem & 15;
+        if (pw < npw && 2 * strip + h < pl.nh) {
+            const int sw = (h << 1) | (q >> 3); // swz of the writer: rp = 4 h + (q >> 2)
+            const f32x4 v = *reinterpret_cast<const f32x4*>(Ls + (h * 32 + pw) * 64 + 4 * (q ^ sw));
+            *reinterpret_cast<f32x4*>(Xi + g.p[0].xoff + ((long)(2 * strip + h) * nwl + ww0) * 64 + rem * 4) = v;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2: SVD initialisation = the exact Gram matrix (k_gram64, lrf_gram_kernels.hip: 128-bit partials per row chunk, added
 // here) + top-R eigen-pairs of the 64 x 64 Gram matrix (Householder tridiagonalisation, 64-way multisection on
