@@ -218,8 +218,16 @@ def decode_leg(torch, _lib, ctx, U, V, H, W, ranks, steps):
     alg = 3 * B * H * W + U.numel() + V.numel()  # u8 pixels written once + int8 factors read once
     k = ms / n
     del out
+    dims = _lib.plane_dims(H, W)
+    left, cleft = (dims[0][3] - dims[0][1]) // 2, (dims[1][3] - dims[1][1]) // 2
+    if H % 16 == 0 and W % 16 == 0:
+        kname = "k_decode16"
+    elif W % 2 == 0 and left % 2 == 0 and (cleft - left // 2) % 4 == 0:  # the host's choice in lrf_qmf_decode_rgb_u8
+        kname = "k_decode_strip"
+    else:
+        kname = "k_decode8"
     return {"decode_mpix_s": round(B * H * W / (k * 1e-3) / 1e6, 1), "decode_ms_per_batch": round(k, 5),
-            "decode_roofline": {"bound": "hbm", "kernel": "k_decode16" if (H % 16 == 0 and W % 16 == 0) else "k_decode8",
+            "decode_roofline": {"bound": "hbm", "kernel": kname,
                                 "achieved": round(alg / (k * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                                 "frac": round(alg / (k * 1e-3) / 1e9 / 8000.0, 4), "algorithmic_bytes_per_launch": alg}}
 

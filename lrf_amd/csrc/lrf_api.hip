@@ -1005,6 +1005,17 @@ int lrf_qmf_decode_rgb_u8(lrf_ctx* c, const int8_t* U, const int8_t* V, int64_t 
         else
             hipLaunchKernelGGL(k_decode16<8>, grid, dim3(256), 0, c->stream, U, V, (int)H, (int)W, g, R[0], R[1], R[2], u_img, v_img, rgb);
     }
+    else if (R[0] <= 8 && R[1] <= 8 && R[2] <= 8 && !no_tiled && W % 2 == 0 && g.p[0].left_crop % 2 == 0 &&
+             (g.p[1].left_crop - g.p[0].left_crop / 2) % 4 == 0 && g.p[1].w == W / 2)
+    {
+        // any height, widths whose chroma samples sit four-aligned under the eight pixels of a thread: tiles over the padded luma plane
+        const int per_strip = (g.p[0].nw + 31) / 32;
+        const dim3 grid((unsigned)(((g.p[0].nh + 1) / 2) * per_strip), (unsigned)B);
+        if (R[1] <= 4 && R[2] <= 4)
+            hipLaunchKernelGGL(k_decode_strip<4>, grid, dim3(256), 0, c->stream, U, V, (int)H, (int)W, g, R[0], R[1], R[2], u_img, v_img, rgb, per_strip);
+        else
+            hipLaunchKernelGGL(k_decode_strip<8>, grid, dim3(256), 0, c->stream, U, V, (int)H, (int)W, g, R[0], R[1], R[2], u_img, v_img, rgb, per_strip);
+    }
     else if (R[0] <= 8 && R[1] <= 8 && R[2] <= 8)
 {
         // groups of four pixels per thread: as many as leave the call ~2048 workgroups (small calls keep one group per thread)

@@ -1878,6 +1878,144 @@ __global__ __launch_bounds__(256) void k_decode16(const int8_t* __restrict__ U, 
     }
 }
 
+// k_decode16's tiling for every height and for the widths where the four chroma samples under a thread's eight pixels are
+// the four aligned columns of one chroma patch (W even, left pad even, left-pad difference a multiple of four: e.g. every
+// W that is a multiple of 16, whatever H — CLIC's 1365 x 2048): the tiles lie over the PADDED luma plane, a thread owns
+// padded luma rows 16 s + 2 rp (+ 1) of one patch and stores the image rows / columns that survive the centre crop.  The
+// nearest-neighbour chroma row of an image row y is min(floor(y * (h_c / H)), h_c - 1) in fp32 (F.interpolate "nearest",
+// lrf/compression/utils.py:98-105): the two rows of a thread usually share it (then the chroma sums are computed once, as
+// in k_decode16), otherwise the second row's are computed separately, from the u rows of its own chroma patch.
+// Same arithmetic as k_decode8 / k_decode16.
+template <int RC> // chroma rank bound: 4 or 8
+__global__ __launch_bounds__(256) void k_decode_strip(const int8_t* __restrict__ U, const int8_t* __restrict__ V, int H, int W,
+                                                      ImageGeom g, int R0, int R1, int R2, long u_img, long v_img,
+                                                      uint8_t* __restrict__ rgb, int per_strip)
+{
+    __shared__ __attribute__((aligned(16))) float Vs[3][8][64];
+    const int8_t* Ui = U + (long)blockIdx.y * u_img;
+    const int8_t* Vi = V + (long)blockIdx.y * v_img;
+    const int8_t* Uc[3] = {Ui, Ui + (long)g.p[0].M * R0, Ui + (long)g.p[0].M * R0 + (long)g.p[1].M * R1};
+    const int8_t* Vc[3] = {Vi, Vi + 64 * R0, Vi + 64 * R0 + 64 * R1};
+    const int Rc[3] = {R0, R1, R2};
+    const PlaneGeom pl = g.p[0], pc = g.p[1];
+    const int nwl = pl.nw, nwc = pc.nw;
+    const int strip = blockIdx.x / per_strip;
+    const int ww = (blockIdx.x - strip * per_strip) * 32 + (threadIdx.x & 31);
+    const int rp = threadIdx.x >> 5; // row pair inside the strip: padded luma rows 16 strip + 2 rp, + 1
+    const int prow = 2 * strip + (rp >> 2);
+    const bool live = ww < nwl && prow < pl.nh;
+    const int wwc = ww < nwl ? ww : nwl - 1, prc = prow < pl.nh ? prow : pl.nh - 1;
+    // image rows / columns of this thread and their chroma samples (padded chroma coordinates)
+    const int y0 = 16 * strip + 2 * rp - pl.top_crop, x0 = 8 * wwc - pl.left_crop;
+    const float sh = (float)pc.h / (float)H;
+    int q[2];
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+        int y = y0 + rr;
+        y = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);
+        int sy = (int)floorf((float)y * sh);
+        sy = sy > pc.h - 1 ? pc.h - 1 : sy;
+        q[rr] = sy + pc.top_crop;
+    }
+    int cx = (x0 >> 1) + pc.left_crop; // x0 is even, cx a multiple of four (host check); columns cropped away are clamped
+    cx = cx < 0 ? 0 : (cx > pc.wp - 4 ? pc.wp - 4 : cx);
+    const long mc0 = (long)(q[0] >> 3) * nwc + (cx >> 3), mc1 = (long)(q[1] >> 3) * nwc + (cx >> 3);
+    // the u rows of the luma patch and of the chroma patches of the first row: issued before the V table is staged
+    unsigned ulo[3], uhi[3];
+    decode16_u_load(Uc[0] + ((long)prc * nwl + wwc) * R0, R0, ulo[0], uhi[0]);
+    decode16_u_load(Uc[1] + mc0 * R1, R1, ulo[1], uhi[1]);
+    decode16_u_load(Uc[2] + mc0 * R2, R2, ulo[2], uhi[2]);
+    for (int e = threadIdx.x; e < 3 * 8 * 64; e += 256) {
+        const int c = e >> 9, r = (e >> 6) & 7, n = e & 63;
+        Vs[c][r][n] = (r < Rc[c]) ? (float)Vc[c][n * Rc[c] + r] : 0.f;
+    }
+    __syncthreads();
+    if (!live) return;
+    float u[3][8]; // zero padded to 8 columns
+#pragma unroll
+    for (int c = 0; c < 3; c++) decode16_u_unpack(ulo[c], uhi[c], Rc[c], u[c]);
+    float cb[4], cr[4];
+    auto chroma = [&](int qq) { // samples (padded row qq, padded columns cx .. cx + 3) of both planes, "+ -128.f"
+#pragma unroll
+        for (int i = 0; i < 4; i++) cb[i] = cr[i] = 0.f;
+        const int nc = (qq & 7) * 8 + (cx & 7);
+#pragma unroll
+        for (int r = 0; r < RC; r++) {
+            const f32x4 vb = *reinterpret_cast<const f32x4*>(&Vs[1][r][nc]);
+            const f32x4 vr = *reinterpret_cast<const f32x4*>(&Vs[2][r][nc]);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                cb[i] = fmaf(u[1][r], vb[i], cb[i]);
+                cr[i] = fmaf(u[2][r], vr[i], cr[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            cb[i] = cb[i] + -128.f;
+            cr[i] = cr[i] + -128.f;
+        }
+    };
+    chroma(q[0]);
+    const long hw = (long)H * W;
+    uint8_t* out = rgb + (long)blockIdx.y * 3 * hw;
+    const bool xfull = x0 >= 0 && x0 + 8 <= W;
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+        const int y = y0 + rr;
+        if (rr == 1 && q[1] != q[0]) { // the second row sits over another chroma row (possibly of the next chroma patch row)
+            if (mc1 != mc0) {
+                decode16_u_load(Uc[1] + mc1 * R1, R1, ulo[1], uhi[1]);
+                decode16_u_load(Uc[2] + mc1 * R2, R2, ulo[2], uhi[2]);
+                decode16_u_unpack(ulo[1], uhi[1], R1, u[1]);
+                decode16_u_unpack(ulo[2], uhi[2], R2, u[2]);
+            }
+            chroma(q[1]);
+        }
+        if (y < 0 || y >= H) continue;
+        float yv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int n0 = (2 * (rp & 3) + rr) * 8;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(&Vs[0][r][n0]);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(&Vs[0][r][n0 + 4]);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                yv[i] = fmaf(u[0][r], v0[i], yv[i]);
+                yv[4 + i] = fmaf(u[0][r], v1[i], yv[4 + i]);
+            }
+        }
+        uint2 pk[3];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            float ch[3][4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) { // the k-ordered chains without their no-op steps
+                const float c0 = yv[4 * h + i], c1 = cb[2 * h + (i >> 1)], c2 = cr[2 * h + (i >> 1)];
+                ch[0][i] = fmaf(1.402f, c2, c0);
+                ch[1][i] = fmaf(-0.714136f, c2, fmaf(-0.344136f, c1, c0));
+                ch[2][i] = fmaf(1.772f, c1, c0);
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const unsigned w = decode16_pack4(ch[k][0], ch[k][1], ch[k][2], ch[k][3]);
+                if (h == 0) pk[k].x = w; else pk[k].y = w;
+            }
+        }
+        uint8_t* dst = out + (long)y * W + x0;
+        if (xfull) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) *reinterpret_cast<uint2 __attribute__((aligned(1)))*>(dst + k * hw) = pk[k];
+        } else { // the crop cuts this thread's run: byte by byte
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const unsigned long long w = ((unsigned long long)pk[k].y << 32) | pk[k].x;
+                for (int j = 0; j < 8; j++)
+                    if (x0 + j >= 0 && x0 + j < W) dst[k * hw + j] = (uint8_t)(w >> (8 * j));
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_decode(const int8_t* __restrict__ U, const int8_t* __restrict__ V, int H, int W,
                                                 ImageGeom g, int R0, int R1, int R2, long u_img, long v_img,
                                                 uint8_t* __restrict__ rgb)
