@@ -11,6 +11,8 @@
 #include <condition_variable>
 #include <mutex>
 #include <thread>
+#include <algorithm>
+#include <functional>
 #include <vector>
 
 #include "../../include/lrf_hip.h"
@@ -28,6 +30,7 @@
 #define LRF_PLANES_GRAM_EXP 8
 // largest rank of the 64-column BCD kernels (k_bcd_w <= 8, k_bcd <= 16, k_bcd_mid <= 32); above it the any-shape kernels iterate
 #define LRF_BIG_TO_ANY_RANK 32
+#define LRF_TABLE_SETS 6 // descriptor-table sets a context keeps resident (upload_tables)
 #define LRF_BCDW_MIN_BLOCKS 1024 // smaller rank <= 8 runs iterate on the workgroup kernel k_bcd (run_bcd)
 #define LRF_BCDW16_MIN_BLOCKS 1024 // likewise for rank <= 16 runs and k_bcd_w16
 
@@ -101,10 +104,15 @@ struct lrf_ctx {
     long acc_n[LRF_K_COUNT] = {0};
     int init_sweeps = 0; // developer aid: stop k_init after stage n (0 = run everything)
     std::vector<char> table_key; // bytes of the descriptor tables now resident on the device (planes / blocks)
-    // the previously used tables: calls that alternate between two geometries (a pipeline's full and last, shorter
-    // sub-batch) find both resident and skip the synchronising upload
-    DevBuf planes_alt, blocks_alt, gchunks_alt;
-    std::vector<char> table_key_alt;
+    // earlier tables, least recently used one replaced: calls that alternate between a few geometries (a pipeline slot sees
+    // its full sub-batch size and the two or three sizes of the tapered tail) find them resident and skip the synchronising upload
+    struct TableSet {
+        DevBuf planes, blocks, gchunks;
+        std::vector<char> key;
+        unsigned long stamp = 0;
+    };
+    TableSet talt[LRF_TABLE_SETS - 1];
+    unsigned long tstamp = 0;
     unsigned attr_done = 0;      // hipFuncSetAttribute call sites already executed for this context's device (bit per site)
     hipEvent_t planes_done = nullptr; // set by a pipe: recorded after the planes kernel of lrf_qmf_encode_rgb_u8 (input buffer free)
 };
@@ -358,10 +366,21 @@ static int upload_tables(lrf_ctx* c, Tables& t)
     memcpy(key.data(), t.planes.data(), pb);
     memcpy(key.data() + pb, t.blocks.data(), bb);
     if (key == c->table_key) return LRF_OK;
-    std::swap(c->planes, c->planes_alt);
-    std::swap(c->blocks, c->blocks_alt);
-    std::swap(c->gchunks, c->gchunks_alt);
-    c->table_key.swap(c->table_key_alt);
+    int victim = 0;
+    for (int j = 0; j < LRF_TABLE_SETS - 1; j++) {
+        lrf_ctx::TableSet& a = c->talt[j];
+        const bool hit = a.key == key;
+        if (hit || a.stamp < c->talt[victim].stamp) victim = j;
+        if (hit) break;
+    }
+    { // the current set goes to the victim's place, the victim's buffers become current (its tables, if this was a hit)
+        lrf_ctx::TableSet& a = c->talt[victim];
+        std::swap(c->planes, a.planes);
+        std::swap(c->blocks, a.blocks);
+        std::swap(c->gchunks, a.gchunks);
+        c->table_key.swap(a.key);
+        a.stamp = ++c->tstamp;
+    }
     if (key == c->table_key) return LRF_OK;
     c->table_key.clear();
     int rc = upload(c, c->planes, t.planes.data(), pb);
@@ -610,12 +629,17 @@ void lrf_ctx_destroy(lrf_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     fold_events(c);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-    DevBuf* bufs[] = {&c->planes_alt, &c->blocks_alt, &c->gchunks_alt, &c->gchunks, &c->gpart, &c->gexp, &c->planes, &c->blocks, &c->vf, &c->wf, &c->bf, &c->ppart, &c->qpart, &c->x, &c->sign,
+    DevBuf* bufs[] = {&c->gchunks, &c->gpart, &c->gexp, &c->planes, &c->blocks, &c->vf, &c->wf, &c->bf, &c->ppart, &c->qpart, &c->x, &c->sign,
                       &c->sx, &c->sg, &c->svn, &c->swn, &c->suf, &c->smm,
                       &c->any_uf, &c->any_vf, &c->any_a, &c->any_b, &c->any_p, &c->any_e2, &c->any_g, &c->any_td,
                       &c->vf16, &c->wf16, &c->bf16, &c->pp16, &c->qp16};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
+    for (auto& a : c->talt) {
+        DevBuf* tb[] = {&a.planes, &a.blocks, &a.gchunks};
+        for (DevBuf* b : tb)
+            if (b->p) (void)hipFree(b->p);
+    }
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -651,12 +675,13 @@ int lrf_ctx_synchronize(lrf_ctx* c)
 size_t lrf_ctx_workspace_bytes(const lrf_ctx* c)
 {
     if (!c) return 0;
-    const DevBuf* bufs[] = {&c->planes_alt, &c->blocks_alt, &c->gchunks_alt, &c->gchunks, &c->gpart, &c->gexp, &c->planes, &c->blocks, &c->vf, &c->wf, &c->bf, &c->ppart, &c->qpart, &c->x, &c->sign,
+    const DevBuf* bufs[] = {&c->gchunks, &c->gpart, &c->gexp, &c->planes, &c->blocks, &c->vf, &c->wf, &c->bf, &c->ppart, &c->qpart, &c->x, &c->sign,
                             &c->sx, &c->sg, &c->svn, &c->swn, &c->suf, &c->smm,
                             &c->any_uf, &c->any_vf, &c->any_a, &c->any_b, &c->any_p, &c->any_e2, &c->any_g, &c->any_td,
                       &c->vf16, &c->wf16, &c->bf16, &c->pp16, &c->qp16};
     size_t total = 0;
     for (const DevBuf* b : bufs) total += b->cap;
+    for (const auto& a : c->talt) total += a.planes.cap + a.blocks.cap + a.gchunks.cap;
     return total;
 }
 
@@ -665,7 +690,7 @@ int lrf_ctx_trim(lrf_ctx* c)
     if (!c) return set_err(LRF_EINVAL, "ctx is NULL");
     LRF_ON_DEVICE(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
-    DevBuf* bufs[] = {&c->planes_alt, &c->blocks_alt, &c->gchunks_alt, &c->gchunks, &c->gpart, &c->gexp, &c->planes, &c->blocks, &c->vf,
+    DevBuf* bufs[] = {&c->gchunks, &c->gpart, &c->gexp, &c->planes, &c->blocks, &c->vf,
                       &c->wf, &c->bf, &c->ppart, &c->qpart, &c->x, &c->sign, &c->sx, &c->sg, &c->svn, &c->swn, &c->suf, &c->smm,
                       &c->any_uf, &c->any_vf, &c->any_a, &c->any_b, &c->any_p, &c->any_e2, &c->any_g, &c->any_td,
                       &c->vf16, &c->wf16, &c->bf16, &c->pp16, &c->qp16};
@@ -674,8 +699,17 @@ int lrf_ctx_trim(lrf_ctx* c)
         b->p = nullptr;
         b->cap = 0;
     }
+    for (auto& a : c->talt) {
+        DevBuf* tb[] = {&a.planes, &a.blocks, &a.gchunks};
+        for (DevBuf* b : tb) {
+            if (b->p) HIP_TRY(hipFree(b->p));
+            b->p = nullptr;
+            b->cap = 0;
+        }
+        a.key.clear();
+        a.stamp = 0;
+    }
     c->table_key.clear();     // the descriptor tables went with their buffers
-    c->table_key_alt.clear();
     return LRF_OK;
 }
 
@@ -929,42 +963,60 @@ int lrf_qmf_svd_init_f32(lrf_ctx* c, const float* X, int64_t B, int64_t M, int64
     return LRF_OK;
 }
 
+// The part of lrf_qmf_encode_rgb_u8 that may allocate or upload: argument checks, the X workspace, the plane / block tables of
+// B images (resident afterwards: upload_tables).  A pipe calls it for every sub-batch size of a submission before any
+// transfer is in flight, so that nothing synchronises or allocates once its threads and streams are busy.
+struct EncodePlan {
+    ImageGeom g;
+    Tables t;
+    long u_img = 0, v_img = 0, uoff[3], voff[3], u0c[4] = {0, 0, 0, 0}, v0c[4] = {0, 0, 0, 0};
+};
+static int encode_rgb_prepare(lrf_ctx* c, int64_t B, int64_t H, int64_t W, const int R[3], int K, int lo, int hi, bool with_sign,
+                              EncodePlan& ep)
+{
+    if (B < 1 || B > 65535) return set_err(LRF_EINVAL, "B=%ld out of range [1,65535]", (long)B);
+    int rc = make_geom(H, W, &ep.g);
+    if (rc) return rc;
+    const ImageGeom& g = ep.g;
+    for (int ch = 0; ch < 3; ch++)
+        if ((rc = check_params(g.p[ch].M, 64, R[ch], K, lo, hi))) return rc;
+    if ((rc = ensure(c, c->x, (size_t)B * g.img_floats * sizeof(float)))) return rc;
+    // plane table: all Y planes first (four times the work of a chroma plane), then Cb, then Cr
+    const long s_img = R[0] + R[1] + R[2];
+    const long soff[3] = {0, R[0], R[0] + R[1]};
+    for (int ch = 0; ch < 3; ch++) {
+        ep.uoff[ch] = ep.u_img; ep.voff[ch] = ep.v_img;
+        ep.u_img += (long)g.p[ch].M * R[ch];
+        ep.v_img += 64L * R[ch];
+    }
+    // fp32 initial factors, if they are wanted (ranks above LRF_BIG_TO_ANY_RANK): per plane class contiguous [B][M][R] / [B][64][R]
+    for (int ch = 0; ch < 3; ch++) {
+        ep.u0c[ch + 1] = ep.u0c[ch] + B * (long)g.p[ch].M * R[ch];
+        ep.v0c[ch + 1] = ep.v0c[ch] + B * 64L * R[ch];
+    }
+    for (int ch = 0; ch < 3; ch++)
+        for (int64_t b = 0; b < B; b++)
+            add_plane(ep.t, b * g.img_floats + g.p[ch].xoff, b * ep.u_img + ep.uoff[ch], b * ep.v_img + ep.voff[ch],
+                      ep.u0c[ch] + b * (long)g.p[ch].M * R[ch], ep.v0c[ch] + b * 64L * R[ch], g.p[ch].M, R[ch],
+                      with_sign ? (int)(b * s_img + soff[ch]) : -1);
+    return upload_tables(c, ep.t);
+}
+
 int lrf_qmf_encode_rgb_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_t H, int64_t W, const int R[3], int K, int lo,
                           int hi, const int8_t* sign, int8_t* U, int8_t* V)
 {
     if (!c || !rgb || !R || !U || !V) return set_err(LRF_EINVAL, "NULL argument");
-    if (B < 1 || B > 65535) return set_err(LRF_EINVAL, "B=%ld out of range [1,65535]", (long)B);
-    ImageGeom g;
-    int rc = make_geom(H, W, &g);
-    if (rc) return rc;
-    for (int ch = 0; ch < 3; ch++)
-        if ((rc = check_params(g.p[ch].M, 64, R[ch], K, lo, hi))) return rc;
     LRF_ON_DEVICE(c);
-    if ((rc = ensure(c, c->x, (size_t)B * g.img_floats * sizeof(float)))) return rc;
+    EncodePlan ep;
+    int rc = encode_rgb_prepare(c, B, H, W, R, K, lo, hi, sign != nullptr, ep);
+    if (rc) return rc;
+    const ImageGeom& g = ep.g;
+    Tables& t = ep.t;
+    const long u_img = ep.u_img, v_img = ep.v_img;
+    const long *uoff = ep.uoff, *voff = ep.voff, *u0c = ep.u0c, *v0c = ep.v0c;
     float* X = (float*)c->x.p;
     if ((rc = lrf_qmf_planes_from_rgb_u8(c, rgb, B, H, W, X))) return rc;
     if (c->planes_done) HIP_TRY(hipEventRecord(c->planes_done, c->stream)); // the RGB bytes are not read again
-    // plane table: all Y planes first (four times the work of a chroma plane), then Cb, then Cr
-    long u_img = 0, v_img = 0, s_img = R[0] + R[1] + R[2];
-    long uoff[3], voff[3], soff[3] = {0, R[0], R[0] + R[1]};
-    for (int ch = 0; ch < 3; ch++) {
-        uoff[ch] = u_img; voff[ch] = v_img;
-        u_img += (long)g.p[ch].M * R[ch];
-        v_img += 64L * R[ch];
-    }
-    // fp32 initial factors, if they are wanted (ranks above LRF_BIG_TO_ANY_RANK): per plane class contiguous [B][M][R] / [B][64][R]
-    long u0c[4] = {0, 0, 0, 0}, v0c[4] = {0, 0, 0, 0};
-    for (int ch = 0; ch < 3; ch++) {
-        u0c[ch + 1] = u0c[ch] + B * (long)g.p[ch].M * R[ch];
-        v0c[ch + 1] = v0c[ch] + B * 64L * R[ch];
-    }
-    Tables t;
-    for (int ch = 0; ch < 3; ch++)
-        for (int64_t b = 0; b < B; b++)
-            add_plane(t, b * g.img_floats + g.p[ch].xoff, b * u_img + uoff[ch], b * v_img + voff[ch],
-                      u0c[ch] + b * (long)g.p[ch].M * R[ch], v0c[ch] + b * 64L * R[ch], g.p[ch].M, R[ch],
-                      sign ? (int)(b * s_img + soff[ch]) : -1);
-    if ((rc = upload_tables(c, t))) return rc;
     if (table_rmax(t) > LRF_BIG_TO_ANY_RANK) {
         float *U0, *V0;
         if ((rc = init_to_fp32(c, X, t, sign, (size_t)u0c[3], (size_t)v0c[3], &U0, &V0, LRF_PLANES_GRAM_EXP))) return rc;
@@ -1049,9 +1101,13 @@ struct lrf_pipe {
     int64_t sub_batch = 0;
     hipStream_t h2d = nullptr;      // all uploads, in order: one sub-batch at a time gets the whole link, so the first one
                                     // lands early and its kernels run under the uploads of the following ones
+    hipStream_t d2h = nullptr;      // all downloads of factors, in order: a slot's next kernels do not queue behind its copies
+                                    // (LRF_PIPE_NO_D2H=1 at creation: downloads on the slot's own stream, as in round 2)
+    hipEvent_t sign_done = nullptr; // the batch's sign vectors have landed
     std::vector<PipeSlot> slots;
     DevBuf sign;                    // the whole batch's sign vectors, uploaded once per call ahead of the first sub-batch
-    std::vector<hipEvent_t> done;   // one per sub-batch of the call in flight
+    std::vector<hipEvent_t> done;   // one per sub-batch of the call in flight: its factors are in the caller's buffers
+    std::vector<hipEvent_t> kdone;  // one per sub-batch: its kernels have finished (the download stream waits for it)
     std::vector<int64_t> first, count;
     size_t next_wait = 0;
 };
@@ -1076,6 +1132,8 @@ int lrf_pipe_create(int device, int slots, int64_t sub_batch, lrf_pipe** out)
     }
     DevGuard dev_guard_(device);
     hipError_t e = hipStreamCreateWithFlags(&p->h2d, hipStreamNonBlocking);
+    if (e == hipSuccess && !getenv("LRF_PIPE_NO_D2H")) e = hipStreamCreateWithFlags(&p->d2h, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->sign_done, hipEventDisableTiming);
     for (auto& s : p->slots) {
         if (e == hipSuccess) e = hipEventCreateWithFlags(&s.h2d_done, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&s.rgb_free, hipEventDisableTiming);
@@ -1094,6 +1152,7 @@ void lrf_pipe_destroy(lrf_pipe* p)
     if (!p) return;
     DevGuard dev_guard_(p->device);
     if (p->h2d) (void)hipStreamSynchronize(p->h2d);
+    if (p->d2h) (void)hipStreamSynchronize(p->d2h);
     for (auto& s : p->slots) {
         if (!s.ctx) continue;
         (void)hipStreamSynchronize(s.ctx->stream);
@@ -1106,8 +1165,11 @@ void lrf_pipe_destroy(lrf_pipe* p)
         if (s.rgb_free) (void)hipEventDestroy(s.rgb_free);
     }
     if (p->h2d) (void)hipStreamDestroy(p->h2d);
+    if (p->d2h) (void)hipStreamDestroy(p->d2h);
+    if (p->sign_done) (void)hipEventDestroy(p->sign_done);
     if (p->sign.p) (void)hipFree(p->sign.p);
     for (auto e : p->done) (void)hipEventDestroy(e);
+    for (auto e : p->kdone) (void)hipEventDestroy(e);
     delete p;
 }
 
@@ -1115,7 +1177,7 @@ int lrf_pipe_slots(const lrf_pipe* p) { return p ? (int)p->slots.size() : 0; }
 
 lrf_ctx* lrf_pipe_slot_ctx(lrf_pipe* p, int slot)
 {
-    if (!p || slot < 0 || slot >= (int)p->slots.size()) return nullptr;
+    if (!p || slot < 0 || slot >= lrf_pipe_slots(p)) return nullptr;
     return p->slots[(size_t)slot].ctx;
 }
 
@@ -1127,19 +1189,65 @@ size_t lrf_pipe_workspace_bytes(const lrf_pipe* p)
     return total + p->sign.cap;
 }
 
-/* images per sub-batch when the caller left it to the library: about 40 MB of input (0.7 ms of a Gen5 x16 link; 32 images of
- * 512x768).  Measured at 256 x 512x768 (tools/dev_pipe_sweep.py): 16 images 8.8 ms per batch, 32: 6.57, 64: 6.61 — smaller
- * sub-batches are bound by the per-matrix latency chain of the initialisation, larger ones lengthen the un-overlapped tail. */
-static int64_t pipe_sub_batch(const lrf_pipe* p, int64_t B, int64_t H, int64_t W)
+/* The sub-batches of a submission.  A pipe created with an explicit sub_batch cuts the batch into equal pieces (the last one
+ * shorter).  Left to the library (sub_batch 0): pieces of about 80 MB of input (1.4 ms of a Gen5 x16 link; 64 images of
+ * 512x768) or a sixteenth of the batch, whichever is larger — smaller ones are bound by the per-matrix latency chain of the
+ * initialisation and by this thread's launch rate (a CLIC-sized batch in 4-image pieces: 128 x 22 launches), and every piece
+ * costs ~20 us of idle link between two copies of the upload stream — and a tapered tail: what happens after the last byte
+ * has landed is the kernels of the LAST piece, which no transfer hides, so the batch ends with a piece of three quarters and
+ * one of a quarter of the regular size (256 x 512x768: 64, 64, 64, 48, 16; the 48's kernels run on the other slot's stream
+ * under the upload and the kernels of the 16).  Measured (tools/dev_pipe_taper.py): the taper and the
+ * larger pieces are worth 1-2 % (6.14 -> 6.07 ms); a stream of its own for the last piece's kernels, or two upload streams
+ * with two copies in flight, made it slower (every further stream costs more in the runtime's cross-stream waits than
+ * the idle time it removes).  LRF_PIPE_TAIL="a,b,.." overrides the tail and
+ * LRF_PIPE_BULK the regular size (developer aids: tools/dev_pipe_sweep.py, tests/test_pipeline.py). */
+static std::vector<int64_t> pipe_schedule(const lrf_pipe* p, int64_t B, int64_t H, int64_t W)
 {
-    int64_t sb = p->sub_batch;
-    if (sb <= 0) {
-        sb = (40L << 20) / (3 * H * W);
-        if (sb >= 8) sb -= sb % 8;
-        if (sb < 1) sb = 1;
-        if (sb > 1024) sb = 1024;
+    std::vector<int64_t> sizes;
+    if (p->sub_batch > 0) {
+        for (int64_t b = 0; b < B; b += p->sub_batch) sizes.push_back(b + p->sub_batch <= B ? p->sub_batch : B - b);
+        return sizes;
     }
-    return sb < B ? sb : B;
+    const int64_t img = 3 * H * W;
+    int64_t bytes = (int64_t)80 << 20;
+    if (B * img / 16 > bytes) bytes = B * img / 16;
+    int64_t sb = bytes / img;
+    if (sb >= 8) sb -= sb % 8;
+    if (sb < 1) sb = 1;
+    if (sb > 1024) sb = 1024;
+    if (const char* e = getenv("LRF_PIPE_BULK")) // developer aid: images per regular piece of the tapered schedule
+        if (atol(e) > 0) sb = atol(e);
+    std::vector<int64_t> tail;
+    if (const char* e = getenv("LRF_PIPE_TAIL")) {
+        for (const char* q = e; *q;) {
+            char* end = nullptr;
+            const long v = strtol(q, &end, 10);
+            if (end == q) break;
+            if (v > 0) tail.push_back(v);
+            q = *end == ',' ? end + 1 : end;
+        }
+    } else if (sb >= 4) {
+        tail.push_back(sb - sb / 4);
+        tail.push_back(sb / 4);
+    }
+    int64_t tail_sum = 0;
+    for (int64_t v : tail) tail_sum += v;
+    if (B < sb + tail_sum) { // too small for a regular piece and the tail: equal pieces, as for an explicit size
+        for (int64_t b = 0; b < B; b += sb) sizes.push_back(b + sb <= B ? sb : B - b);
+        return sizes;
+    }
+    int64_t rem = B - tail_sum;
+    while (rem >= 2 * sb) {
+        sizes.push_back(sb);
+        rem -= sb;
+    }
+    if (rem > sb) { // two pieces of about half of what is left, rather than a regular one and a sliver
+        sizes.push_back(rem - rem / 2);
+        rem = rem / 2;
+    }
+    if (rem > 0) sizes.push_back(rem);
+    for (int64_t v : tail) sizes.push_back(v);
+    return sizes;
 }
 
 int lrf_pipe_qmf_encode_submit(lrf_pipe* p, const uint8_t* rgb_host, int64_t B, int64_t H, int64_t W, const int R[3], int K, int lo,
@@ -1159,8 +1267,19 @@ int lrf_pipe_qmf_encode_submit(lrf_pipe* p, const uint8_t* rgb_host, int64_t B, 
         v_img += 64L * R[ch];
     }
     const size_t img_bytes = (size_t)3 * H * W;
-    const int64_t sb = pipe_sub_batch(p, B, H, W);
-    const size_t nsub = (size_t)((B + sb - 1) / sb);
+    const std::vector<int64_t> sizes = pipe_schedule(p, B, H, W);
+    const size_t nsub = sizes.size(), S = (size_t)lrf_pipe_slots(p);
+    // sub-batch -> slot: the slots in turn.  prev[i]: the sub-batch that had i's slot before.
+    std::vector<int64_t> first(nsub);
+    std::vector<size_t> slot_of(nsub);
+    std::vector<long> prev(nsub, -1);
+    int64_t sb_max = 0;
+    for (size_t i = 0, b = 0; i < nsub; b += (size_t)sizes[i], i++) {
+        first[i] = (int64_t)b;
+        sb_max = sizes[i] > sb_max ? sizes[i] : sb_max;
+        slot_of[i] = i % S;
+        if (slot_of[i] < S && i >= S) prev[i] = (long)(i - S);
+    }
     DevGuard dev_guard_(p->device);
     if (dev_guard_.err != hipSuccess) return set_err(LRF_EHIP, "selecting device %d failed", p->device);
     while (p->done.size() < nsub) {
@@ -1168,66 +1287,89 @@ int lrf_pipe_qmf_encode_submit(lrf_pipe* p, const uint8_t* rgb_host, int64_t B, 
         HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         p->done.push_back(e);
     }
+    while (p->kdone.size() < nsub) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        p->kdone.push_back(e);
+    }
     p->first.clear();
     p->count.clear();
     p->next_wait = 0;
+    // Everything that allocates, uploads a descriptor table or synchronises happens here, before the first transfer: per slot
+    // the buffers for its largest piece, the workspace and the tables of every piece size it will see (largest first, so
+    // that the workspace is allocated once; a context keeps LRF_TABLE_SETS table sets resident).
+    if (sign_host && (rc = ensure(p->slots[0].ctx, p->sign, (size_t)B * s_img))) return rc;
+    for (size_t sl = 0; sl < p->slots.size(); sl++) {
+        PipeSlot& s = p->slots[sl];
+        std::vector<int64_t> seen;
+        for (size_t i = 0; i < nsub; i++)
+            if (slot_of[i] == sl && std::find(seen.begin(), seen.end(), sizes[i]) == seen.end()) seen.push_back(sizes[i]);
+        if (seen.empty()) continue;
+        std::sort(seen.begin(), seen.end(), std::greater<int64_t>());
+        if ((rc = pipe_ensure(p, s, s.rgb, (size_t)seen[0] * img_bytes))) return rc;
+        if ((rc = pipe_ensure(p, s, s.u, (size_t)seen[0] * u_img))) return rc;
+        if ((rc = pipe_ensure(p, s, s.v, (size_t)seen[0] * v_img))) return rc;
+        if (seen.size() <= LRF_TABLE_SETS) // (more sizes than table sets: the calls below upload as they go, still correct)
+            for (int64_t nb : seen) {
+                EncodePlan ep;
+                if ((rc = encode_rgb_prepare(s.ctx, nb, H, W, R, K, lo, hi, sign_host != nullptr, ep))) return rc;
+            }
+    }
     // upload of sub-batch i: on the upload stream, once the planes kernel of the sub-batch that used the slot before has read
     // its input; enqueued one sub-batch ahead of the kernels so that the link never waits for this host thread
     auto enqueue_upload = [&](size_t i) -> int {
-        PipeSlot& s = p->slots[i % p->slots.size()];
-        const int64_t b0 = (int64_t)i * sb, nb = (b0 + sb <= B) ? sb : B - b0;
-        HIP_TRY(hipStreamWaitEvent(p->h2d, s.rgb_free, 0));
-        HIP_TRY(hipMemcpyAsync(s.rgb.p, rgb_host + (size_t)b0 * img_bytes, (size_t)nb * img_bytes, hipMemcpyHostToDevice, p->h2d));
-        HIP_TRY(hipEventRecord(s.h2d_done, p->h2d));
+        PipeSlot& s = p->slots[slot_of[i]];
+        hipStream_t up = p->h2d;
+        HIP_TRY(hipStreamWaitEvent(up, s.rgb_free, 0));
+        HIP_TRY(hipMemcpyAsync(s.rgb.p, rgb_host + (size_t)first[i] * img_bytes, (size_t)sizes[i] * img_bytes, hipMemcpyHostToDevice, up));
+        HIP_TRY(hipEventRecord(s.h2d_done, up));
         return LRF_OK;
     };
     // The sign vectors are read by the initialisation kernel, long after the planes kernel has released the slot's input
-    // buffer: they get a buffer of their own for the whole batch (a few bytes per image), first thing on the upload stream.
+    // buffer: they get a buffer of their own for the whole batch (a few bytes per image), first thing on an upload stream.
     if (sign_host) {
-        if ((rc = ensure(p->slots[0].ctx, p->sign, (size_t)B * s_img))) return rc;
         HIP_TRY(hipMemcpyAsync(p->sign.p, sign_host, (size_t)B * s_img, hipMemcpyHostToDevice, p->h2d));
+        HIP_TRY(hipEventRecord(p->sign_done, p->h2d));
     }
-    // kernels and downloads of sub-batch i on its slot's stream, behind its upload
+    // kernels of sub-batch i on its slot's stream, behind its upload and behind the download of the slot's previous factors
     auto enqueue_kernels = [&](size_t i) -> int {
-        PipeSlot& s = p->slots[i % p->slots.size()];
-        const int64_t b0 = (int64_t)i * sb, nb = (b0 + sb <= B) ? sb : B - b0;
+        PipeSlot& s = p->slots[slot_of[i]];
         hipStream_t st = s.ctx->stream;
         int rc2;
         HIP_TRY(hipStreamWaitEvent(st, s.h2d_done, 0));
-        if ((rc2 = lrf_qmf_encode_rgb_u8(s.ctx, (const uint8_t*)s.rgb.p, nb, H, W, R, K, lo, hi, sign_host ? (const int8_t*)p->sign.p + (size_t)b0 * s_img : nullptr,
-                                         (int8_t*)s.u.p, (int8_t*)s.v.p)))
+        if (sign_host) HIP_TRY(hipStreamWaitEvent(st, p->sign_done, 0));
+        if (prev[i] >= 0 && p->d2h) HIP_TRY(hipStreamWaitEvent(st, p->done[(size_t)prev[i]], 0));
+        if ((rc2 = lrf_qmf_encode_rgb_u8(s.ctx, (const uint8_t*)s.rgb.p, sizes[i], H, W, R, K, lo, hi,
+                                         sign_host ? (const int8_t*)p->sign.p + (size_t)first[i] * s_img : nullptr, (int8_t*)s.u.p, (int8_t*)s.v.p)))
             return rc2;
+        if (p->d2h) HIP_TRY(hipEventRecord(p->kdone[i], st));
         return LRF_OK;
     };
+    // its factors to the caller's buffers, on the download stream
     auto enqueue_download = [&](size_t i) -> int {
-        PipeSlot& s = p->slots[i % p->slots.size()];
-        const int64_t b0 = (int64_t)i * sb, nb = (b0 + sb <= B) ? sb : B - b0;
-        hipStream_t st = s.ctx->stream;
-        HIP_TRY(hipMemcpyAsync(U_host + (size_t)b0 * u_img, s.u.p, (size_t)nb * u_img, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(V_host + (size_t)b0 * v_img, s.v.p, (size_t)nb * v_img, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipEventRecord(p->done[i], st));
-        p->first.push_back(b0);
-        p->count.push_back(nb);
+        PipeSlot& s = p->slots[slot_of[i]];
+        hipStream_t dn = p->d2h ? p->d2h : s.ctx->stream;
+        if (p->d2h) HIP_TRY(hipStreamWaitEvent(dn, p->kdone[i], 0));
+        HIP_TRY(hipMemcpyAsync(U_host + (size_t)first[i] * u_img, s.u.p, (size_t)sizes[i] * u_img, hipMemcpyDeviceToHost, dn));
+        HIP_TRY(hipMemcpyAsync(V_host + (size_t)first[i] * v_img, s.v.p, (size_t)sizes[i] * v_img, hipMemcpyDeviceToHost, dn));
+        HIP_TRY(hipEventRecord(p->done[i], dn));
+        p->first.push_back(first[i]);
+        p->count.push_back(sizes[i]);
         return LRF_OK;
     };
-    for (auto& s : p->slots) { // all allocations up front: none may happen while two threads work on the pipe (below)
-        if ((rc = pipe_ensure(p, s, s.rgb, (size_t)sb * img_bytes))) return rc;
-        if ((rc = pipe_ensure(p, s, s.u, (size_t)sb * u_img))) return rc;
-        if ((rc = pipe_ensure(p, s, s.v, (size_t)sb * v_img))) return rc;
-    }
     // Pageable source memory (what a torch tensor is unless it was pinned): hipMemcpyAsync from it returns when the transfer is
     // over, so a single submitting thread enqueues the kernels of sub-batch i only after upload i + 1 and the pipeline drains
     // (256 x 512x768: 9.7 ms against 6.1 ms from page-locked memory).  Then a second thread issues the uploads, in order;
     // the two threads hand over through two counters: the kernels of sub-batch i wait for upload i to have been issued (its
-    // event must be RECORDED before a stream can wait for it), upload i + S for the kernels of sub-batch i (which record
-    // rgb_free, the event that says the slot's input buffer may be overwritten).
+    // event must be RECORDED before a stream can wait for it), the upload into a slot for the kernels of the sub-batch that
+    // had the slot before (which record rgb_free, the event that says the slot's input buffer may be overwritten).  The uploader only copies and records
+    // events; allocations and table uploads were done above.
     bool pageable = false;
     {
         hipPointerAttribute_t attr;
         if (hipPointerGetAttributes(&attr, rgb_host) == hipSuccess) pageable = attr.type == hipMemoryTypeUnregistered;
         else { (void)hipGetLastError(); pageable = true; } // some runtimes report an error for an unregistered pointer
     }
-    const size_t S = p->slots.size();
     if (pageable && S > 1 && nsub > 1) {
         struct Handover {
             std::mutex m;
@@ -1236,26 +1378,31 @@ int lrf_pipe_qmf_encode_submit(lrf_pipe* p, const uint8_t* rgb_host, int64_t B, 
             int err = 0;
             char msg[512] = "";
         } ho;
-        std::thread uploader([&]() {
-            DevGuard guard(p->device);
-            for (size_t i = 0; i < nsub; i++) {
-                {
+        std::thread uploader;
+        try {
+            uploader = std::thread([&]() {
+                DevGuard guard(p->device);
+                for (size_t i = 0; i < nsub; i++) {
+                    {
+                        std::unique_lock<std::mutex> lk(ho.m);
+                        ho.cv.wait(lk, [&] { return ho.err != 0 || prev[i] < 0 || ho.enqueued > (size_t)prev[i]; });
+                        if (ho.err) return;
+                    }
+                    const int rcu = enqueue_upload(i);
                     std::unique_lock<std::mutex> lk(ho.m);
-                    ho.cv.wait(lk, [&] { return ho.err != 0 || i < S || ho.enqueued + S > i; });
-                    if (ho.err) return;
+                    if (rcu) {
+                        ho.err = rcu;
+                        snprintf(ho.msg, sizeof(ho.msg), "%s", lrf_last_error()); // this thread's message, for the caller's thread
+                    } else {
+                        ho.uploaded = i + 1;
+                    }
+                    ho.cv.notify_all();
+                    if (rcu) return;
                 }
-                const int rcu = enqueue_upload(i);
-                std::unique_lock<std::mutex> lk(ho.m);
-                if (rcu) {
-                    ho.err = rcu;
-                    snprintf(ho.msg, sizeof(ho.msg), "%s", lrf_last_error()); // this thread's message, for the caller's thread
-                } else {
-                    ho.uploaded = i + 1;
-                }
-                ho.cv.notify_all();
-                if (rcu) return;
-            }
-        });
+            });
+        } catch (const std::exception& ex) { // no exception crosses the C ABI
+            return set_err(LRF_EHIP, "starting the upload thread failed: %s", ex.what());
+        }
         int rcm = LRF_OK;
         for (size_t i = 0; i < nsub && rcm == LRF_OK; i++) {
             {
@@ -1278,8 +1425,6 @@ int lrf_pipe_qmf_encode_submit(lrf_pipe* p, const uint8_t* rgb_host, int64_t B, 
         for (size_t i = 0; i < nsub; i++) {
             // With one slot the next upload overwrites the buffer this sub-batch still has to read: it is enqueued after the
             // kernels (which record rgb_free); with more slots it goes first, so that the link never waits for this thread.
-            PipeSlot& s = p->slots[i % S];
-            HIP_TRY(hipStreamWaitEvent(s.ctx->stream, s.h2d_done, 0));
             if (i + 1 < nsub && S > 1 && (rc = enqueue_upload(i + 1))) return rc;
             if ((rc = enqueue_kernels(i))) return rc;
             if (i + 1 < nsub && S == 1 && (rc = enqueue_upload(i + 1))) return rc;

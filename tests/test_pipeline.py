@@ -32,6 +32,52 @@ def test_pipelined_factors_equal_one_shot_factors(B, sub, slots, pinned):
         pipe.close()
 
 
+@pytest.mark.parametrize("slots,pinned", [(2, True), (3, True), (2, False), (1, True)])
+def test_tapered_schedule_of_unequal_pieces(slots, pinned, monkeypatch):
+    """Left to the library (sub_batch 0) a submission is cut into regular pieces and a tapered tail (pipe_schedule, lrf_api.hip);
+    here with a regular size of 8 images and the tail 5, 2, 1: 37 images -> 8, 8, 7, 6, 5, 2, 1.  A slot then sees up to four
+    piece sizes (its descriptor tables are all resident from the second call on); downloads run on a stream of their own.
+    Byte for byte the one-shot result, also from pageable memory (the two-thread submission)."""
+    import lrf_amd
+    from lrf_amd import _lib
+    monkeypatch.setenv("LRF_PIPE_BULK", "8")
+    monkeypatch.setenv("LRF_PIPE_TAIL", "5,2,1")
+    B, H, W, ranks = 37, 96, 160, [7, 3, 3]
+    imgs = _images(B, H, W, 5)
+    if pinned:
+        imgs = imgs.pin_memory()
+    U0, V0 = lrf_amd.qmf_factorize_batch(imgs.cuda(), ranks)
+    pipe = _lib.Pipe(0, slots=slots, sub_batch=0)
+    try:
+        for _ in range(3):
+            seen = []
+            for first, n, U, V in pipe.encode_rgb_host_iter(imgs, ranks, 10, -16, 15):
+                seen.append((first, n))
+                assert torch.equal(U[first:first + n], U0[first:first + n].cpu())
+            assert [n for _, n in seen] == [8, 8, 7, 6, 5, 2, 1] and [f for f, _ in seen] == [0, 8, 16, 23, 29, 34, 36]
+            assert torch.equal(U, U0.cpu()) and torch.equal(V, V0.cpu())
+    finally:
+        pipe.close()
+
+
+def test_default_schedule_on_a_batch_large_enough_to_taper():
+    """2500 images of 32x32: the regular piece is capped at 1024 images (80 MB of input would be 27306), the tail is three
+    quarters and one quarter of it: 738, 738, 768, 256."""
+    import lrf_amd
+    from lrf_amd import _lib
+    B, H, W, ranks = 2500, 32, 32, [4, 2, 2]
+    imgs = _images(B, H, W, 8).pin_memory()
+    U0, V0 = lrf_amd.qmf_factorize_batch(imgs.cuda(), ranks, num_iters=2)
+    pipe = _lib.Pipe(0, slots=2, sub_batch=0)
+    try:
+        seen = [(first, n) for first, n, U, V in pipe.encode_rgb_host_iter(imgs, ranks, 2, -16, 15)]
+        assert [n for _, n in seen] == [738, 738, 768, 256]
+        U, V = pipe.encode_rgb_host(imgs, ranks, 2, -16, 15)
+        assert torch.equal(U, U0.cpu()) and torch.equal(V, V0.cpu())
+    finally:
+        pipe.close()
+
+
 def test_pipelined_with_signs_and_odd_geometry(oracle):
     """reflect-padded geometry, per-image sign vectors, and the generator form that hands back finished sub-batches"""
     import lrf_amd
