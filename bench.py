@@ -309,6 +309,8 @@ def main():
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
     cfg = CONFIGS[args.config]
     H, W, RANKS = cfg["H"], cfg["W"], cfg["ranks"]
+    if os.environ.get("LRF_BENCH_SELF_LAUNCHED") == "1":
+        print(f"[bench] rank {os.environ.get('RANK')} of {os.environ.get('WORLD_SIZE')} started (pid {os.getpid()})", file=sys.stderr, flush=True)
 
     import torch
     import torch.distributed as dist
