@@ -955,6 +955,14 @@ __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, 
     }
     __syncthreads();
     if (stop_after == 2) return;
+    if (stop_after == 9) { // developer aid (tools/dev_any_init_bits.py): d, e, lambda as raw doubles in the E1 output
+        double* dbg = reinterpret_cast<double*>(E1 + (long)blockIdx.x * n * R);
+        if ((long)n * R * 4 >= (long)(2 * n + Rc) * 8) {
+            for (int i = tid; i < n; i += 256) { dbg[i] = Ld[i]; dbg[n + i] = Le[i]; }
+            for (int r = tid; r < Rc; r += 256) dbg[2 * n + r] = Llam[r];
+        }
+        return;
+    }
     // ---- twisted factorisation, thread per eigenvalue
     for (int r = tid; r < Rc; r += 256) {
         const double lam = Llam[r];
@@ -997,6 +1005,17 @@ __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, 
     }
     __syncthreads();
     if (stop_after == 3) return;
+    if (stop_after >= 1300 && stop_after < 1400) { // developer aid: vectors r0.. of Z as raw doubles in the E1 output
+        double* dbg = reinterpret_cast<double*>(E1 + (long)blockIdx.x * n * R);
+        const int r0 = stop_after - 1300;
+        const long cap = (long)n * R / 2;
+        for (long q = tid; q < cap; q += 256) {
+            const long r = r0 + q / n;
+            dbg[q] = (r < Rc) ? Z[r * n + q % n] : 0.0;
+        }
+        return;
+    }
+
     // ---- orthonormalisation: classical Gram-Schmidt, twice, against the vectors already fixed
     for (int r = 0; r < Rc; r++) {
         double* Zr = Z + (long)r * n;
@@ -1059,7 +1078,11 @@ __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, 
 #pragma unroll
                         for (int c = 0; c < NCT; c++) {
                             const int i = tid + 256 * c;
-                            zv[u][c] = Zp[i < n ? i : n - 1];
+                            const double zz = Zp[i < n ? i : n - 1];
+                            // entries past the side must stay zero: they are part of the norm below (until round 3 the clamped
+                            // load went into x there: harmless while the coefficients are ~1e-16, but the vectors of a cluster
+                            // — rank-deficient matrices — came out with norms below one; found by the oracle's restatement)
+                            zv[u][c] = (i < n) ? zz : 0.0;
                         }
                     }
 #pragma unroll
@@ -1091,6 +1114,16 @@ __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, 
             if (i < n) Zr[i] = x[c];
         }
         __syncthreads();
+    }
+    if (stop_after >= 1400 && stop_after < 1500) { // developer aid: vectors r0.. of Z as raw doubles in the E1 output
+        double* dbg = reinterpret_cast<double*>(E1 + (long)blockIdx.x * n * R);
+        const int r0 = stop_after - 1400;
+        const long cap = (long)n * R / 2;
+        for (long q = tid; q < cap; q += 256) {
+            const long r = r0 + q / n;
+            dbg[q] = (r < Rc) ? Z[r * n + q % n] : 0.0;
+        }
+        return;
     }
     if (stop_after == 4) return;
     // ---- back-transformation x <- H_0 H_1 ... H_{n-3} x, CW vectors per wave at a time, lane owns i = lane + 64 e

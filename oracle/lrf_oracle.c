@@ -1084,11 +1084,13 @@ int lrf_oracle_svd_topr(const float* X, long M, long N, int R, const int8_t* sig
     return 0;
 }
 
-/* The same for any shape: the eigen-problem is solved on the SHORT side (n = min(M, N)); when M < N the roles of the
- * factors swap (u = e sqrt(sigma), v = X^T e / sqrt(sigma)) and the column sign is imposed on the finished v, as
- * include/lrf_hip.h states it.  Odd n: the Gram matrix is bordered with a zero row / column (the Jacobi sweep pairs
- * an even number of indices); the extra eigenvector is e_n with eigenvalue 0 and contributes zero columns at most. */
-int lrf_oracle_svd_topr_any(const float* X, long M, long N, int R, const int8_t* sign, float* u, float* v)
+/* The same for any shape, by the cyclic Jacobi solver — a SECOND OPINION on lrf_oracle_svd_topr_any (lrf_oracle_any.c, the
+ * restatement of the GPU's own eigen-solver): the two agree to fp32 accuracy, not bit for bit.  The eigen-problem is solved
+ * on the SHORT side (n = min(M, N)); when M < N the roles of the factors swap (u = e sqrt(sigma), v = X^T e / sqrt(sigma))
+ * and the column sign is imposed on the finished v, as include/lrf_hip.h states it.  Odd n: the Gram matrix is bordered
+ * with a zero row / column (the Jacobi sweep pairs an even number of indices); the extra eigenvector is e_n with
+ * eigenvalue 0 and contributes zero columns at most. */
+int lrf_oracle_svd_topr_any_jacobi(const float* X, long M, long N, int R, const int8_t* sign, float* u, float* v)
 {
     const int tall = N <= M;
     const long n = tall ? N : M, D = tall ? M : N;
@@ -1173,3 +1175,5 @@ int lrf_oracle_svd_decode_rgb(const uint8_t* qu, const uint8_t* qv, long M, int 
     free(u); free(v); free(X); free(img);
     return 0;
 }
+
+#include "lrf_oracle_any.c"

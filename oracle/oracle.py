@@ -243,6 +243,20 @@ def svd_topr(X, R, sign=None):
     return u, v
 
 
+def svd_topr_u8(X, R, sign=None):
+    """The same for a matrix of uint8-valued floats (svd_encode's and the RGB colour space's [M, c p q] patch matrices), as
+    the GPU computes it: exact Gram matrix, then the restated eigen-solver (lrf_oracle_any.c) — bit for bit the library's."""
+    X = _f32(X)
+    M, N = X.shape
+    u = np.empty((M, R), np.float32)
+    v = np.empty((N, R), np.float32)
+    keep, sp = _sign_arg(sign, R)
+    lib().lrf_oracle_svd_topr_u8.restype = c_int
+    rc = lib().lrf_oracle_svd_topr_u8(_ptr(X, _fp), c_long(M), c_long(N), c_int(R), sp, _ptr(u, _fp), _ptr(v, _fp))
+    assert rc == 0
+    return u, v
+
+
 def svd_decode_rgb(qu, qv, quant_u, quant_v, H, W):
     qu = np.ascontiguousarray(qu, dtype=np.uint8)
     qv = np.ascontiguousarray(qv, dtype=np.uint8)
@@ -259,7 +273,7 @@ def qmf_rgbspace_decompose(img_u8, R, num_iters=10, bounds=(-16, 15), sign=None,
     """uint8 [3,H,W] -> int8 (u [M,R], v [192,R]): X = patchify(pad(img)), SVD initialisation (svd_topr) unless
     `init` = (u0, v0) is given, then the same BCD as the 64-column path (lrf_oracle_bcd is written for any N)."""
     X = pad_patchify(np.asarray(img_u8, dtype=np.float32))
-    u0, v0 = init if init is not None else svd_topr(X, R, sign)
+    u0, v0 = init if init is not None else svd_topr_u8(X, R, sign)
     return bcd(X, u0, v0, num_iters, bounds)
 
 
@@ -272,15 +286,17 @@ def qmf_rgbspace_decode(u, v, H, W):
 
 
 # ---- qmf_encode / qmf_decode, YCbCr branch with any patch size or patch=False (qmf.py:227-286, 325-351) ----------
-def svd_topr_any(X, R, sign=None):
-    """(u0 [M,R], v0 [N,R]) for any shape: eigen-problem on the short side (lrf_oracle_svd_topr_any)."""
+def svd_topr_any(X, R, sign=None, jacobi=False):
+    """(u0 [M,R], v0 [N,R]) for any shape: eigen-problem on the short side.  The default is the restatement of the GPU's
+    own initialisation (lrf_oracle_any.c: bit for bit the library's); jacobi=True the independent cyclic-Jacobi solver."""
     X = _f32(X)
     M, N = X.shape
     u = np.empty((M, R), np.float32)
     v = np.empty((N, R), np.float32)
     keep, sp = _sign_arg(sign, R)
-    lib().lrf_oracle_svd_topr_any.restype = c_int
-    rc = lib().lrf_oracle_svd_topr_any(_ptr(X, _fp), c_long(M), c_long(N), c_int(R), sp, _ptr(u, _fp), _ptr(v, _fp))
+    fn = lib().lrf_oracle_svd_topr_any_jacobi if jacobi else lib().lrf_oracle_svd_topr_any
+    fn.restype = c_int
+    rc = fn(_ptr(X, _fp), c_long(M), c_long(N), c_int(R), sp, _ptr(u, _fp), _ptr(v, _fp))
     assert rc == 0
     return u, v
 
