@@ -105,6 +105,23 @@ def test_repack_is_byte_identical(name):
     assert pack_anyshape(c.ref_factors(), (H, W), c.ranks, tuple(c.kwargs.get("bounds", (-16, 15))), ps) == c.encoded
 
 
+@pytest.mark.parametrize("M,N,R", [(384, 16, 5), (35, 256, 6), (100, 300, 40), (300, 100, 100), (64, 64, 3), (200, 230, 9), (330, 290, 12)])
+def test_oracle_restated_init_agrees_with_jacobi_and_lapack(M, N, R, oracle):
+    """lrf_oracle_svd_topr_any (the restatement of the GPU's eigen-solver, every tridiagonalisation variant) against the
+    independent cyclic-Jacobi routine and numpy's LAPACK SVD: the same rank-R approximation to fp32 accuracy."""
+    rng = np.random.default_rng(M + N + R)
+    X = (rng.normal(size=(M, 12)) @ rng.normal(size=(12, N)) * 20 + rng.normal(size=(M, N)) * 5 + 100).astype(np.float32)
+    u, v = oracle.svd_topr_any(X, R)
+    uj, vj = oracle.svd_topr_any(X, R, jacobi=True)
+    Uf, sf, Vt = np.linalg.svd(X.astype(np.float64), full_matrices=False)
+    Rc = min(R, M, N)
+    best = (Uf[:, :Rc] * sf[:Rc]) @ Vt[:Rc]
+    tol = 2e-3 * sf[0] ** 0.5 + 1e-2
+    assert np.abs(u.astype(np.float64) @ v.T - best).max() < tol
+    assert np.abs(u.astype(np.float64) @ v.T - uj.astype(np.float64) @ vj.T).max() < tol
+    assert np.allclose((v.astype(np.float64) ** 2).sum(0)[:Rc], sf[:Rc], rtol=2e-4, atol=1e-3)
+
+
 def test_oracle_init_wide_and_tall_agree(oracle):
     """svd_topr_any on X and on X^T give the same rank-R approximation (short-side eigen-problem either way)"""
     rng = np.random.default_rng(3)
@@ -180,6 +197,30 @@ def test_hip_own_init_is_close_to_reference(name):
     assert meta == json.loads(lrf_amd.separate_bytes(c.encoded, 2)[0].decode())
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SMALL + NO_INIT + LARGE)
+def test_hip_own_init_equals_oracle_bytes(name, oracle):
+    """The whole default encode — this library's SVD initialisation included — against the oracle's restatement of it
+    (oracle/lrf_oracle_any.c), byte for byte: the tolerances above are only what separates both from LAPACK."""
+    import lrf_amd
+    from lrf_amd.codec import pack_anyshape
+    c = Case(name)
+    ps, K, bounds = _params(c)
+    kw = dict(c.kwargs)
+    if "patch_size" in kw:
+        kw["patch_size"] = tuple(kw["patch_size"])
+    if "bounds" in kw:
+        kw["bounds"] = tuple(kw["bounds"])
+    stream = lrf_amd.qmf_encode(c.image, init_sign=np.concatenate(c.signs()), **kw)
+    fac = oracle.qmf_anyshape_decompose(c.image.numpy(), ps, c.ranks, K, bounds, signs=c.signs())
+    flat = []
+    for u, v in fac:  # (K = 0: the float SVD factors go through .to(int8), truncation toward zero, qmf.py:258-260)
+        u8, v8 = np.trunc(u).astype(np.int8), np.trunc(v).astype(np.int8)
+        flat += [u8, v8] if ps is not None else [u8[None], v8[None]]
+    H, W = c.image.shape[-2:]
+    assert stream == pack_anyshape(flat, (H, W), c.ranks, tuple(c.kwargs.get("bounds", (-16, 15))), ps)
+
+
 SHAPES = [  # M, N, R, K, bounds — products with 1..64 blocks, both native thresholds, wide and tall, rank above 64, rank > min(M, N)
     (7, 16, 1, 3, (-16, 15)), (5, 16, 3, 3, (-16, 15)), (24, 16, 4, 2, (-16, 15)), (3, 5, 2, 4, (-16, 15)),
     (400, 16, 16, 3, (-16, 15)), (1000, 16, 5, 3, (-128, 127)), (96, 1024, 20, 3, (-16, 15)), (35, 256, 4, 10, (-16, 15)),
@@ -213,14 +254,18 @@ def test_hip_bcd_equals_oracle_on_any_shape(M, N, R, K, bounds, oracle):
 @pytest.mark.parametrize("M,N,R", [(384, 16, 5), (35, 256, 6), (100, 300, 40), (300, 100, 100), (64, 64, 3), (513, 300, 7),
                                   (20, 1024, 20), (700, 600, 30)])
 def test_hip_init_matches_oracle_init(M, N, R, oracle):
-    """SVD initialisation on any shape: the rank-R product u0 v0^T agrees with the oracle's (Jacobi) to fp32 accuracy, the
-    column norms are the singular values, the default column sign holds"""
+    """SVD initialisation on any shape: bit for bit the oracle's restatement (lrf_oracle_any.c: all three tridiagonalisation
+    variants are in the list — sides 16 / 35 / 64, 100, 300 / 600); against LAPACK (numpy) and the independent Jacobi solver
+    the rank-R product u0 v0^T agrees to fp32 accuracy, the column norms are the singular values, the default sign holds"""
     from lrf_amd import _lib
     rng = np.random.default_rng(M + N + R)
     base = rng.normal(size=(M, 12)) @ rng.normal(size=(12, N)) * 20 + rng.normal(size=(M, N)) * 5 + 100
     X = base.astype(np.float32)
     ctx = _lib.context()
     u0, v0 = ctx.svd_init(torch.from_numpy(X[None]).cuda(), R)
+    uo, vo = oracle.svd_topr_any(X, R)
+    assert np.array_equal(u0[0].cpu().numpy().view(np.int32), uo.view(np.int32)), "u0 differs from the oracle's"
+    assert np.array_equal(v0[0].cpu().numpy().view(np.int32), vo.view(np.int32)), "v0 differs from the oracle's"
     u0, v0 = u0[0].cpu().numpy().astype(np.float64), v0[0].cpu().numpy().astype(np.float64)
     s = np.linalg.svd(X.astype(np.float64), compute_uv=False)
     Rc = min(R, M, N)
@@ -232,8 +277,30 @@ def test_hip_init_matches_oracle_init(M, N, R, oracle):
     w = np.arange(1, N + 1)[:, None]
     assert ((w * v0[:, :Rc]).sum(0) < 0).all()
     if min(M, N) <= 300:
-        uo, vo = oracle.svd_topr_any(X, R)
-        assert np.abs(uo.astype(np.float64) @ vo.T - u0 @ v0.T).max() < 2e-3 * s[0] ** 0.5 + 1e-2
+        uj, vj = oracle.svd_topr_any(X, R, jacobi=True)
+        assert np.abs(uj.astype(np.float64) @ vj.T - u0 @ v0.T).max() < 2e-3 * s[0] ** 0.5 + 1e-2
+
+
+@pytest.mark.gpu
+def test_hip_init_of_rank_deficient_matrices_equals_oracle(oracle):
+    """Matrices of rank a third of their side, ranks asked beyond it, with sign vectors: the eigenvalues of the null space
+    form clusters (repeated ones included), where the vectors come from the Gram-Schmidt fallbacks.  Bit for bit — this is the
+    case that exposed the clamped loads leaking into the norm in k_any_eig (round 3)."""
+    from lrf_amd import _lib
+    ctx = _lib.context()
+    rng = np.random.default_rng(3)
+    for (M, N, R) in ((200, 17, 17), (96, 256, 70), (40, 40, 45), (14, 46, 18), (31, 389, 37), (300, 150, 80)):
+        k = max(1, min(M, N) // 3)
+        X = (rng.integers(0, 16, (M, k)) @ rng.integers(0, 16, (k, N))).astype(np.float32)
+        sign = (rng.integers(0, 2, R) * 2 - 1).astype(np.int8)
+        u0, v0 = ctx.svd_init(torch.from_numpy(X[None]).cuda(), R, torch.from_numpy(sign[None]).cuda())
+        uo, vo = oracle.svd_topr_any(X, R, sign)
+        assert np.array_equal(u0[0].cpu().numpy().view(np.int32), uo.view(np.int32)), (M, N, R)
+        assert np.array_equal(v0[0].cpu().numpy().view(np.int32), vo.view(np.int32)), (M, N, R)
+        g = v0[0].cpu().numpy().astype(np.float64) if N <= M else u0[0].cpu().numpy().astype(np.float64)
+        nz = [r for r in range(min(R, M, N)) if np.abs(g[:, r]).max() > 0]
+        gn = g[:, nz] / np.linalg.norm(g[:, nz], axis=0)
+        assert np.abs(gn.T @ gn - np.eye(len(nz))).max() < 1e-5, "the short-side vectors are not orthonormal"
 
 
 @pytest.mark.gpu

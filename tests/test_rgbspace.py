@@ -118,12 +118,11 @@ def test_hip_encode_own_init(name, oracle):
     dec = lrf_amd.qmf_decode(enc)
     assert abs(_psnr(c.image.numpy(), dec.numpy()) - c.psnr) < 0.1
     assert abs(len(enc) - len(c.encoded)) <= 0.03 * len(c.encoded) + 16
-    if c.spec["kind"] != "natural":  # against the oracle run the same way: the factors agree except at rounding ties
-        u, v = oracle.qmf_rgbspace_decompose(c.image.numpy(), c.R, c.K, sign=c.z["sign"])
-        from lrf_amd.container import decode_tensor
-        uh, vh = (decode_tensor(f) for f in separate_bytes(separate_bytes(enc, 2)[1], 2))
-        diff = np.mean(uh != u.astype(np.int8)) + np.mean(vh != v.astype(np.int8))
-        assert diff < 0.02, f"{diff:.4f} of the factor entries differ from the oracle's"
+    # against the oracle run the same way (exact Gram matrix + the restated eigen-solver, lrf_oracle_any.c): bit for bit
+    u, v = oracle.qmf_rgbspace_decompose(c.image.numpy(), c.R, c.K, sign=c.z["sign"])
+    from lrf_amd.container import decode_tensor
+    uh, vh = (decode_tensor(f) for f in separate_bytes(separate_bytes(enc, 2)[1], 2))
+    assert np.array_equal(uh, u.astype(np.int8)) and np.array_equal(vh, v.astype(np.int8))
 
 
 @pytest.mark.gpu
@@ -216,7 +215,23 @@ def test_hip_rgb_any_reproduces_reference(name, oracle):
     assert np.array_equal(dec.numpy(), c.decoded)
     enc = lrf_amd.qmf_encode(c.image, color_space="RGB", init=(c.z["u0"], c.z["v0"]), **c.kwargs)
     assert enc == c.encoded, "from the reference's initial factors the encoder must emit the reference's bytes"
-    own = lrf_amd.qmf_encode(c.image, color_space="RGB", **c.kwargs)  # own initialisation: by tolerance
+    own = lrf_amd.qmf_encode(c.image, color_space="RGB", **c.kwargs)  # own initialisation: by tolerance against LAPACK ...
     d2 = lrf_amd.qmf_decode(own)
     assert abs(_psnr(c.image.numpy(), d2.numpy()) - c.psnr) < (1.5 if c.K == 0 else 0.3)
     assert abs(len(own) / len(c.encoded) - 1) < 0.08
+    # ... and bit for bit against the oracle run the same way (8x8 patches: exact Gram matrix of the [M,192] matrix; other
+    # shapes: the short-side eigen-problem of the any-shape path)
+    from lrf_amd.container import decode_tensor, separate_bytes
+    Xo = oracle.rgb_matrix_any(c.image.numpy(), c.patch_size)
+    us, vs = [], []
+    for Xm in ([Xo] if c.patch_size is not None else list(Xo)):
+        u0, v0 = oracle.svd_topr_u8(Xm, c.R) if c.patch_size == (8, 8) else oracle.svd_topr_any(Xm, c.R)
+        if c.K == 0:
+            u, v = torch.from_numpy(u0).to(torch.int8).numpy(), torch.from_numpy(v0).to(torch.int8).numpy()  # the truncating cast
+        else:
+            u, v = oracle.bcd(Xm, u0, v0, c.K, (-16, 15))
+        us.append(u.astype(np.int8)); vs.append(v.astype(np.int8))
+    uo = us[0] if c.patch_size is not None else np.stack(us)
+    vo = vs[0] if c.patch_size is not None else np.stack(vs)
+    uh, vh = (decode_tensor(f) for f in separate_bytes(separate_bytes(own, 2)[1], 2))
+    assert np.array_equal(uh, uo) and np.array_equal(vh, vo), "own-initialisation factors differ from the oracle's"
