@@ -485,3 +485,69 @@ def gen_loess():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "loess":
     gen_loess()
+
+
+# ---- the reference at 8 torch threads against itself at one thread ---------------------------------
+# MKL splits the long `x.mT @ u` reduction (lrf/factorization/qmf.py:107 via :139) differently with more threads, so the
+# reference's own byte stream depends on torch.get_num_threads().  Every other fixture is a one-thread run; this one records
+# how far a default multi-threaded reference user lands from it: stream size, bpp, PSNR and the fraction of int8 factor
+# entries that differ, per case; where the two streams differ (and the image is Kodak-sized or smaller) both are kept, so
+# that a test can measure the distance of the oracle / HIP result to either directly.
+THREAD_CASES = [
+    ("thr_s1_q7", dict(kind="randint", seed=0, H=512, W=768), dict(quality=7)),
+    ("thr_s1_r7", dict(kind="randint", seed=0, H=512, W=768), dict(rank=7)),
+    ("thr_s3_r7", dict(kind="randint", seed=3, H=512, W=768), dict(rank=7)),
+    ("thr_smooth_r7", dict(kind="smooth", seed=21, H=512, W=768), dict(rank=7)),
+    ("thr_smooth_q20", dict(kind="smooth", seed=22, H=512, W=768), dict(quality=20)),
+    ("thr_nat_r7", dict(kind="natural"), dict(rank=7)),
+    ("thr_odd_r7", dict(kind="randint", seed=12, H=173, W=264), dict(rank=7)),
+    ("thr_clic_q7", dict(kind="randint", seed=5, H=1365, W=2048), dict(quality=7)),
+    ("thr_clic_r7", dict(kind="randint", seed=6, H=1365, W=2048), dict(rank=7)),
+    ("thr_clic_smooth_r7", dict(kind="smooth", seed=23, H=1365, W=2048), dict(rank=7)),
+]
+
+
+def gen_threads(n_threads=8):
+    ns = ref_loader.load()
+    records, streams = [], {}
+    for name, spec, kw in THREAD_CASES:
+        torch.set_num_threads(1)  # (the "smooth" recipe itself is pinned at one thread)
+        img = make_image(spec)
+        out = {}
+        for nt in (1, n_threads):
+            torch.set_num_threads(nt)
+            enc = ns.cqmf.qmf_encode(img, **kw)
+            dec = ns.cqmf.qmf_decode(enc)
+            mse = torch.mean((img.float() - dec.float()) ** 2, dim=(-3, -2, -1))
+            fac = [ns.cutils.decode_tensor(f).numpy() for f in ns.cutils.separate_bytes(ns.cutils.separate_bytes(enc, 2)[1], 6)]
+            out[nt] = dict(enc=enc, fac=fac, len=len(enc), bpp=len(enc) * 8 / (img.shape[-2] * img.shape[-1]),
+                           psnr=(20 * torch.log10(255 / torch.sqrt(mse))).item(), sha256=hashlib.sha256(enc).hexdigest())
+        torch.set_num_threads(1)
+        ycbcr = ns.cutils.rgb_to_ycbcr(img.float())
+        chans = ns.cutils.chroma_downsampling(ycbcr, scale_factor=(0.5, 0.5), mode="area")
+        meta = json.loads(ns.cutils.separate_bytes(out[1]["enc"], 2)[0].decode())
+        signs = []
+        for c, ch in enumerate(chans):
+            x = ns.cqmf.patchify(ns.cutils.pad_image(ch, (8, 8), mode="reflect"), (8, 8))
+            u0, v0, _ = ns.fqmf.SVDInit(rank=meta["rank"][c])(x.unsqueeze(0).float())
+            signs.append([int(s) for s in wsign(v0[0].numpy())])
+        a, b = out[1], out[n_threads]
+        ndiff = sum(int((x != y).sum()) for x, y in zip(a["fac"], b["fac"]))
+        ntot = sum(x.size for x in a["fac"])
+        rec = dict(name=name, spec=spec, kwargs=kw, ranks=meta["rank"], signs=signs, threads=n_threads,
+                   image_sha256=hashlib.sha256(img.numpy().tobytes()).hexdigest(),
+                   t1={k: a[k] for k in ("len", "bpp", "psnr", "sha256")}, tN={k: b[k] for k in ("len", "bpp", "psnr", "sha256")},
+                   differing_entries=ndiff, entries=ntot,
+                   max_abs_entry_diff=max(int(np.abs(x.astype(np.int16) - y.astype(np.int16)).max()) for x, y in zip(a["fac"], b["fac"])))
+        records.append(rec)
+        if img.shape[-2] * img.shape[-1] <= 512 * 768 * 2 and a["sha256"] != b["sha256"]:
+            streams[name + "_t1"] = np.frombuffer(a["enc"], np.uint8)
+            streams[name + "_tN"] = np.frombuffer(b["enc"], np.uint8)
+        print(name, {k: rec[k] for k in ("t1", "tN", "differing_entries", "entries", "max_abs_entry_diff")}, flush=True)
+    with open(os.path.join(OUT, "threads8.json"), "w") as f:
+        json.dump(records, f, indent=1)
+    np.savez_compressed(os.path.join(OUT, "threads8_streams.npz"), **streams)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "threads":
+    gen_threads()
