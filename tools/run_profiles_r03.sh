@@ -1,0 +1,48 @@
+#!/bin/bash
+# Round-3 profile set (GPU box).  usage: bash tools/run_profiles_r03.sh <tag>   (outputs under gpurun_out/<tag>/)
+#   bench lines of the three configs, rocprofv3 kernel stats of the default bench command, two PMC passes for HBM traffic,
+#   two SQ counter passes, kernel stats of the rank sweep (64 images; 256 images timed without the profiler), of the CLIC-sized
+#   and of the svd config, the config-3 R-D table.
+# rocprofv3 gets `python3 <script>` directly after `--` (no env / shell hop), counters in passes of their own.
+set -e
+TAG=${1:-r03_a}
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+python bench.py > $OUT/bench.json 2> $OUT/bench.err
+python bench.py --config clic --steps 5 --warmup 1 > $OUT/bench_clic.json 2> $OUT/bench_clic.err
+python bench.py --config svd --steps 5 --warmup 1 > $OUT/bench_svd.json 2> $OUT/bench_svd.err
+python tools/run_config3.py $OUT/config3.json > $OUT/config3.txt 2> $OUT/config3.err
+cd /tmp
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats -o run -- python3 $REPO/bench.py --no-cpu-baseline > $OUT/stats_bench.json 2> $OUT/stats.err
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats_plain -o run -- python3 $REPO/bench.py --no-extras > $OUT/stats_plain_bench.json 2> $OUT/stats_plain.err
+rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o run -- python3 $REPO/bench.py --no-extras --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o run -- python3 $REPO/bench.py --no-extras --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_write.err
+rocprofv3 --output-format csv --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU GRBM_GUI_ACTIVE -d $OUT/sq_a -o run -- python3 $REPO/bench.py --no-extras --steps 2 --warmup 1 > /dev/null 2> $OUT/sq_a.err
+rocprofv3 --output-format csv --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/sq_b -o run -- python3 $REPO/bench.py --no-extras --steps 2 --warmup 1 > /dev/null 2> $OUT/sq_b.err
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats_rank -o run -- python3 $REPO/tools/dev_rank_sweep.py > $OUT/rank_sweep.txt 2> $OUT/stats_rank.err
+LRF_SWEEP_BATCH=256 python3 $REPO/tools/dev_rank_sweep.py > $OUT/rank_sweep256.txt 2> $OUT/rank_sweep256.err
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats_svd -o run -- python3 $REPO/bench.py --config svd --steps 3 --warmup 1 > /dev/null 2> $OUT/stats_svd.err
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats_clic -o run -- python3 $REPO/bench.py --config clic --steps 3 --warmup 1 --no-extras > /dev/null 2> $OUT/stats_clic.err
+cd $REPO
+python tools/make_traffic.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/traffic.json
+python3 - "$OUT" <<'PY'
+import csv, glob, sys, collections
+out = sys.argv[1]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for d in ("sq_a", "sq_b"):
+    for f in glob.glob(f"{out}/{d}/**/*counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            k = row["Kernel_Name"].split("(")[0].replace("void ", "")
+            if k.startswith("at::") or "elementwise" in k or "rocclr" in k:
+                continue
+            acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+with open(f"{out}/sq_counters.csv", "w") as f:
+    f.write("kernel,counter,launches,avg_per_launch\n")
+    for k in sorted(acc):
+        for c in sorted(acc[k]):
+            v = acc[k][c]
+            f.write(f'"{k}",{c},{len(v)},{sum(v)/len(v):.0f}\n')
+PY
+find $OUT -name "*kernel_stats.csv"
