@@ -6,7 +6,8 @@
 // uint8-valued matrices, k_gram192_u8, or fp64, k_gram_blk below) through the
 // eigen-solver of the any-shape path (k_any_eig<1>, lrf_anyshape_kernels.hip: Householder tridiagonalisation, multisection,
 // twisted factorisation, Gram-Schmidt, back-transformation) and its ordered product (k_any_prod) for u = X w.  Parity for
-// this path is by tolerance.
+// this path against the reference is by tolerance (LAPACK's SVD there); against the oracle, which
+// restates this solver operation for operation (oracle/lrf_oracle_any.c), the encoder is byte for byte.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
