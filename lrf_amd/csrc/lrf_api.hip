@@ -1516,24 +1516,31 @@ int lrf_debug_read_gram_stamps(lrf_ctx* c, unsigned long long* out_host, int n)
 #endif
 
 // Gram matrices of B matrices [M,192] of uint8-valued floats (svd_encode, RGB colour-space branch): exact, int8 MFMA
-static int gram192_u8(lrf_ctx* c, const float* X, long xs, int B, int M, double* G)
+// int32 sums hold 128^2 x 131072 rows; longer matrices take the fp64 kernel (float X only)
+#define LRF_G192_MAX_ROWS 100000
+extern "C++" {
+template <typename T>
+static int gram192_u8(lrf_ctx* c, const T* X, long xs, int B, int M, double* G)
 {
     static const bool use_f64 = getenv("LRF_GRAM192_F64") && getenv("LRF_GRAM192_F64")[0] == '1'; // developer comparison aid
-    if (use_f64 || M > 100000) { // int32 sums hold 128^2 x 131072 rows; longer matrices take the fp64 kernel
-        hipLaunchKernelGGL(k_gram_blk, dim3(6, (unsigned)B), dim3(256), 0, c->stream, X, xs, M, 192, 3, G);
-        LAUNCH_CHECK();
-        return LRF_OK;
+    if constexpr (sizeof(T) == 4) {
+        if (use_f64 || M > LRF_G192_MAX_ROWS) {
+            hipLaunchKernelGGL(k_gram_blk, dim3(6, (unsigned)B), dim3(256), 0, c->stream, X, xs, M, 192, 3, G);
+            LAUNCH_CHECK();
+            return LRF_OK;
+        }
     }
     const int nchunks = (M + LRF_G192_ROWS - 1) / LRF_G192_ROWS;
     int rc;
     if ((rc = ensure(c, c->any_td, (size_t)B * nchunks * (192 * 192 + 192) * sizeof(int)))) return rc;
     int* P = (int*)c->any_td.p; // consumed by the fold before the eigen-solver reuses the buffer (same stream)
-    hipLaunchKernelGGL(k_gram192_u8, dim3((unsigned)nchunks, (unsigned)B), dim3(256), 0, c->stream, X, xs, M, P, nchunks);
+    hipLaunchKernelGGL((k_gram192_u8<T>), dim3((unsigned)nchunks, (unsigned)B), dim3(256), 0, c->stream, X, xs, M, P, nchunks);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_gram192_fold, dim3(144, (unsigned)B), dim3(256), 0, c->stream, (const int*)P, nchunks, M, G);
     LAUNCH_CHECK();
     return LRF_OK;
 }
+} // extern "C++"
 
 /* ---- SVD baseline (lrf.svd_encode / svd_decode, default RGB branch) ---- */
 static int svd_geom(int64_t H, int64_t W, int* hp, int* wp, int* top, int* left, int* nw, int* M)
@@ -1571,10 +1578,26 @@ int lrf_svd_encode_rgb_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_t H, 
     float* Wn = (float*)c->swn.p;
     float* Uf = (float*)c->suf.p;
     float* mm = (float*)c->smm.p;
-    hipLaunchKernelGGL(k_patchify_rgb, dim3(hp / 8, (unsigned)B), dim3(256), 0, c->stream, rgb, (int)H, (int)W, top, left, nw, xs, X);
-    LAUNCH_CHECK();
-    if ((rc = gram192_u8(c, X, xs, (int)B, M, G))) return rc;
-    if ((rc = any_factors_from_gram(c, X, G, (int)B, M, N, R, sign, Vn, Wn, Uf))) return rc;
+    static const bool f32_matrix = getenv("LRF_SVD_F32_MATRIX") && getenv("LRF_SVD_F32_MATRIX")[0] == '1'; // developer comparison aid
+    if (R <= 8 && M <= LRF_G192_MAX_ROWS && !f32_matrix) {
+        // the matrix as BYTES (round 3): its three passes — this one, the exact Gram matrix, u = X w — move a quarter of the bytes
+        uint8_t* X8 = (uint8_t*)c->sx.p; // (allocated for the float matrix: four times what the bytes need)
+        hipLaunchKernelGGL((k_patchify_rgb<uint8_t>), dim3(hp / 8, (unsigned)B), dim3(256), 0, c->stream, rgb, (int)H, (int)W, top, left, nw, xs, X8);
+        LAUNCH_CHECK();
+        if ((rc = gram192_u8(c, (const uint8_t*)X8, xs, (int)B, M, G))) return rc;
+        if ((rc = any_eig_from_gram(c, G, (int)B, M, N, R, sign, Vn, Wn))) return rc;
+        const dim3 pg((unsigned)((M + 255) / 256), (unsigned)B);
+        if (R <= 4)
+            hipLaunchKernelGGL((k_prod192_u8<4>), pg, dim3(256), 0, c->stream, (const uint8_t*)X8, xs, M, (const float*)Wn, R, Uf);
+        else
+            hipLaunchKernelGGL((k_prod192_u8<8>), pg, dim3(256), 0, c->stream, (const uint8_t*)X8, xs, M, (const float*)Wn, R, Uf);
+        LAUNCH_CHECK();
+    } else {
+        hipLaunchKernelGGL((k_patchify_rgb<float>), dim3(hp / 8, (unsigned)B), dim3(256), 0, c->stream, rgb, (int)H, (int)W, top, left, nw, xs, X);
+        LAUNCH_CHECK();
+        if ((rc = gram192_u8(c, (const float*)X, xs, (int)B, M, G))) return rc;
+        if ((rc = any_factors_from_gram(c, X, G, (int)B, M, N, R, sign, Vn, Wn, Uf))) return rc;
+    }
     hipLaunchKernelGGL(k_minmax, dim3((unsigned)B), dim3(256), 0, c->stream, (const float*)Uf, (long)M * R, (long)M * R, mm);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_minmax, dim3((unsigned)B), dim3(256), 0, c->stream, (const float*)Vn, (long)N * R, (long)N * R, mm + 2 * B);
@@ -1632,7 +1655,7 @@ int lrf_qmf_rgbspace_encode_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_
     float* X = (float*)c->sx.p;
     {
         Prof p(c, LRF_K_PLANES);
-        hipLaunchKernelGGL(k_patchify_rgb, dim3(hp / 8, (unsigned)B), dim3(256), 0, c->stream, rgb, (int)H, (int)W, top, left, nw, xs, X);
+        hipLaunchKernelGGL((k_patchify_rgb<float>), dim3(hp / 8, (unsigned)B), dim3(256), 0, c->stream, rgb, (int)H, (int)W, top, left, nw, xs, X);
         LAUNCH_CHECK();
     }
     // The factorisation itself runs on the any-shape kernels (lrf_anyshape_kernels.hip): measured against a dedicated
@@ -1649,7 +1672,7 @@ int lrf_qmf_rgbspace_encode_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_
         double* G = (double*)c->sg.p;
         float* Wn = (float*)c->swn.p;
         Prof p(c, LRF_K_INIT);
-        if ((rc = gram192_u8(c, X, xs, (int)B, M, G))) return rc;
+        if ((rc = gram192_u8(c, (const float*)X, xs, (int)B, M, G))) return rc;
         if ((rc = any_factors_from_gram(c, X, G, (int)B, M, N, R, sign, Vf, Wn, Uf))) return rc;
     }
     return any_run_bcd(c, X, (int)B, M, N, R, K, lo, hi, U, V);

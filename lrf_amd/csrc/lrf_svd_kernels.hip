@@ -12,12 +12,15 @@
 #include <stdint.h>
 
 // ---- "c (h p) (w q) -> (h w) (c p q)" with reflect padding: one workgroup per (patch row, image) ----
+// T = float: the matrix the factorisation kernels take.  T = uint8_t (round 3, svd_encode): the same matrix as bytes — a quarter
+// of the traffic for the three passes of svd_encode over it (this one, the exact Gram matrix, u = X w).
+template <typename T>
 __global__ __launch_bounds__(256) void k_patchify_rgb(const uint8_t* __restrict__ rgb, int H, int W, int top, int left,
-                                                      int nw, long img_floats, float* __restrict__ X)
+                                                      int nw, long img_floats, T* __restrict__ X)
 {
     const int hh = blockIdx.x;
     const uint8_t* img = rgb + (long)blockIdx.y * 3 * H * W;
-    float* Xp = X + (long)blockIdx.y * img_floats + (long)hh * nw * 192;
+    T* Xp = X + (long)blockIdx.y * img_floats + (long)hh * nw * 192;
     for (int it = threadIdx.x; it < nw * 48; it += 256) {
         const int ww = it / 48, rem = it - ww * 48;
         const int c = rem >> 4, a = (rem >> 1) & 7, b4 = (rem & 1) * 4;
@@ -25,16 +28,22 @@ __global__ __launch_bounds__(256) void k_patchify_rgb(const uint8_t* __restrict_
         f32x4 out;
         const int x0 = ww * 8 + b4 - left;
         const uint8_t* rowp = img + (long)c * H * W + (long)y * W;
+        uint32_t w4;
         if (x0 >= 0 && x0 + 3 < W) { // no reflection inside these four pixels: one (unaligned) word instead of four byte loads
             typedef uint32_t __attribute__((aligned(1))) u32u;
-            const uint32_t w4 = *reinterpret_cast<const u32u*>(rowp + x0);
+            w4 = *reinterpret_cast<const u32u*>(rowp + x0);
+        } else {
+            w4 = 0;
 #pragma unroll
-            for (int i = 0; i < 4; i++) out[i] = (float)((w4 >> (8 * i)) & 255u);
+            for (int i = 0; i < 4; i++) w4 |= (uint32_t)rowp[reflect_idx(x0 + i, W)] << (8 * i);
+        }
+        if constexpr (sizeof(T) == 1) {
+            *reinterpret_cast<uint32_t*>(Xp + ww * 192 + c * 64 + a * 8 + b4) = w4;
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; i++) out[i] = (float)rowp[reflect_idx(x0 + i, W)];
+            for (int i = 0; i < 4; i++) out[i] = (float)((w4 >> (8 * i)) & 255u);
+            *reinterpret_cast<f32x4*>(Xp + ww * 192 + c * 64 + a * 8 + b4) = out;
         }
-        *reinterpret_cast<f32x4*>(Xp + ww * 192 + c * 64 + a * 8 + b4) = out;
     }
 }
 
@@ -115,11 +124,12 @@ __global__ __launch_bounds__(256) void k_gram_blk(const float* __restrict__ X, l
 // the column sums of its tiles as products with a tile of ones.  k_gram192_fold adds the chunks' int32
 // partials and the offset terms.  256 x [6144,192]: 2.49 ms (k_gram_blk, fp64 MFMA at 39 % of its peak) -> 0.8 ms with strided dword loads -> see DESIGN.md.
 #define LRF_G192_ROWS 1536
-__global__ __launch_bounds__(256) void k_gram192_u8(const float* __restrict__ X, long x_stride, int M, int* __restrict__ P, int nchunks)
+template <typename T> // float: uint8-valued floats; uint8_t: the bytes themselves (k_patchify_rgb<uint8_t>)
+__global__ __launch_bounds__(256) void k_gram192_u8(const T* __restrict__ X, long x_stride, int M, int* __restrict__ P, int nchunks)
 {
     __shared__ uint4 lds[2][12 * 64]; // [buffer][tile][lane = 16 kq + li]: rows 16 kq .. + 15 of column 16 tile + li; 24 KB
     const int chunk = blockIdx.x;
-    const float* Xp = X + (long)blockIdx.y * x_stride;
+    const T* Xp = X + (long)blockIdx.y * x_stride;
     int* Pp = P + ((long)blockIdx.y * nchunks + chunk) * (192 * 192 + 192);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -137,7 +147,9 @@ __global__ __launch_bounds__(256) void k_gram192_u8(const float* __restrict__ X,
     // operand layout ran at 1.5 TB/s): item = (row group g of 4 rows, column group c4 of 4 columns), 16 x 48 items, three
     // per thread; its 4 x 4 values become int8, are transposed in registers (v_perm_b32) and go to LDS as four dwords, each
     // the four rows of one column — so that an operand (sixteen rows of a column) is one ds_read_b128.
-    f32x4 vals[3][4];
+    constexpr bool BYTES = sizeof(T) == 1;
+    f32x4 vals[BYTES ? 1 : 3][BYTES ? 1 : 4];
+    unsigned valb[BYTES ? 3 : 1][BYTES ? 4 : 1]; // bytes: the four columns of a row as one dword
     auto load_block = [&](int blk) __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < 3; it++) {
@@ -145,8 +157,14 @@ __global__ __launch_bounds__(256) void k_gram192_u8(const float* __restrict__ X,
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int row = row_lo + blk * 64 + 4 * g + r;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(Xp + (long)(row < row_hi ? row : row_hi - 1) * 192 + 4 * c4);
-                vals[it][r] = (row < row_hi) ? v : (f32x4){128.f, 128.f, 128.f, 128.f}; // rows past the end: a = 0
+                const long off = (long)(row < row_hi ? row : row_hi - 1) * 192 + 4 * c4;
+                if constexpr (BYTES) {
+                    const unsigned v = *reinterpret_cast<const unsigned*>(Xp + off);
+                    valb[it][r] = (row < row_hi) ? v : 0x80808080u; // rows past the end: a = 0
+                } else {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(Xp + off);
+                    vals[it][r] = (row < row_hi) ? v : (f32x4){128.f, 128.f, 128.f, 128.f};
+                }
             }
         }
     };
@@ -159,9 +177,13 @@ __global__ __launch_bounds__(256) void k_gram192_u8(const float* __restrict__ X,
             unsigned rw[4]; // row r: its four columns as bytes
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const f32x4 v = vals[it][r];
-                rw[r] = ((unsigned)((int)v[0] - 128) & 255u) | (((unsigned)((int)v[1] - 128) & 255u) << 8) |
-                        (((unsigned)((int)v[2] - 128) & 255u) << 16) | (((unsigned)((int)v[3] - 128) & 255u) << 24);
+                if constexpr (BYTES) {
+                    rw[r] = valb[it][r] ^ 0x80808080u; // x - 128 as int8, four at a time
+                } else {
+                    const f32x4 v = vals[it][r];
+                    rw[r] = ((unsigned)((int)v[0] - 128) & 255u) | (((unsigned)((int)v[1] - 128) & 255u) << 8) |
+                            (((unsigned)((int)v[2] - 128) & 255u) << 16) | (((unsigned)((int)v[3] - 128) & 255u) << 24);
+                }
             }
             // 4 x 4 byte transpose: cw[i] = column i, its four rows
             const unsigned t0 = __builtin_amdgcn_perm(rw[1], rw[0], 0x05010400u), t1 = __builtin_amdgcn_perm(rw[1], rw[0], 0x07030602u);
@@ -222,6 +244,56 @@ __global__ __launch_bounds__(256) void k_gram192_fold(const int* __restrict__ P,
         sj += pc[192 * 192 + j];
     }
     G[(long)blockIdx.y * 192 * 192 + e] = (double)(S + 128 * (si + sj) + 16384ll * M);
+}
+
+// ---- u = X w for the byte matrix [M,192] and R <= RP columns (svd_encode, round 3): U[m][r] = the k-ordered fp32 fma chain
+// over k = 0..191 of x[m][k] w[k][r] — one block of the reference's K-blocking, the chain k_any_prod's MFMA tiles compute —
+// with lane = row: a thread loads its row's 192 bytes (twelve 16-byte loads; the 64 rows of a wave are 12 KB contiguous) and
+// reads w[k][0..RP) from an LDS table by broadcast ds_read_b128s.  k_any_prod took 0.67 ms for 256 x [6144,192] x [192,5]
+// (a 32-wide rank tile with 5 columns in use, 1.2 GB of fp32 X at 1.8 TB/s).  grid (ceil(M/256), B)
+template <int RP>
+__global__ __launch_bounds__(256) void k_prod192_u8(const uint8_t* __restrict__ X, long x_stride, int M, const float* __restrict__ Wn, int R,
+                                                    float* __restrict__ Uf)
+{
+    __shared__ __attribute__((aligned(16))) float Ws[192 * RP];
+    const float* Wb = Wn + (long)blockIdx.y * 192 * R;
+    for (int e = threadIdx.x; e < 192 * RP; e += 256) {
+        const int k = e / RP, r = e - k * RP;
+        Ws[e] = (r < R) ? Wb[k * R + r] : 0.f;
+    }
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    const uint8_t* xr = X + (long)blockIdx.y * x_stride + (long)(m < M ? m : M - 1) * 192;
+    uint4 xn = *reinterpret_cast<const uint4*>(xr);
+    __syncthreads();
+    float acc[RP];
+#pragma unroll
+    for (int r = 0; r < RP; r++) acc[r] = 0.f;
+    // sixteen columns per trip, the next sixteen bytes of the row requested before this trip's arithmetic; the loop is NOT
+    // unrolled: with all 192 steps in one block the compiler hoists the 384 table reads and spills 1600 registers
+#pragma unroll 1
+    for (int i = 0; i < 12; i++) {
+        const unsigned w4[4] = {xn.x, xn.y, xn.z, xn.w};
+        xn = *reinterpret_cast<const uint4*>(xr + 16 * (i < 11 ? i + 1 : 11));
+        const float* wi = &Ws[16 * i * RP];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const float x = (float)((w4[j >> 2] >> (8 * (j & 3))) & 255u);
+#pragma unroll
+            for (int r = 0; r < RP; r += 4) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(wi + j * RP + r);
+                acc[r] = fmaf(x, wv[0], acc[r]);
+                acc[r + 1] = fmaf(x, wv[1], acc[r + 1]);
+                acc[r + 2] = fmaf(x, wv[2], acc[r + 2]);
+                acc[r + 3] = fmaf(x, wv[3], acc[r + 3]);
+            }
+        }
+    }
+    if (m < M) {
+        float* uo = Uf + ((long)blockIdx.y * M + m) * R;
+#pragma unroll
+        for (int r = 0; r < RP; r++)
+            if (r < R) uo[r] = acc[r];
+    }
 }
 
 // ---- reductions shared with the eigen-solver of the any-shape path (k_any_eig, lrf_anyshape_kernels.hip) ----
