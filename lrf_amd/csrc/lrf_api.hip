@@ -114,6 +114,14 @@ struct lrf_ctx {
     TableSet talt[LRF_TABLE_SETS - 1];
     unsigned long tstamp = 0;
     unsigned attr_done = 0;      // hipFuncSetAttribute call sites already executed for this context's device (bit per site)
+    // Kernel families of one call on streams of their own (run_init / run_bcd): the runs of plan_runs touch disjoint planes, so
+    // the whole chain of a run — initialisation, b table, K x (U update, V update) — is independent of the other runs'; the
+    // first run stays on `stream`, the others fork behind the Gram pass and are joined at the end of run_bcd.  Created on
+    // first use (a call with 3072 blocks or more that mixes rank families); never while kernel profiling is on.
+    hipStream_t fam_stream[2] = {nullptr, nullptr};
+    hipEvent_t fam_fork = nullptr, fam_join[2] = {nullptr, nullptr};
+    bool fam_parallel = false;   // set by the fused entry points whose run_init is followed by run_bcd at once
+    bool fam_forked = false;     // run_init forked: run_bcd uses the same streams and joins
     hipEvent_t planes_done = nullptr; // set by a pipe: recorded after the planes kernel of lrf_qmf_encode_rgb_u8 (input buffer free)
 };
 
@@ -335,6 +343,34 @@ static FamBufs run_bufs(lrf_ctx* c, const FamRun& r, bool mixed)
     return FamBufs{(float*)c->vf.p, (float*)c->wf.p, (float*)c->bf.p, (float*)c->ppart.p, (float*)c->qpart.p};
 }
 
+static hipStream_t run_stream(lrf_ctx* c, size_t run_idx) { return (c->fam_forked && run_idx > 0) ? c->fam_stream[run_idx - 1] : c->stream; }
+static int fam_fork_streams(lrf_ctx* c, size_t nruns)
+{
+    static const bool off = getenv("LRF_NO_FAMILY_STREAMS") && getenv("LRF_NO_FAMILY_STREAMS")[0] == '1'; // developer comparison aid
+    c->fam_forked = false;
+    if (off || !c->fam_parallel || c->profile || nruns < 2 || nruns > 3) return LRF_OK;
+    if (!c->fam_fork) HIP_TRY(hipEventCreateWithFlags(&c->fam_fork, hipEventDisableTiming));
+    for (size_t i = 0; i + 1 < nruns; i++) {
+        if (!c->fam_stream[i]) HIP_TRY(hipStreamCreateWithFlags(&c->fam_stream[i], hipStreamNonBlocking));
+        if (!c->fam_join[i]) HIP_TRY(hipEventCreateWithFlags(&c->fam_join[i], hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventRecord(c->fam_fork, c->stream));
+    for (size_t i = 0; i + 1 < nruns; i++) HIP_TRY(hipStreamWaitEvent(c->fam_stream[i], c->fam_fork, 0));
+    c->fam_forked = true;
+    return LRF_OK;
+}
+static int fam_join_streams(lrf_ctx* c, size_t nruns)
+{
+    if (!c->fam_forked) return LRF_OK;
+    c->fam_forked = false;
+    for (size_t i = 0; i + 1 < nruns && i < 2; i++) {
+        if (!c->fam_stream[i] || !c->fam_join[i]) continue;
+        HIP_TRY(hipEventRecord(c->fam_join[i], c->fam_stream[i]));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->fam_join[i], 0));
+    }
+    return LRF_OK;
+}
+
 // Row chunks of the exact Gram pass (k_gram64: one workgroup per chunk, one 128-bit partial per chunk for k_init to add):
 // LRF_GRAM_ROWS rows each — fewer for small calls, so that the pass still has a few workgroups per CU (a chunk is a latency
 // chain of 64-row blocks: one 512x768 image 38 -> 14 us, 64 images 57 -> 44 us).  Exact integer sums: the cut does not change a bit.
@@ -439,10 +475,16 @@ static int run_init(lrf_ctx* c, const float* X, const Tables& t, const int8_t* s
     Prof p(c, LRF_K_INIT);
     const std::vector<FamRun> runs = plan_runs(t);
     const bool mixed = plan_is_mixed(runs);
-    for (const FamRun& r : runs) {
+    {
+        int rcf = fam_fork_streams(c, runs.size());
+        if (rcf) return rcf;
+    }
+    for (size_t ri = 0; ri < runs.size(); ri++) {
+        const FamRun& r = runs[ri];
+        hipStream_t rs = run_stream(c, ri);
         const FamBufs fb = run_bufs(c, r, mixed);
 #define LRF_LAUNCH_INIT(ZR)                                                                                          \
-    hipLaunchKernelGGL(k_init<ZR>, dim3(r.nplanes), dim3(256), sizeof(InitLds<ZR>), c->stream, (const ulonglong2*)c->gpart.p, \
+    hipLaunchKernelGGL(k_init<ZR>, dim3(r.nplanes), dim3(256), sizeof(InitLds<ZR>), rs, (const ulonglong2*)c->gpart.p, \
                        (const int*)c->gexp.p, gram_exp, (const PlaneDesc*)c->planes.p, sign_dev, fb.vf, fb.wf, c->init_sweeps, r.pitch, r.plane0)
         if (r.rmax <= 8) LRF_LAUNCH_INIT(8);
         else if (r.rmax <= 16) LRF_LAUNCH_INIT(16);
@@ -498,12 +540,14 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
         c->attr_done |= 1u << 2;
     }
     // the b tables of the initial V
-    for (const FamRun& r : runs) {
+    for (size_t ri = 0; ri < runs.size(); ri++) {
+        const FamRun& r = runs[ri];
+        hipStream_t rs = run_stream(c, ri);
         const FamBufs fb = run_bufs(c, r, mixed);
         if (r.pitch == 16)
-            hipLaunchKernelGGL(k_bprep, dim3(r.nplanes), dim3(256), 0, c->stream, pl, (const float*)fb.vf, fb.bf, r.plane0);
+            hipLaunchKernelGGL(k_bprep, dim3(r.nplanes), dim3(256), 0, rs, pl, (const float*)fb.vf, fb.bf, r.plane0);
         else
-            hipLaunchKernelGGL(k_bprep_big, dim3(r.nplanes), dim3(256), 0, c->stream, pl, (const float*)fb.vf, fb.bf, r.plane0);
+            hipLaunchKernelGGL(k_bprep_big, dim3(r.nplanes), dim3(256), 0, rs, pl, (const float*)fb.vf, fb.bf, r.plane0);
         LAUNCH_CHECK();
     }
     // Iterations >= 2 with bounds where every term and partial sum of `uu @ bb` is an exact integer in fp32 for the largest
@@ -516,20 +560,22 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
         {
             Prof p(c, LRF_K_BCD);
             const int mode = (it == 0) ? first_mode : 0;
-            for (const FamRun& r : runs) {
+            for (size_t ri = 0; ri < runs.size(); ri++) {
+                const FamRun& r = runs[ri];
+                hipStream_t rs = run_stream(c, ri);
                 const FamBufs fb = run_bufs(c, r, mixed);
                 const BlockDesc* blr = bl + r.block0;
                 const int nbr = r.nblocks;
                 GsParams gpr = gp;
                 gpr.exact_int = (!exact_off && (long)(r.rmax - 1) * 64 * mx_b * mx_b * mx_b < (1L << 24)) ? 1 : 0;
 #define LRF_LAUNCH_W(MODE)                                                                                           \
-    hipLaunchKernelGGL((k_bcd_w<MODE>), dim3((nbr + LRF_BCDW_WAVES - 1) / LRF_BCDW_WAVES), dim3(64 * LRF_BCDW_WAVES), LRF_BCDW_LDS, c->stream, X, pl, blr, \
+    hipLaunchKernelGGL((k_bcd_w<MODE>), dim3((nbr + LRF_BCDW_WAVES - 1) / LRF_BCDW_WAVES), dim3(64 * LRF_BCDW_WAVES), LRF_BCDW_LDS, rs, X, pl, blr, \
                        (const float*)fb.vf, (const float*)fb.wf, (const float*)fb.bf, U0, U, fb.pp, fb.qp, gpr, nbr)
 #define LRF_LAUNCH_WG(MODE, RMAX)                                                                                    \
-    hipLaunchKernelGGL((k_bcd<MODE, RMAX>), dim3(nbr), dim3(256), 0, c->stream, X, pl, blr, (const float*)fb.vf, (const float*)fb.wf, \
+    hipLaunchKernelGGL((k_bcd<MODE, RMAX>), dim3(nbr), dim3(256), 0, rs, X, pl, blr, (const float*)fb.vf, (const float*)fb.wf, \
                        (const float*)fb.bf, U0, U, fb.pp, fb.qp, gpr)
 #define LRF_LAUNCH_MID(MODE)                                                                                         \
-    hipLaunchKernelGGL((k_bcd_mid<MODE>), dim3(nbr), dim3(256), sizeof(MidLds<MODE>), c->stream, X, pl, blr, (const float*)fb.vf, \
+    hipLaunchKernelGGL((k_bcd_mid<MODE>), dim3(nbr), dim3(256), sizeof(MidLds<MODE>), rs, X, pl, blr, (const float*)fb.vf, \
                        (const float*)fb.wf, (const float*)fb.bf, U0, U, fb.pp, fb.qp, gpr)
                 if (r.fam == 2) {
                     if (mode == 1) LRF_LAUNCH_MID(1);
@@ -548,7 +594,7 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
                     // the first iteration from the initialisation's W0 unless a plane is small enough for ATen's native order
 #define LRF_LAUNCH_W16(MODE)                                                                                         \
     hipLaunchKernelGGL((k_bcd_w16<MODE>), dim3((nbr + LRF_BCDW16_WAVES - 1) / LRF_BCDW16_WAVES), dim3(64 * LRF_BCDW16_WAVES), LRF_BCDW16_LDS, \
-                       c->stream, X, pl, blr, (const float*)fb.vf, (const float*)fb.wf, (const float*)fb.bf, U, fb.pp, fb.qp, gpr, nbr)
+                       rs, X, pl, blr, (const float*)fb.vf, (const float*)fb.wf, (const float*)fb.bf, U, fb.pp, fb.qp, gpr, nbr)
                     if (mode == 1) LRF_LAUNCH_W16(1);
                     else LRF_LAUNCH_W16(0);
 #undef LRF_LAUNCH_W16
@@ -566,22 +612,24 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
         {
             Prof p(c, LRF_K_VUPDATE);
             const int last = it == K - 1 ? 1 : 0;
-            for (const FamRun& r : runs) {
+            for (size_t ri = 0; ri < runs.size(); ri++) {
+                const FamRun& r = runs[ri];
+                hipStream_t rs = run_stream(c, ri);
                 const FamBufs fb = run_bufs(c, r, mixed);
                 if (r.fam == 2)
-                    hipLaunchKernelGGL(k_vupdate_mid, dim3(r.nplanes), dim3(256), sizeof(BigVLds), c->stream, pl, (const float*)fb.pp,
+                    hipLaunchKernelGGL(k_vupdate_mid, dim3(r.nplanes), dim3(256), sizeof(BigVLds), rs, pl, (const float*)fb.pp,
                                        (const float*)fb.qp, fb.vf, fb.bf, V, gp.lo, gp.hi, last, r.plane0);
                 else if (r.fam == 0)
-                    hipLaunchKernelGGL(k_vupdate<8>, dim3(r.nplanes), dim3(256), 0, c->stream, pl, (const float*)fb.pp, (const float*)fb.qp,
+                    hipLaunchKernelGGL(k_vupdate<8>, dim3(r.nplanes), dim3(256), 0, rs, pl, (const float*)fb.pp, (const float*)fb.qp,
                                        fb.vf, fb.bf, V, gp, last, r.plane0);
                 else
-                    hipLaunchKernelGGL(k_vupdate<16>, dim3(r.nplanes), dim3(256), 0, c->stream, pl, (const float*)fb.pp, (const float*)fb.qp,
+                    hipLaunchKernelGGL(k_vupdate<16>, dim3(r.nplanes), dim3(256), 0, rs, pl, (const float*)fb.pp, (const float*)fb.qp,
                                        fb.vf, fb.bf, V, gp, last, r.plane0);
                 LAUNCH_CHECK();
             }
         }
     }
-    return LRF_OK;
+    return fam_join_streams(c, runs.size());
 }
 
 // ---- C ABI ------------------------------------------------------------------------------------
@@ -641,6 +689,14 @@ void lrf_ctx_destroy(lrf_ctx* c)
             if (b->p) (void)hipFree(b->p);
     }
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    for (int i = 0; i < 2; i++) {
+        if (c->fam_stream[i]) {
+            (void)hipStreamSynchronize(c->fam_stream[i]);
+            (void)hipStreamDestroy(c->fam_stream[i]);
+        }
+        if (c->fam_join[i]) (void)hipEventDestroy(c->fam_join[i]);
+    }
+    if (c->fam_fork) (void)hipEventDestroy(c->fam_fork);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -886,7 +942,13 @@ int lrf_qmf_decompose_f32(lrf_ctx* c, const float* X, int64_t B, int64_t M, int6
         if ((rc = init_to_fp32(c, X, t, sign, (size_t)B * M * R, (size_t)B * 64 * R, &U0, &V0, LRF_GRAM_EXP_FROM_DATA))) return rc;
         return any_bcd_from_init(c, X, M * 64, (int)B, (int)M, R, K, lo, hi, U0, V0, U, M * R, V, 64L * R);
     }
-    if ((rc = run_init(c, X, t, sign, LRF_GRAM_EXP_FROM_DATA))) return rc;
+    c->fam_parallel = true; // run_init is followed by run_bcd at once: the kernel families of the call may run side by side
+    rc = run_init(c, X, t, sign, LRF_GRAM_EXP_FROM_DATA);
+    c->fam_parallel = false;
+    if (rc) {
+        (void)fam_join_streams(c, 3);
+        return rc;
+    }
     return run_bcd(c, X, t, K, lo, hi, 1, nullptr, U, V);
 }
 
@@ -1026,7 +1088,13 @@ int lrf_qmf_encode_rgb_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_t H, 
                 return rc;
         return LRF_OK;
     }
-    if ((rc = run_init(c, X, t, sign, LRF_PLANES_GRAM_EXP))) return rc;
+    c->fam_parallel = true; // run_init is followed by run_bcd at once: the kernel families of the call may run side by side
+    rc = run_init(c, X, t, sign, LRF_PLANES_GRAM_EXP);
+    c->fam_parallel = false;
+    if (rc) {
+        (void)fam_join_streams(c, 3);
+        return rc;
+    }
     return run_bcd(c, X, t, K, lo, hi, 1, nullptr, U, V);
 }
 
