@@ -368,7 +368,76 @@ __global__ __launch_bounds__(256) void k_planes_strip(const uint8_t* __restrict_
     // border): every load of the thread — two luma rows, KH chroma window rows, three channels each — is issued before the
     // first use, without a branch in between (rows past the last patch row are clamped into the image and not stored).
     const int xl = 8 * ww0 - pl.left, xc = 4 * ww0 - pc.left;
-    if (xl >= 0 && xl + 256 <= pl.w && ww0 + 32 <= nwl && xc >= 0 && xc + 128 <= pc.w && (ww0 >> 1) + 16 <= nwc) {
+    const bool xfast = xl >= 0 && xl + 256 <= pl.w && ww0 + 32 <= nwl && xc >= 0 && xc + 128 <= pc.w && (ww0 >> 1) + 16 <= nwc;
+    // Strips whose luma rows and chroma windows are the SAME source rows (round 3, after the ablations of DESIGN.md section 4):
+    // the two luma rows y0, y0 + 1 of a thread lie inside the window of chroma sample row floor(y0 / 2) — for KH = 3 always
+    // (rows y0 - 1 .. y0 + 1 or y0 .. y0 + 2 by the parity of the top pad), for KH = 2 when the top pad is even — and the
+    // columns coincide when the left pads do (left = 2 * chroma left).  Such a strip loads KH rows per thread instead of
+    // 2 + KH and converts their bytes once; the price is that its eight chroma rows are shifted by d = chroma top -
+    // ceil(top / 2) against the chroma patch row of the strip (they straddle two patch rows: stores of 32-byte rows, not whole
+    // patches) and that a strip next to one that is not shared fills the |d| rows between them the separate way.
+    const int tpar = pl.top & 1, dsh = pc.top - ((pl.top + 1) >> 1);
+    auto strip_shared = [&](int s2) {
+        if (s2 < 0) return false;
+        const int ya = 16 * s2 - pl.top - ((KH == 3 && tpar) ? 1 : 0), yb = 16 * s2 + 15 - pl.top + ((KH == 3 && !tpar) ? 1 : 0);
+        return (KH == 3 || !tpar) && pl.left == 2 * pc.left && ya >= 0 && yb <= H - 1 && 2 * s2 + 1 < pl.nh && 8 * s2 + dsh >= 0 &&
+               8 * s2 + 7 + dsh < pc.hp;
+    };
+    const bool shared = xfast && strip_shared(strip);
+    if (shared) {
+        constexpr int NR = KH; // rows per thread: the window rows; the luma rows are rows l0, l0 + 1 of them
+        const int l0 = (KH == 3 && tpar) ? 1 : 0;
+        const int x0 = 8 * ww - pl.left, y0 = 16 * strip + 2 * rp - pl.top;
+        uint32_t wlo[NR][3], whi[NR][3], wex[NR][3];
+#pragma unroll
+        for (int dy = 0; dy < NR; dy++) {
+            const uint8_t* p0 = img + (long)(y0 - l0 + dy) * W + x0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const uint64_t v = *reinterpret_cast<const u64u*>(p0 + (long)k * hw);
+                wlo[dy][k] = (uint32_t)v;
+                whi[dy][k] = (uint32_t)(v >> 32);
+                wex[dy][k] = KW == 3 ? p0[(long)k * hw + 8] : 0u;
+            }
+        }
+        uint32_t lo[2][3], hi[2][3];
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                lo[rr][k] = wlo[l0 + rr][k];
+                hi[rr][k] = whi[l0 + rr][k];
+            }
+        strip_luma(lo, hi, Lp, rp);
+        f32x4 o, o2;
+        strip_chroma<KH, KW>(wlo, whi, wex, o, o2);
+        const int q = 8 * strip + rp + dsh; // padded chroma row of sample row floor(y0 / 2)
+        const long co = ((long)(q >> 3) * nwc + (ww >> 1)) * 64 + (q & 7) * 8 + 4 * (ww & 1);
+        *reinterpret_cast<f32x4*>(Xi + g.p[1].xoff + co) = o;
+        *reinterpret_cast<f32x4*>(Xi + g.p[2].xoff + co) = o2;
+        // the rows between this strip's chroma rows and those of a neighbour that is not shared
+        const bool fill = dsh > 0 ? !strip_shared(strip - 1) : (dsh < 0 && !strip_shared(strip + 1));
+        const int nfill = dsh > 0 ? dsh : -dsh, qf = dsh > 0 ? 8 * strip + rp : 8 * strip + 8 + dsh + rp;
+        if (fill && rp < nfill && qf >= 0 && qf < pc.hp) {
+            const int cy = reflect_idx(qf - pc.top, pc.h), cx0 = 4 * ww - pc.left;
+            uint32_t clo[KH][3], chi[KH][3], cex[KH][3];
+#pragma unroll
+            for (int dy = 0; dy < KH; dy++) {
+                const uint8_t* p0 = img + (long)(2 * cy + dy) * W + 2 * cx0;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const uint64_t v = *reinterpret_cast<const u64u*>(p0 + (long)k * hw);
+                    clo[dy][k] = (uint32_t)v;
+                    chi[dy][k] = (uint32_t)(v >> 32);
+                    cex[dy][k] = KW == 3 ? p0[(long)k * hw + 8] : 0u;
+                }
+            }
+            strip_chroma<KH, KW>(clo, chi, cex, o, o2);
+            const long cf = ((long)(qf >> 3) * nwc + (ww >> 1)) * 64 + (qf & 7) * 8 + 4 * (ww & 1);
+            *reinterpret_cast<f32x4*>(Xi + g.p[1].xoff + cf) = o;
+            *reinterpret_cast<f32x4*>(Xi + g.p[2].xoff + cf) = o2;
+        }
+    } else if (xfast) {
         uint32_t lo[2][3], hi[2][3], clo[KH][3], chi[KH][3], cex[KH][3];
         const int x0 = 8 * ww - pl.left, cx0 = 4 * ww - pc.left;
         int yl = 16 * strip + 2 * rp - pl.top, cy = 8 * strip + rp - pc.top;
