@@ -151,6 +151,10 @@ typedef struct lrf_qmf_opts {
     float lo, hi;
     double l2_u, l2_v, l1_ratio;
     int factors;
+    double eps;   /* CoordinateDescent(eps=...) (lrf/factorization/qmf.py:82, 90, 117-118); 0 selects the default 1e-16 */
+    int w_init;   /* non-zero: W [B][2] holds the INITIAL pair (w0, w1) on entry — SVDInit(num_levels=...), qmf.py:56-68 —
+                     and U0 / V0 the factors it belongs to; the u / v updates then see safe_divide(x - w0, w1) (qmf.py:104-105)
+                     also when bit 2 of `factors` is clear.  Zero: [0; 1]. */
 } lrf_qmf_opts;
 int lrf_qmf_decompose_ex_f32(lrf_ctx* ctx, const float* X, int64_t B, int64_t M, int64_t N, int R, int K, const lrf_qmf_opts* opts,
                              const int8_t* sign, const float* U0, const float* V0, float* U, float* V, float* W);

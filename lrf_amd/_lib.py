@@ -27,7 +27,7 @@ class LrfError(RuntimeError):
 class QmfOpts(ctypes.Structure):
     """lrf_qmf_opts (include/lrf_hip.h)"""
     _fields_ = [("bounded", c_int), ("lo", ctypes.c_float), ("hi", ctypes.c_float), ("l2_u", ctypes.c_double), ("l2_v", ctypes.c_double),
-                ("l1_ratio", ctypes.c_double), ("factors", c_int)]
+                ("l1_ratio", ctypes.c_double), ("factors", c_int), ("eps", ctypes.c_double), ("w_init", c_int)]
 
 
 def load():
@@ -258,8 +258,10 @@ class Context:
         check(self._lib.lrf_qmf_decompose_f32(self._h, _dptr(X), B, M, N, R, K, lo, hi, _dptr(sign), _dptr(U), _dptr(V)))
         return U, V
 
-    def decompose_ex(self, X, R, K, bounds=(None, None), l2=0.0, l1_ratio=0.0, factor=(0, 1, 2), sign=None, init=None):
-        """The general QMF.decompose (lrf_qmf_decompose_ex_f32): X [B,M,N] fp32 CUDA -> fp32 (U [B,M,R], V [B,N,R], W [B,2])."""
+    def decompose_ex(self, X, R, K, bounds=(None, None), l2=0.0, l1_ratio=0.0, factor=(0, 1, 2), sign=None, init=None, eps=1e-16, w_init=None):
+        """The general QMF.decompose (lrf_qmf_decompose_ex_f32): X [B,M,N] fp32 CUDA -> fp32 (U [B,M,R], V [B,N,R], W [B,2]).
+        init = (u0, v0): initial factors instead of the library's SVD; w_init [B,2]: the initial affine pair that belongs to
+        them (SVDInit(num_levels=...)); eps: CoordinateDescent's eps."""
         import torch
         X = X.float().contiguous()
         B, M, N = X.shape
@@ -269,7 +271,10 @@ class Context:
         bounded = bounds is not None and tuple(bounds) != (None, None)
         l2 = tuple(l2) if isinstance(l2, (tuple, list)) else (l2, l2)
         opts = QmfOpts(int(bounded), float(bounds[0]) if bounded else 0.0, float(bounds[1]) if bounded else 0.0, float(l2[0]), float(l2[1]),
-                       float(l1_ratio), sum(1 << int(f) for f in set(factor)))
+                       float(l1_ratio), sum(1 << int(f) for f in set(factor)), 0.0 if eps == 1e-16 else float(eps), int(w_init is not None))
+        if w_init is not None:
+            assert init is not None, "w_init belongs to initial factors"
+            W.copy_(w_init.to(device=X.device, dtype=torch.float32).reshape(B, 2))
         u0 = v0 = None
         if init is not None:
             u0, v0 = (t.to(device=X.device, dtype=torch.float32).contiguous() for t in init)

@@ -186,7 +186,7 @@ __device__ __forceinline__ float any_soft_threshold(float x, float thr)
 }
 
 __global__ __launch_bounds__(64) void k_any_gs(const float* __restrict__ a, const float* __restrict__ bm, float* __restrict__ F,
-                                               int I, int R, int native, float lo, float hi, float l1, float l2)
+                                               int I, int R, int native, float lo, float hi, float l1, float l2, float eps)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* us = reinterpret_cast<float*>(smem);
@@ -206,8 +206,8 @@ __global__ __launch_bounds__(64) void k_any_gs(const float* __restrict__ a, cons
         for (int r = 0; r < R; r++) {
             const float* brow = bb + (long)r * R;
             const float term2 = any_term2(u, brow, r, R, native != 0);
-            const float num = any_soft_threshold(ab[(long)lane * R + r] - term2, l1) + LRF_EPS;
-            const float den = (brow[r] + l2) + LRF_EPS;
+            const float num = any_soft_threshold(ab[(long)lane * R + r] - term2, l1) + eps; // CoordinateDescent's eps (qmf.py:90, 117-118)
+            const float den = (brow[r] + l2) + eps;
             const float val = rintf(num / den);
             u[r] = fminf(fmaxf(val, lo), hi);
         }

@@ -980,6 +980,8 @@ int lrf_qmf_decompose_ex_f32(lrf_ctx* c, const float* X, int64_t B, int64_t M, i
     if (o->bounded && !(o->lo <= o->hi)) return set_err(LRF_EINVAL, "bounds (%g, %g)", (double)o->lo, (double)o->hi);
     if (!(o->l2_u >= 0.0) || !(o->l2_v >= 0.0) || !(o->l1_ratio >= 0.0 && o->l1_ratio <= 1.0))
         return set_err(LRF_EINVAL, "l2 must be >= 0 and l1_ratio in [0, 1]");
+    if (!(o->eps >= 0.0)) return set_err(LRF_EINVAL, "eps must be >= 0 (0 selects the default 1e-16)");
+    if (o->w_init && !U0) return set_err(LRF_EINVAL, "w_init needs the initial factors (U0, V0) it belongs to");
     int rc = any_check(B, M, N, R, -128, 127);
     if (rc) return rc;
     LRF_ON_DEVICE(c);
@@ -990,16 +992,24 @@ int lrf_qmf_decompose_ex_f32(lrf_ctx* c, const float* X, int64_t B, int64_t M, i
     } else if ((rc = any_run_init(c, X, (int)B, (int)M, (int)N, R, sign))) {
         return rc;
     }
-    // w = [0; 1] (SVDInit, qmf.py:54,70), on the device
-    std::vector<float> w0((size_t)2 * B);
-    for (int64_t b = 0; b < B; b++) { w0[2 * b] = 0.f; w0[2 * b + 1] = 1.f; }
-    if ((rc = upload(c, c->sign, w0.data(), w0.size() * sizeof(float)))) return rc; // the (otherwise unused here) sign scratch holds w
+    // w = [0; 1] (SVDInit, qmf.py:54,70), on the device — or the caller's initial pair (SVDInit(num_levels=...), qmf.py:56-68)
+    if ((rc = ensure(c, c->sign, (size_t)2 * B * sizeof(float)))) return rc; // the (otherwise unused here) sign scratch holds w
     float* Wd = (float*)c->sign.p;
+    if (o->w_init) {
+        HIP_TRY(hipMemcpyAsync(Wd, W, (size_t)2 * B * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        std::vector<float> w0((size_t)2 * B);
+        for (int64_t b = 0; b < B; b++) { w0[2 * b] = 0.f; w0[2 * b + 1] = 1.f; }
+        if ((rc = upload(c, c->sign, w0.data(), w0.size() * sizeof(float)))) return rc;
+        Wd = (float*)c->sign.p;
+    }
     // qmf.py:154-157: the products in double like Python, fp32 where they meet fp32 tensors; bounds through ceil / floor (:194)
     const float l1_u = (float)(o->l2_u * o->l1_ratio * (double)N), l2_u = (float)(o->l2_u * (1.0 - o->l1_ratio) * (double)N);
     const float l1_v = (float)(o->l2_v * o->l1_ratio * (double)M), l2_v = (float)(o->l2_v * (1.0 - o->l1_ratio) * (double)M);
     const float lo = o->bounded ? ceilf(o->lo) : -INFINITY, hi = o->bounded ? floorf(o->hi) : INFINITY;
-    if ((rc = any_run_bcd_general(c, X, (int)B, (int)M, (int)N, R, K, lo, hi, l1_u, l2_u, l1_v, l2_v, o->factors, Wd))) return rc;
+    const float eps = o->eps > 0.0 ? (float)o->eps : LRF_EPS; // a Python float meeting fp32 tensors: rounded to fp32 (qmf.py:117-118)
+    if ((rc = any_run_bcd_general(c, X, (int)B, (int)M, (int)N, R, K, lo, hi, l1_u, l2_u, l1_v, l2_v, o->factors, Wd, eps, o->w_init != 0)))
+        return rc;
     HIP_TRY(hipMemcpyAsync(U, c->any_uf.p, (size_t)B * M * R * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(V, c->any_vf.p, (size_t)B * N * R * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(W, Wd, (size_t)2 * B * sizeof(float), hipMemcpyDeviceToDevice, c->stream));

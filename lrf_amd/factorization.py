@@ -16,7 +16,7 @@ class QMF:
     option of it: `bounds` or none, `factor` subsets (the default (0, 1, 2) also refits the affine pair w every iteration),
     `l2` / `l1_ratio`.  The configuration `qmf_encode` uses — factor=(0, 1), integer bounds within int8, no penalties — runs on
     the tuned int8 kernels (lrf_qmf_decompose_f32); everything else on the general entry point (lrf_qmf_decompose_ex_f32,
-    float factors).  Not covered: `eps` other than 1e-16, `num_levels`, a user `project`.  Extra keyword (not in the
+    float factors), also `eps` and `num_levels` (round 3).  Not covered: a user `project`.  Extra keyword (not in the
     reference): `init_sign` — int8 [R] or [B,R], the sign to impose on each initial component (include/lrf_hip.h).
     """
 
@@ -32,20 +32,20 @@ class QMF:
         self.factor = (factor,) if isinstance(factor, int) else tuple(factor)
         self.l2 = kwargs.pop("l2", 0)
         self.l1_ratio = kwargs.pop("l1_ratio", 0)
-        eps = kwargs.pop("eps", 1e-16)
+        self.eps = kwargs.pop("eps", 1e-16)
         if kwargs.pop("project", None) is not None:
             raise NotImplementedError("a user `project` is not on the HIP path (QMF builds its own, qmf.py:188)")
         if kwargs:
             raise TypeError(f"unexpected keyword arguments {sorted(kwargs)}")  # CoordinateDescent.__init__ would raise
-        if eps != 1e-16 or num_levels:
-            raise NotImplementedError("eps / num_levels other than the defaults are not on the HIP path")
+        if not (self.eps >= 0):
+            raise ValueError("eps must be >= 0")
         if not set(self.factor) <= {0, 1, 2}:
             raise ValueError("factor must be a subset of (0, 1, 2)")
         self._bounded = self.bounds != (None, None)
         l2 = self.l2 if isinstance(self.l2, (tuple, list)) else (self.l2, self.l2)
         no_penalty = l2[0] == 0 and l2[1] == 0
         # what qmf_encode uses (lrf/compression/qmf.py:256): the int8 kernels
-        self._int8_path = (self._bounded and set(self.factor) == {0, 1} and no_penalty and
+        self._int8_path = (self._bounded and set(self.factor) == {0, 1} and no_penalty and self.eps == 1e-16 and not num_levels and
                            math.ceil(self.bounds[0]) >= -128 and math.floor(self.bounds[1]) <= 127)
         if self._bounded:
             self._lo, self._hi = math.ceil(self.bounds[0]), math.floor(self.bounds[1])  # qmf.py:194
@@ -67,7 +67,20 @@ class QMF:
             sign = sign.contiguous().cuda(ctx.device)
         if self.verbose:
             print("QMF(verbose=True): per-iteration loss is not reported by the fused HIP path")
-        if self.num_iters == 0:
+        if self.num_levels:
+            # SVDInit(num_levels=...) (qmf.py:56-68): both factors scaled to num_levels quantisation steps, w1 = their product.
+            # The scaling itself is three elementwise torch operations on the initial factors (amax / amin / divide): the same
+            # fp32 arithmetic as the reference's, bit for bit from the same u0, v0
+            u0, v0 = ctx.svd_init(xd, self.rank, sign)
+            su = (u0.amax(dim=(-2, -1), keepdim=True) - u0.amin(dim=(-2, -1), keepdim=True)) / self.num_levels
+            sv = (v0.amax(dim=(-2, -1), keepdim=True) - v0.amin(dim=(-2, -1), keepdim=True)) / self.num_levels
+            u, v = u0 / su, v0 / sv
+            w = torch.cat([torch.zeros_like(su), (su * sv) * torch.ones_like(su)], dim=-2)
+            if self.num_iters > 0:
+                u, v, w2 = ctx.decompose_ex(xd, self.rank, self.num_iters, self.bounds, self.l2, self.l1_ratio, self.factor, None,
+                                            init=(u, v), eps=self.eps, w_init=w.reshape(-1, 2))
+                w = w2.reshape(-1, 2, 1)
+        elif self.num_iters == 0:
             u, v = ctx.svd_init(xd, self.rank, sign)
             w = torch.cat([torch.zeros_like(xd[..., 0:1, 0:1]), torch.ones_like(xd[..., 0:1, 0:1])], dim=-2)
         elif self._int8_path:
@@ -75,7 +88,7 @@ class QMF:
             u, v = u8.float(), v8.float()
             w = torch.cat([torch.zeros_like(xd[..., 0:1, 0:1]), torch.ones_like(xd[..., 0:1, 0:1])], dim=-2)
         else:
-            u, v, w2 = ctx.decompose_ex(xd, self.rank, self.num_iters, self.bounds, self.l2, self.l1_ratio, self.factor, sign)
+            u, v, w2 = ctx.decompose_ex(xd, self.rank, self.num_iters, self.bounds, self.l2, self.l1_ratio, self.factor, sign, eps=self.eps)
             w = w2.reshape(-1, 2, 1)
         return u.to(dev_in), v.to(dev_in), w.to(dev_in)
 

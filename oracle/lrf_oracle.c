@@ -248,13 +248,13 @@ static float soft_threshold(float x, float thr)
 
 static void update_factor_ex(const float* X, long sxi, long sxk, long rows, long depth, int R,
                              float* Uo, const float* Vf, int bounded, float lo, float hi, float l1, float l2,
-                             float* a_ws, float* b_ws)
+                             float* a_ws, float* b_ws, float eps)
 {
     mm_torch(X, sxi, sxk, Vf, R, 1, a_ws, R, rows, depth, R);
     mm_torch(Vf, 1, R, Vf, R, 1, b_ws, R, R, depth, R);
     if (R == 1) { /* qmf.py:120-124 */
         for (long i = 0; i < rows; i++)
-            Uo[i] = project((soft_threshold(a_ws[i], l1) + LRF_EPS) / ((b_ws[0] + l2) + LRF_EPS), bounded, lo, hi);
+            Uo[i] = project((soft_threshold(a_ws[i], l1) + eps) / ((b_ws[0] + l2) + eps), bounded, lo, hi);
         return;
     }
     int native = aten_uses_native(R - 1, rows, 1);
@@ -264,14 +264,14 @@ static void update_factor_ex(const float* X, long sxi, long sxk, long rows, long
         int n = 0;
         for (int j = 0; j < R; j++)
             if (j != r) bb[n++] = b_ws[j * R + r];
-        float den = (b_ws[r * R + r] + l2) + LRF_EPS; /* qmf.py:117-118 */
+        float den = (b_ws[r * R + r] + l2) + eps; /* qmf.py:117-118 */
         for (long i = 0; i < rows; i++) {
             n = 0;
             for (int j = 0; j < R; j++)
                 if (j != r) uu[n++] = Uo[i * R + j];
             float term2 = native ? dot_native(uu, bb, R - 1) : dot_mkl_n1(uu, bb, R - 1);
             float num = soft_threshold(a_ws[i * R + r] - term2, l1); /* qmf.py:116 */
-            Uo[i * R + r] = project((num + LRF_EPS) / den, bounded, lo, hi);
+            Uo[i * R + r] = project((num + eps) / den, bounded, lo, hi);
         }
     }
     free(uu);
@@ -280,9 +280,19 @@ static void update_factor_ex(const float* X, long sxi, long sxk, long rows, long
 /* factors: bit 0 = update u, bit 1 = update v, bit 2 = update w.  l2u, l2v: the `l2` pair; l1_ratio as in the class
  * (l1_u = l2u * l1_ratio * N, l2_u = l2u * (1 - l1_ratio) * N, and with M for v: qmf.py:154-157, evaluated in double like
  * Python and rounded to fp32 where they meet fp32 tensors).  W[2] = (w0, w1), in: the initial pair ([0; 1] from SVDInit). */
+int lrf_oracle_bcd_ex_eps(const float* X, long M, long N, int R, int num_iters, int bounded, float lo, float hi,
+                          double l2u, double l2v, double l1_ratio, int factors, float* U, float* V, float* W, double eps_d);
 int lrf_oracle_bcd_ex(const float* X, long M, long N, int R, int num_iters, int bounded, float lo, float hi,
                       double l2u, double l2v, double l1_ratio, int factors, float* U, float* V, float* W)
 {
+    return lrf_oracle_bcd_ex_eps(X, M, N, R, num_iters, bounded, lo, hi, l2u, l2v, l1_ratio, factors, U, V, W, 1e-16);
+}
+/* eps_d: CoordinateDescent's eps (qmf.py:82, 90, 117-118), a Python float that meets fp32 tensors: rounded to fp32.  The eps of
+ * safe_divide (utils.py:18) is that function's own default and stays 1e-16. */
+int lrf_oracle_bcd_ex_eps(const float* X, long M, long N, int R, int num_iters, int bounded, float lo, float hi,
+                          double l2u, double l2v, double l1_ratio, int factors, float* U, float* V, float* W, double eps_d)
+{
+    const float eps = (float)eps_d;
     if (R < 1) return -1;
     long mx = M > N ? M : N;
     float* a_ws = (float*)malloc(sizeof(float) * ((size_t)mx * R + (size_t)R * R));
@@ -298,8 +308,8 @@ int lrf_oracle_bcd_ex(const float* X, long M, long N, int R, int num_iters, int 
         float den = w1;
         if (fabsf(w1) < LRF_EPS) den = LRF_EPS * ((w1 > 0.f) ? 1.f : (w1 < 0.f ? -1.f : 0.f));
         for (long e = 0; e < M * N; e++) Xp[e] = (X[e] - w0) / den;
-        if (factors & 1) update_factor_ex(Xp, N, 1, M, N, R, U, V, bounded, lo, hi, l1_u, l2_u, a_ws, b_ws);
-        if (factors & 2) update_factor_ex(Xp, 1, N, N, M, R, V, U, bounded, lo, hi, l1_v, l2_v, a_ws, b_ws);
+        if (factors & 1) update_factor_ex(Xp, N, 1, M, N, R, U, V, bounded, lo, hi, l1_u, l2_u, a_ws, b_ws, eps);
+        if (factors & 2) update_factor_ex(Xp, 1, N, N, M, R, V, U, bounded, lo, hi, l1_v, l2_v, a_ws, b_ws, eps);
         if (factors & 4) { /* update_w: least squares of x on [1, z], z = u v^T (fp32 product, k-ordered like u @ v.mT) */
             double n = (double)M * (double)N, sz = 0, szz = 0, sx = 0, sxz = 0;
             for (long m = 0; m < M; m++)

@@ -142,7 +142,7 @@ def bcd(X, u0, v0, num_iters, bounds=(-16, 15)):
     return U, V
 
 
-def bcd_ex(X, u0, v0, num_iters, bounds=(None, None), l2=(0.0, 0.0), l1_ratio=0.0, factor=(0, 1, 2), w=(0.0, 1.0)):
+def bcd_ex(X, u0, v0, num_iters, bounds=(None, None), l2=(0.0, 0.0), l1_ratio=0.0, factor=(0, 1, 2), w=(0.0, 1.0), eps=1e-16):
     """The general CoordinateDescent loop (lrf_oracle_bcd_ex): returns fp32 (U, V, W[2])."""
     X = _f32(X)
     M, N = X.shape
@@ -155,9 +155,9 @@ def bcd_ex(X, u0, v0, num_iters, bounds=(None, None), l2=(0.0, 0.0), l1_ratio=0.
     l2 = (l2, l2) if not isinstance(l2, (tuple, list)) else l2
     mask = sum(1 << int(f) for f in set(factor))
     c_double = ctypes.c_double
-    rc = lib().lrf_oracle_bcd_ex(_ptr(X, _fp), c_long(M), c_long(N), c_int(R), c_int(num_iters), c_int(int(bounded)), c_float(lo),
-                                 c_float(hi), c_double(l2[0]), c_double(l2[1]), c_double(l1_ratio), c_int(mask), _ptr(U, _fp),
-                                 _ptr(V, _fp), _ptr(W, _fp))
+    rc = lib().lrf_oracle_bcd_ex_eps(_ptr(X, _fp), c_long(M), c_long(N), c_int(R), c_int(num_iters), c_int(int(bounded)), c_float(lo),
+                                     c_float(hi), c_double(l2[0]), c_double(l2[1]), c_double(l1_ratio), c_int(mask), _ptr(U, _fp),
+                                     _ptr(V, _fp), _ptr(W, _fp), c_double(eps))
     assert rc == 0
     return U, V, W
 

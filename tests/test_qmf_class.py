@@ -12,7 +12,8 @@ import torch
 
 from conftest import GOLDEN
 
-CASES = ["qmfx_unbounded_f01", "qmfx_unbounded_f012", "qmfx_bounded_l2", "qmfx_unbounded_l2_f012", "qmfx_bounded_f0"]
+CASES = ["qmfx_unbounded_f01", "qmfx_unbounded_f012", "qmfx_bounded_l2", "qmfx_unbounded_l2_f012", "qmfx_bounded_f0",
+         "qmfx_levels_f01", "qmfx_levels_f012", "qmfx_eps"]  # the last three (round 3): SVDInit(num_levels=...), CoordinateDescent(eps=...)
 
 
 def _case(name):
@@ -30,14 +31,19 @@ def _loss(x, u, v, w):
 
 def _oracle_args(kw):
     return dict(bounds=tuple(kw.get("bounds", (None, None))), l2=kw.get("l2", 0.0), l1_ratio=kw.get("l1_ratio", 0.0),
-                factor=tuple(kw.get("factor", (0, 1, 2))))
+                factor=tuple(kw.get("factor", (0, 1, 2))), eps=kw.get("eps", 1e-16))
+
+
+def _w0(z):
+    """the initial affine pair of the fixture: [0; 1] unless SVDInit ran with num_levels (stored since round 3)"""
+    return z["w0"] if "w0" in z else np.array([0.0, 1.0], np.float32)
 
 
 @pytest.mark.parametrize("name", CASES)
 def test_oracle_general_bcd_against_reference(name, oracle):
     z, kw, x = _case(name)
     X = x[0].numpy()
-    U, V, W = oracle.bcd_ex(X, z["u0"], z["v0"], kw["num_iters"], **_oracle_args(kw))
+    U, V, W = oracle.bcd_ex(X, z["u0"], z["v0"], kw["num_iters"], w=_w0(z), **_oracle_args(kw))
     if 2 not in _oracle_args(kw)["factor"]:
         assert np.array_equal(U, z["u"]) and np.array_equal(V, z["v"]), "without update_w the reference is reproduced bit for bit"
         assert np.array_equal(W, z["w"])
@@ -57,9 +63,11 @@ def test_hip_general_bcd(name, oracle):
     X = x[0].numpy()
     a = _oracle_args(kw)
     ctx = _lib.context(0)
-    U, V, W = ctx.decompose_ex(x.cuda(), int(kw["rank"]), kw["num_iters"], init=(torch.from_numpy(z["u0"])[None], torch.from_numpy(z["v0"])[None]), **a)
+    w_init = torch.from_numpy(_w0(z))[None] if "w0" in z and not np.array_equal(_w0(z), [0.0, 1.0]) else None
+    U, V, W = ctx.decompose_ex(x.cuda(), int(kw["rank"]), kw["num_iters"], init=(torch.from_numpy(z["u0"])[None], torch.from_numpy(z["v0"])[None]),
+                               w_init=w_init, **a)
     U, V, W = U[0].cpu().numpy(), V[0].cpu().numpy(), W[0].cpu().numpy()
-    Uo, Vo, Wo = oracle.bcd_ex(X, z["u0"], z["v0"], kw["num_iters"], **a)
+    Uo, Vo, Wo = oracle.bcd_ex(X, z["u0"], z["v0"], kw["num_iters"], w=_w0(z), **a)
     if 2 not in a["factor"]:
         assert np.array_equal(U, Uo) and np.array_equal(V, Vo) and np.array_equal(W, Wo)
         assert np.array_equal(U, z["u"]) and np.array_equal(V, z["v"])
@@ -89,3 +97,27 @@ def test_reference_smoke_test_runs():
     u2, v2, w2 = lrf_amd.QMF(**kw2).decompose(x2)
     assert float(u2.min()) >= -16 and float(u2.max()) <= 15
     assert abs(lrf_amd.QMF.loss(x2, u2, v2, w2).item() - float(z2["loss"])) < 5e-3
+
+
+@pytest.mark.gpu
+def test_num_levels_and_eps_through_the_class():
+    """lrf_amd.QMF(num_levels=...) / QMF(eps=...) end to end with the library's own initialisation and the reference's LAPACK
+    column signs (the scales are max - min of a factor: they move with the signs): the reference's loss to 1e-5, the same
+    affine pair to 2e-3; the scaled initial factors span num_levels steps, w1 is the product of the two scales, and
+    num_iters=0 returns exactly that initialisation.  With the default signs the loss stays within 2e-3."""
+    import lrf_amd
+    for name in ("qmfx_levels_f01", "qmfx_levels_f012", "qmfx_eps"):
+        z, kw, x = _case(name)
+        u, v, w = lrf_amd.QMF(init_sign=torch.from_numpy(z["sign"]), **kw).decompose(x)
+        assert abs(lrf_amd.QMF.loss(x, u, v, w).item() - float(z["loss"])) < 1e-5, name
+        assert np.allclose(w.reshape(-1).numpy(), z["w"], rtol=2e-3, atol=2e-2), (name, w.reshape(-1), z["w"])
+        assert torch.equal(u, torch.round(u)) and torch.equal(v, torch.round(v))
+        u, v, w = lrf_amd.QMF(**kw).decompose(x)
+        assert abs(lrf_amd.QMF.loss(x, u, v, w).item() - float(z["loss"])) < 2e-3, name
+    z, kw, x = _case("qmfx_levels_it0")
+    u, v, w = lrf_amd.QMF(init_sign=torch.from_numpy(z["sign"]), **kw).decompose(x)
+    assert abs(float(u.max() - u.min()) - kw["num_levels"]) < 1e-3 and abs(float(v.max() - v.min()) - kw["num_levels"]) < 1e-3
+    assert abs(float(w[0, 1, 0]) - float(z["w0"][1])) < 2e-3 * float(z["w0"][1]) and float(w[0, 0, 0]) == 0.0
+    assert abs(lrf_amd.QMF.loss(x, u, v, w).item() - float(z["loss"])) < 1e-5
+    with pytest.raises(NotImplementedError):
+        lrf_amd.QMF(rank=3, project=lambda t: t)

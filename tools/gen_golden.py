@@ -380,7 +380,15 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "anyshape":
     gen_anyshape()
 
 
-def gen_qmfx():
+QMFX_R3 = [  # round 3: SVDInit(num_levels=...) (qmf.py:56-68) and CoordinateDescent(eps=...)
+    ("qmfx_levels_f01", dict(seed=9, M=300, N=64), dict(rank=4, num_iters=5, bounds=(-16, 15), factor=(0, 1), num_levels=31)),
+    ("qmfx_levels_f012", dict(seed=10, M=128, N=96), dict(rank=3, num_iters=4, num_levels=15.0)),
+    ("qmfx_levels_it0", dict(seed=12, M=96, N=64), dict(rank=3, num_iters=0, num_levels=7)),
+    ("qmfx_eps", dict(seed=11, M=200, N=64), dict(rank=5, num_iters=3, bounds=(-8, 7), factor=(0, 1), eps=1e-3)),
+]
+
+
+def gen_qmfx(cases=None, index_name="index_qmfx.json"):
     """The QMF class beyond what qmf_encode uses (lrf/factorization/qmf.py:74-231): unbounded factors, elastic-net terms,
     the affine pair w (factor containing 2) — on the shape of the reference's own smoke test (test/test_factorization.py:5-10:
     randint(0, 256, (1, 784, 192)), rank 5, 10 iterations) and a small bounded case.  Stored: the reference's initial factors
@@ -388,7 +396,7 @@ def gen_qmfx():
     torch.set_num_threads(1)
     ns = ref_loader.load()
     QMF = ns.fqmf.QMF
-    cases = [
+    cases = cases or [
         ("qmfx_unbounded_f01", dict(seed=5, M=784, N=192), dict(rank=5, num_iters=10, factor=(0, 1))),
         ("qmfx_unbounded_f012", dict(seed=5, M=784, N=192), dict(rank=5, num_iters=10)),  # the reference's smoke test, as is
         ("qmfx_bounded_l2", dict(seed=6, M=300, N=64), dict(rank=4, num_iters=5, bounds=(-16, 15), factor=(0, 1), l2=(0.02, 0.01), l1_ratio=0.5)),
@@ -405,15 +413,17 @@ def gen_qmfx():
         loss = QMF.loss(x, u, v, w)
         np.savez_compressed(os.path.join(OUT, name + ".npz"), spec=json.dumps(spec), kwargs=json.dumps(kw), u0=u0[0].numpy(), v0=v0[0].numpy(),
                             u=u[0].numpy(), v=v[0].numpy(), w=w[0].numpy().reshape(2), loss=np.float64(loss.item()),
-                            sign=wsign(v0[0].numpy()))
+                            sign=wsign(v0[0].numpy()), w0=w0[0].numpy().reshape(2))
         index[name] = {"loss": loss.item(), "w": w[0].reshape(2).tolist()}
         print(name, index[name], flush=True)
-    with open(os.path.join(OUT, "index_qmfx.json"), "w") as f:
+    with open(os.path.join(OUT, index_name), "w") as f:
         json.dump(index, f, indent=1)
 
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "qmfx":
     gen_qmfx()
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "qmfx_r3":
+    gen_qmfx(QMFX_R3, "index_qmfx_r3.json")
 
 
 SVD_ANY_CASES = [
