@@ -1127,24 +1127,29 @@ int lrf_qmf_decode_rgb_u8(lrf_ctx* c, const int8_t* U, const int8_t* V, int64_t 
     long n4 = (long)H * ((W + 3) / 4);
     Prof p(c, LRF_K_DECODE);
     static const bool no_tiled = getenv("LRF_DECODE_NO_TILED") && getenv("LRF_DECODE_NO_TILED")[0] == '1'; // developer comparison aid
-    if (R[0] <= 8 && R[1] <= 8 && R[2] <= 8 && H % 16 == 0 && W % 16 == 0 && (reinterpret_cast<uintptr_t>(rgb) & 7) == 0 && !no_tiled)
-    {
-        const dim3 grid((unsigned)((H / 16) * ((g.p[0].nw + 31) / 32)), (unsigned)B);
-        if (R[1] <= 4 && R[2] <= 4)
-            hipLaunchKernelGGL(k_decode16<4>, grid, dim3(256), 0, c->stream, U, V, (int)H, (int)W, g, R[0], R[1], R[2], u_img, v_img, rgb);
-        else
-            hipLaunchKernelGGL(k_decode16<8>, grid, dim3(256), 0, c->stream, U, V, (int)H, (int)W, g, R[0], R[1], R[2], u_img, v_img, rgb);
-    }
-    else if (R[0] <= 8 && R[1] <= 8 && R[2] <= 8 && !no_tiled && W % 2 == 0 && g.p[0].left_crop % 2 == 0 &&
-             (g.p[1].left_crop - g.p[0].left_crop / 2) % 4 == 0 && g.p[1].w == W / 2)
-    {
-        // any height, widths whose chroma samples sit four-aligned under the eight pixels of a thread: tiles over the padded luma plane
+    // the tiled kernels (k_decode16: sides multiples of 16; k_decode_strip: any height, four-aligned chroma columns) are
+    // instantiated for the rank bounds (chroma, luma) = (4,8) (8,8) (8,16) (16,16) (16,32): the reference's quality sweep up to 40
+    const int rcm = R[1] > R[2] ? R[1] : R[2];
+    const int RCb = rcm <= 4 ? 4 : (rcm <= 8 ? 8 : 16), RLb = R[0] <= 8 ? 8 : (R[0] <= 16 ? 16 : 32);
+    const bool tiled_ranks = R[0] <= 32 && rcm <= 16 && !no_tiled;
+    const bool sides16 = H % 16 == 0 && W % 16 == 0 && (reinterpret_cast<uintptr_t>(rgb) & 7) == 0;
+    const bool strip_ok = W % 2 == 0 && g.p[0].left_crop % 2 == 0 && (g.p[1].left_crop - g.p[0].left_crop / 2) % 4 == 0 && g.p[1].w == W / 2;
+    if (tiled_ranks && (sides16 || strip_ok)) {
         const int per_strip = (g.p[0].nw + 31) / 32;
-        const dim3 grid((unsigned)(((g.p[0].nh + 1) / 2) * per_strip), (unsigned)B);
-        if (R[1] <= 4 && R[2] <= 4)
-            hipLaunchKernelGGL(k_decode_strip<4>, grid, dim3(256), 0, c->stream, U, V, (int)H, (int)W, g, R[0], R[1], R[2], u_img, v_img, rgb, per_strip);
-        else
-            hipLaunchKernelGGL(k_decode_strip<8>, grid, dim3(256), 0, c->stream, U, V, (int)H, (int)W, g, R[0], R[1], R[2], u_img, v_img, rgb, per_strip);
+        const dim3 grid16((unsigned)((H / 16) * per_strip), (unsigned)B), grids((unsigned)(((g.p[0].nh + 1) / 2) * per_strip), (unsigned)B);
+#define LRF_DECODE_TILED(RC, RL)                                                                                                  \
+    do {                                                                                                                         \
+        if (sides16)                                                                                                             \
+            hipLaunchKernelGGL((k_decode16<RC, RL>), grid16, dim3(256), 0, c->stream, U, V, (int)H, (int)W, g, R[0], R[1], R[2], u_img, v_img, rgb); \
+        else                                                                                                                     \
+            hipLaunchKernelGGL((k_decode_strip<RC, RL>), grids, dim3(256), 0, c->stream, U, V, (int)H, (int)W, g, R[0], R[1], R[2], u_img, v_img, rgb, per_strip); \
+    } while (0)
+        if (RLb == 8 && RCb == 4) LRF_DECODE_TILED(4, 8);
+        else if (RLb == 8 && RCb == 8) LRF_DECODE_TILED(8, 8);
+        else if (RLb == 16 && RCb <= 8) LRF_DECODE_TILED(8, 16);
+        else if (RLb <= 16) LRF_DECODE_TILED(16, 16);
+        else LRF_DECODE_TILED(16, 32);
+#undef LRF_DECODE_TILED
     }
     else if (R[0] <= 8 && R[1] <= 8 && R[2] <= 8)
 {

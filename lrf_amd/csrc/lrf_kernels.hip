@@ -1819,7 +1819,7 @@ __global__ __launch_bounds__(256) void k_decode8(const int8_t* __restrict__ U, c
     }
 }
 
-// Fast path of K4 for images whose sides are multiples of 16 and ranks <= 8 (no padding, no crop, exact 2x nearest
+// Fast path of K4 for images whose sides are multiples of 16 (no padding, no crop, exact 2x nearest
 // up-sampling): the inverse of k_planes16's tiling.  One workgroup per 16-row strip x 32 luma patches; a thread owns a
 // 2 x 8 pixel block — two rows of one luma patch, and the four chroma samples under them, one row of one chroma patch —
 // so it loads its three u rows once (two unaligned dwords each), reads V from an LDS table laid out [plane][r][n] (a
@@ -1831,25 +1831,33 @@ __global__ __launch_bounds__(256) void k_decode8(const int8_t* __restrict__ U, c
 // gain), 64 lanes per image row (512-byte store segments, but a quarter of the lanes idle at 96 patches per row: slower).
 // Arithmetic: that of k_decode8 / k_decode (sums of products of small integers: exact in any order; "+ -128.f"; the colour
 // chain; clamp; truncate) with the steps dropped that cannot change a bit for finite values: fma(1, y, 0) = y,
-// fma(0, c, acc) = acc.  The chroma sums stop at rank 4 when both chroma ranks are <= 4 (wave-uniform).
-__device__ __forceinline__ void decode16_u_load(const int8_t* up, int R, unsigned& lo, unsigned& hi)
-{
-    hi = 0u;
-    if (R >= 4) { // bytes 0..3 and bytes R-4..R-1 of the row (overlapping): two unaligned dword loads
-        lo = *reinterpret_cast<const unsigned __attribute__((aligned(1)))*>(up);
-        const unsigned h = *reinterpret_cast<const unsigned __attribute__((aligned(1)))*>(up + R - 4);
-        hi = (R > 4) ? h >> (8 * (8 - R)) : 0u;
-    } else {
-        lo = (unsigned)(uint8_t)up[0] | ((unsigned)(uint8_t)up[R > 1 ? 1 : 0] << 8) | ((unsigned)(uint8_t)up[R > 2 ? 2 : 0] << 16);
-    }
-}
-__device__ __forceinline__ void decode16_u_unpack(unsigned lo, unsigned hi, int R, float (&u)[8])
+// fma(0, c, acc) = acc.  Template parameters: the rank bounds of the chroma planes (4, 8, 16) and of luma (8, 16, 32) — table
+// sizes and loop lengths; the u rows are zero padded to them (round 3: until then ranks above 8 fell to the one-thread-per-
+// four-pixels kernel k_decode, 13-16x slower: 256 x 512x768 at ranks (16,8,8) 2.31 -> 0.146 ms, (26,13,13) 3.74 -> 0.227).
+// The int8 row of R <= RM bytes (RM = 8, 16, 32) as RM / 4 dwords, bytes past R zero: dword d comes from offset 4 d while it lies
+// inside the row, the partial last one from offset R - 4 (unaligned, overlapping) shifted down; R < 4: byte loads.  R is
+// uniform across the wave (one plane per call), so the branches are scalar.
+template <int RM>
+__device__ __forceinline__ void decode_u_load(const int8_t* up, int R, unsigned (&w)[RM / 4])
 {
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        u[r] = (r < R) ? (float)(int)(int8_t)(lo >> (8 * r)) : 0.f;
-        u[4 + r] = (4 + r < R) ? (float)(int)(int8_t)(hi >> (8 * r)) : 0.f;
+    for (int d = 0; d < RM / 4; d++) w[d] = 0u;
+    if (R < 4) {
+        w[0] = (unsigned)(uint8_t)up[0] | ((unsigned)(uint8_t)up[R > 1 ? 1 : 0] << 8) | ((unsigned)(uint8_t)up[R > 2 ? 2 : 0] << 16);
+        if (R < 3) w[0] &= (R == 1) ? 0xffu : 0xffffu;
+        return;
     }
+#pragma unroll
+    for (int d = 0; d < RM / 4; d++) {
+        if (4 * d + 4 <= R) w[d] = *reinterpret_cast<const unsigned __attribute__((aligned(1)))*>(up + 4 * d);
+        else if (4 * d < R) w[d] = *reinterpret_cast<const unsigned __attribute__((aligned(1)))*>(up + R - 4) >> (8 * (4 * d + 4 - R));
+    }
+}
+template <int RM>
+__device__ __forceinline__ void decode_u_unpack(const unsigned (&w)[RM / 4], float (&u)[RM])
+{
+#pragma unroll
+    for (int r = 0; r < RM; r++) u[r] = (float)(int)(int8_t)(w[r >> 2] >> (8 * (r & 3)));
 }
 
 // clamp to [0, 255] and truncate four values, packed into one dword (values are finite)
@@ -1860,12 +1868,12 @@ __device__ __forceinline__ unsigned decode16_pack4(float a, float b, float c, fl
     return (ua | (ub << 8)) | ((uc | (ud << 8)) << 16);
 }
 
-template <int RC> // chroma rank bound: 4 or 8
+template <int RC, int RL> // rank bounds of the chroma planes (4, 8, 16) and of luma (8, 16, 32): table sizes and loop lengths
 __global__ __launch_bounds__(256) void k_decode16(const int8_t* __restrict__ U, const int8_t* __restrict__ V, int H, int W,
                                                   ImageGeom g, int R0, int R1, int R2, long u_img, long v_img,
                                                   uint8_t* __restrict__ rgb)
 {
-    __shared__ __attribute__((aligned(16))) float Vs[3][8][64];
+    __shared__ __attribute__((aligned(16))) float VsL[RL][64], VsC[2][RC][64];
     const int8_t* Ui = U + (long)blockIdx.y * u_img;
     const int8_t* Vi = V + (long)blockIdx.y * v_img;
     const int8_t* Uc[3] = {Ui, Ui + (long)g.p[0].M * R0, Ui + (long)g.p[0].M * R0 + (long)g.p[1].M * R1};
@@ -1879,29 +1887,35 @@ __global__ __launch_bounds__(256) void k_decode16(const int8_t* __restrict__ U, 
     const int rp = threadIdx.x >> 5; // row pair inside the strip: image rows 16 strip + 2 rp, + 1
     // the u rows of the luma patch and of the two chroma patches: issued before the V table is staged, so that the two
     // memory round trips of a workgroup overlap
-    unsigned ulo[3], uhi[3];
+    unsigned wl[RL / 4], wb[RC / 4], wr[RC / 4];
     const long mrow[3] = {(long)(2 * strip + (rp >> 2)) * nwl + wwc, (long)strip * nwc + (wwc >> 1), (long)strip * nwc + (wwc >> 1)};
-#pragma unroll
-    for (int c = 0; c < 3; c++) decode16_u_load(Uc[c] + mrow[c] * Rc[c], Rc[c], ulo[c], uhi[c]);
-    for (int e = threadIdx.x; e < 3 * 8 * 64; e += 256) {
-        const int c = e >> 9, r = (e >> 6) & 7, n = e & 63;
-        Vs[c][r][n] = (r < Rc[c]) ? (float)Vc[c][n * Rc[c] + r] : 0.f;
+    decode_u_load<RL>(Uc[0] + mrow[0] * R0, R0, wl);
+    decode_u_load<RC>(Uc[1] + mrow[1] * R1, R1, wb);
+    decode_u_load<RC>(Uc[2] + mrow[2] * R2, R2, wr);
+    for (int e = threadIdx.x; e < RL * 64; e += 256) {
+        const int r = e >> 6, n = e & 63;
+        VsL[r][n] = (r < R0) ? (float)Vc[0][n * R0 + r] : 0.f;
+    }
+    for (int e = threadIdx.x; e < 2 * RC * 64; e += 256) {
+        const int c = e / (RC * 64), r = (e >> 6) % RC, n = e & 63;
+        VsC[c][r][n] = (r < Rc[1 + c]) ? (float)Vc[1 + c][n * Rc[1 + c] + r] : 0.f;
     }
     __syncthreads();
     if (ww >= nwl) return;
-    float u[3][8]; // zero padded to 8 columns
-#pragma unroll
-    for (int c = 0; c < 3; c++) decode16_u_unpack(ulo[c], uhi[c], Rc[c], u[c]);
+    float ul[RL], ub[RC], ur[RC]; // zero padded to the rank bounds
+    decode_u_unpack<RL>(wl, ul);
+    decode_u_unpack<RC>(wb, ub);
+    decode_u_unpack<RC>(wr, ur);
     // chroma: samples (row 8 strip + rp of the plane = row rp of the patch, columns 4 (ww & 1) .. + 3)
     float cb[4] = {0.f, 0.f, 0.f, 0.f}, cr[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < RC; r++) {
-        const f32x4 vb = *reinterpret_cast<const f32x4*>(&Vs[1][r][rp * 8 + 4 * (ww & 1)]);
-        const f32x4 vr = *reinterpret_cast<const f32x4*>(&Vs[2][r][rp * 8 + 4 * (ww & 1)]);
+        const f32x4 vb = *reinterpret_cast<const f32x4*>(&VsC[0][r][rp * 8 + 4 * (ww & 1)]);
+        const f32x4 vr = *reinterpret_cast<const f32x4*>(&VsC[1][r][rp * 8 + 4 * (ww & 1)]);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            cb[i] = fmaf(u[1][r], vb[i], cb[i]);
-            cr[i] = fmaf(u[2][r], vr[i], cr[i]);
+            cb[i] = fmaf(ub[r], vb[i], cb[i]);
+            cr[i] = fmaf(ur[r], vr[i], cr[i]);
         }
     }
 #pragma unroll
@@ -1916,13 +1930,13 @@ __global__ __launch_bounds__(256) void k_decode16(const int8_t* __restrict__ U, 
         float y[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const int n0 = (2 * (rp & 3) + rr) * 8;
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(&Vs[0][r][n0]);
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(&Vs[0][r][n0 + 4]);
+        for (int r = 0; r < RL; r++) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(&VsL[r][n0]);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(&VsL[r][n0 + 4]);
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                y[i] = fmaf(u[0][r], v0[i], y[i]);
-                y[4 + i] = fmaf(u[0][r], v1[i], y[4 + i]);
+                y[i] = fmaf(ul[r], v0[i], y[i]);
+                y[4 + i] = fmaf(ul[r], v1[i], y[4 + i]);
             }
         }
         uint2 pk[3];
@@ -1955,12 +1969,12 @@ __global__ __launch_bounds__(256) void k_decode16(const int8_t* __restrict__ U, 
 // lrf/compression/utils.py:98-105): the two rows of a thread usually share it (then the chroma sums are computed once, as
 // in k_decode16), otherwise the second row's are computed separately, from the u rows of its own chroma patch.
 // Same arithmetic as k_decode8 / k_decode16.
-template <int RC> // chroma rank bound: 4 or 8
+template <int RC, int RL> // rank bounds of the chroma planes (4, 8, 16) and of luma (8, 16, 32)
 __global__ __launch_bounds__(256) void k_decode_strip(const int8_t* __restrict__ U, const int8_t* __restrict__ V, int H, int W,
                                                       ImageGeom g, int R0, int R1, int R2, long u_img, long v_img,
                                                       uint8_t* __restrict__ rgb, int per_strip)
 {
-    __shared__ __attribute__((aligned(16))) float Vs[3][8][64];
+    __shared__ __attribute__((aligned(16))) float VsL[RL][64], VsC[2][RC][64];
     const int8_t* Ui = U + (long)blockIdx.y * u_img;
     const int8_t* Vi = V + (long)blockIdx.y * v_img;
     const int8_t* Uc[3] = {Ui, Ui + (long)g.p[0].M * R0, Ui + (long)g.p[0].M * R0 + (long)g.p[1].M * R1};
@@ -1990,19 +2004,24 @@ __global__ __launch_bounds__(256) void k_decode_strip(const int8_t* __restrict__
     cx = cx < 0 ? 0 : (cx > pc.wp - 4 ? pc.wp - 4 : cx);
     const long mc0 = (long)(q[0] >> 3) * nwc + (cx >> 3), mc1 = (long)(q[1] >> 3) * nwc + (cx >> 3);
     // the u rows of the luma patch and of the chroma patches of the first row: issued before the V table is staged
-    unsigned ulo[3], uhi[3];
-    decode16_u_load(Uc[0] + ((long)prc * nwl + wwc) * R0, R0, ulo[0], uhi[0]);
-    decode16_u_load(Uc[1] + mc0 * R1, R1, ulo[1], uhi[1]);
-    decode16_u_load(Uc[2] + mc0 * R2, R2, ulo[2], uhi[2]);
-    for (int e = threadIdx.x; e < 3 * 8 * 64; e += 256) {
-        const int c = e >> 9, r = (e >> 6) & 7, n = e & 63;
-        Vs[c][r][n] = (r < Rc[c]) ? (float)Vc[c][n * Rc[c] + r] : 0.f;
+    unsigned wl[RL / 4], wb[RC / 4], wr[RC / 4];
+    decode_u_load<RL>(Uc[0] + ((long)prc * nwl + wwc) * R0, R0, wl);
+    decode_u_load<RC>(Uc[1] + mc0 * R1, R1, wb);
+    decode_u_load<RC>(Uc[2] + mc0 * R2, R2, wr);
+    for (int e = threadIdx.x; e < RL * 64; e += 256) {
+        const int r = e >> 6, n = e & 63;
+        VsL[r][n] = (r < R0) ? (float)Vc[0][n * R0 + r] : 0.f;
+    }
+    for (int e = threadIdx.x; e < 2 * RC * 64; e += 256) {
+        const int c = e / (RC * 64), r = (e >> 6) % RC, n = e & 63;
+        VsC[c][r][n] = (r < Rc[1 + c]) ? (float)Vc[1 + c][n * Rc[1 + c] + r] : 0.f;
     }
     __syncthreads();
     if (!live) return;
-    float u[3][8]; // zero padded to 8 columns
-#pragma unroll
-    for (int c = 0; c < 3; c++) decode16_u_unpack(ulo[c], uhi[c], Rc[c], u[c]);
+    float ul[RL], ub[RC], ur[RC]; // zero padded to the rank bounds
+    decode_u_unpack<RL>(wl, ul);
+    decode_u_unpack<RC>(wb, ub);
+    decode_u_unpack<RC>(wr, ur);
     float cb[4], cr[4];
     auto chroma = [&](int qq) { // samples (padded row qq, padded columns cx .. cx + 3) of both planes, "+ -128.f"
 #pragma unroll
@@ -2010,12 +2029,12 @@ __global__ __launch_bounds__(256) void k_decode_strip(const int8_t* __restrict__
         const int nc = (qq & 7) * 8 + (cx & 7);
 #pragma unroll
         for (int r = 0; r < RC; r++) {
-            const f32x4 vb = *reinterpret_cast<const f32x4*>(&Vs[1][r][nc]);
-            const f32x4 vr = *reinterpret_cast<const f32x4*>(&Vs[2][r][nc]);
+            const f32x4 vb = *reinterpret_cast<const f32x4*>(&VsC[0][r][nc]);
+            const f32x4 vr = *reinterpret_cast<const f32x4*>(&VsC[1][r][nc]);
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                cb[i] = fmaf(u[1][r], vb[i], cb[i]);
-                cr[i] = fmaf(u[2][r], vr[i], cr[i]);
+                cb[i] = fmaf(ub[r], vb[i], cb[i]);
+                cr[i] = fmaf(ur[r], vr[i], cr[i]);
             }
         }
 #pragma unroll
@@ -2033,10 +2052,10 @@ __global__ __launch_bounds__(256) void k_decode_strip(const int8_t* __restrict__
         const int y = y0 + rr;
         if (rr == 1 && q[1] != q[0]) { // the second row sits over another chroma row (possibly of the next chroma patch row)
             if (mc1 != mc0) {
-                decode16_u_load(Uc[1] + mc1 * R1, R1, ulo[1], uhi[1]);
-                decode16_u_load(Uc[2] + mc1 * R2, R2, ulo[2], uhi[2]);
-                decode16_u_unpack(ulo[1], uhi[1], R1, u[1]);
-                decode16_u_unpack(ulo[2], uhi[2], R2, u[2]);
+                decode_u_load<RC>(Uc[1] + mc1 * R1, R1, wb);
+                decode_u_load<RC>(Uc[2] + mc1 * R2, R2, wr);
+                decode_u_unpack<RC>(wb, ub);
+                decode_u_unpack<RC>(wr, ur);
             }
             chroma(q[1]);
         }
@@ -2044,13 +2063,13 @@ __global__ __launch_bounds__(256) void k_decode_strip(const int8_t* __restrict__
         float yv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const int n0 = (2 * (rp & 3) + rr) * 8;
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(&Vs[0][r][n0]);
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(&Vs[0][r][n0 + 4]);
+        for (int r = 0; r < RL; r++) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(&VsL[r][n0]);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(&VsL[r][n0 + 4]);
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                yv[i] = fmaf(u[0][r], v0[i], yv[i]);
-                yv[4 + i] = fmaf(u[0][r], v1[i], yv[4 + i]);
+                yv[i] = fmaf(ul[r], v0[i], yv[i]);
+                yv[4 + i] = fmaf(ul[r], v1[i], yv[4 + i]);
             }
         }
         uint2 pk[3];

@@ -151,7 +151,7 @@ def test_qmf_class_api(oracle):
     rec = lrf_amd.QMF.reconstruct(u, v)
     assert torch.allclose(qmf.forward(x), rec)
     with pytest.raises(NotImplementedError):
-        lrf_amd.QMF(rank=3, eps=1e-8)
+        lrf_amd.QMF(rank=3, project=lambda t: t)
     with pytest.raises(TypeError):
         lrf_amd.QMF(rank=3, no_such_option=1)
     # the class's other modes (unbounded, factor (0, 1, 2), penalties): tests/test_qmf_class.py
@@ -454,10 +454,15 @@ def test_ranks_above_32_equal_oracle(oracle):
 
 
 @pytest.mark.parametrize("hw,ranks", [((16, 16), [1, 1, 1]), ((48, 80), [3, 2, 1]), ((32, 528), [4, 4, 4]), ((64, 96), [8, 8, 8]),
-                                      ((112, 272), [7, 3, 3]), ((16, 1040), [5, 8, 2])])
+                                      ((112, 272), [7, 3, 3]), ((16, 1040), [5, 8, 2]),
+                                      ((64, 96), [16, 8, 8]), ((48, 80), [10, 5, 5]), ((32, 528), [13, 16, 9]), ((112, 272), [26, 13, 13]),
+                                      ((64, 96), [32, 16, 1]), ((16, 1040), [20, 2, 11]),
+                                      ((61, 96), [16, 8, 8]), ((173, 272), [26, 13, 13]), ((45, 48), [9, 3, 12]), ((99, 2048), [7, 3, 3])])
 def test_tiled_decode_matches_oracle(hw, ranks, oracle):
-    """k_decode16 (sides multiples of 16, ranks <= 8): random int8 factors over the full int8 range -> the oracle's pixels,
-    for every u-row load form (R < 4, R = 4, 4 < R < 8, R = 8) and widths that are not a multiple of 32 patches."""
+    """k_decode16 (sides multiples of 16) and k_decode_strip (any height, four-aligned chroma columns; the last four sizes),
+    every rank-bound instantiation (chroma 4 / 8 / 16, luma 8 / 16 / 32): random int8 factors over the full int8 range -> the
+    oracle's pixels, for every u-row load form (R < 4, R a multiple of 4, in between) and widths that are not a multiple of
+    32 patches."""
     import lrf_amd
     from lrf_amd import _lib
     H, W = hw

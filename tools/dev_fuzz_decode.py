@@ -14,7 +14,7 @@ for i in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     top = rnd.choice([4, 8, 8, 16, 40])
     if len(sys.argv) > 3 and sys.argv[3] == "strip":  # the sizes k_decode_strip takes: any height, four-aligned chroma columns, ranks <= 8
         H = rnd.choice([8, 9, 15, 17, 23, 25, 31, 33, 41, 99, 173, 255, 333, 511, 683]); W = rnd.choice([16, 32, 48, 60, 124, 252, 508, 1020, 96, 2048, 1040])
-        top = rnd.choice([4, 8, 8])
+        top = rnd.choice([4, 8, 8, 16, 32, 40])
     ranks = tuple(rnd.randint(1, top) for _ in range(3)); amp = rnd.choice([3, 16, 127])
    
     try:
