@@ -336,6 +336,106 @@ __global__ __launch_bounds__(256) void k_any_gram(const float* __restrict__ X, l
 
 // the diagonal tiles above compute (i,j) and (j,i) by the same chain of the same commuting products: exactly symmetric.
 
+// The same Gram matrix on the fp64 matrix cores (round 3).  v_mfma_f64_16x16x4_f64 IS the chain above: per element
+// d = fma(a_3, b_3, fma(a_2, b_2, fma(a_1, b_1, fma(a_0, b_0, c)))), k ascending (tools/probe/run_mfma64.py: 0 of 3072 elements
+// differ from the fma chain, products of fp32 values being exact in fp64), so the result is bit for bit k_any_gram's.  The
+// VALU kernel is bound by its LDS operand reads (a 2 x 2 register tile: one read per fma); here a wave owns a 32 x 32
+// sub-tile as 2 x 2 MFMA tiles and reads four operands per four MFMAs.  64 x 64 tile of G per workgroup, upper tiles
+// mirrored; operand layout: A lane l -> (i = l % 16, k = l / 16), B lane l -> (k = l / 16, j = l % 16), D register r ->
+// (i = l / 16 + 4 r, j = l % 16).  grid (nt64, nt64, B)
+typedef double f64x4_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_any_gram_mfma(const float* __restrict__ X, long x_batch, long sgk, long sgi, int n, int D,
+                                                       double* __restrict__ G)
+{
+    if (blockIdx.y < blockIdx.x) return;
+    constexpr int LS = 81; // row stride of the staged tiles (17 mod 64): the four k rows of an operand read fall into (all but) disjoint
+                           // banks, and the staging stores are conflict-free along k as well as along i
+    __shared__ __attribute__((aligned(16))) float Ss[2 * 64 * LS]; // the two staged tiles; afterwards the transposed output tile
+    float* Is = Ss;
+    float* Js = Ss + 64 * LS;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wi = wave >> 1, wj = wave & 1;
+    const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
+    const bool diag = blockIdx.x == blockIdx.y;
+    const float* Xb = X + (long)blockIdx.z * x_batch;
+    f64x4_t acc[2][2];
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+        for (int q = 0; q < 2; q++) acc[p][q] = (f64x4_t){0.0, 0.0, 0.0, 0.0};
+    // the next 64-deep chunk travels from global memory into registers while the matrix cores work on the current one
+    float ri[16], rj[16];
+    auto fetch = [&](int k0) __attribute__((always_inline)) {
+        const int klen = (D - k0 < 64) ? D - k0 : 64;
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const int e = tid + 256 * t;
+            int kk, cc;
+            if (sgk == 1) { kk = e & 63; cc = e >> 6; } else { cc = e & 63; kk = e >> 6; }
+            float vi = 0.f, vj = 0.f;
+            if (kk < klen) {
+                if (i0 + cc < n) vi = Xb[(long)(k0 + kk) * sgk + (long)(i0 + cc) * sgi];
+                if (!diag && j0 + cc < n) vj = Xb[(long)(k0 + kk) * sgk + (long)(j0 + cc) * sgi];
+            }
+            ri[t] = vi;
+            rj[t] = vj;
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < D; k0 += 64) {
+        const int klen = (D - k0 < 64) ? D - k0 : 64;
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const int e = tid + 256 * t;
+            int kk, cc;
+            if (sgk == 1) { kk = e & 63; cc = e >> 6; } else { cc = e & 63; kk = e >> 6; }
+            Is[kk * LS + cc] = ri[t];
+            if (!diag) Js[kk * LS + cc] = rj[t];
+        }
+        __syncthreads();
+        if (k0 + 64 < D) fetch(k0 + 64);
+        const float* Jt = diag ? Is : Js;
+        const int ksteps = (klen + 3) >> 2; // rows past klen hold zeros: fma(0, 0, acc) = acc
+        for (int ks = 0; ks < ksteps; ks++) {
+            const int kr = (4 * ks + g) * LS;
+            const double a0 = (double)Is[kr + 32 * wi + li], a1 = (double)Is[kr + 32 * wi + 16 + li];
+            const double b0 = (double)Jt[kr + 32 * wj + li], b1 = (double)Jt[kr + 32 * wj + 16 + li];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    double* Gb = G + (long)blockIdx.z * n * n;
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int i = i0 + 32 * wi + 16 * p + g + 4 * r, j = j0 + 32 * wj + 16 * q + li;
+                if (i < n && j < n) Gb[(long)i * n + j] = acc[p][q][r];
+            }
+    if (diag) return;
+    // the mirror image G[j][i]: straight from the registers a lane would write 8 bytes every n doubles (a 64-byte sector per
+    // element; the two Gram kernels spent most of their time there), so the tile goes through LDS and leaves row by row
+    constexpr int TS = 65;
+    double* Tt = reinterpret_cast<double*>(Ss); // [64 j][TS]: 33 KB of the 41 KB
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) Tt[(32 * wj + 16 * q + li) * TS + 32 * wi + 16 * p + g + 4 * r] = acc[p][q][r];
+    __syncthreads();
+    for (int jl = wave; jl < 64; jl += 4) {
+        const int j = j0 + jl, i = i0 + lane;
+        if (j < n && i < n) Gb[(long)j * n + i] = Tt[jl * TS + lane];
+    }
+}
+
 // Top-R eigen-pairs of the n x n Gram matrix G (global, destroyed): E1 = e sqrt(sigma), E2 = e / sqrt(sigma), fp32 [n][R].
 // Householder tridiagonalisation of a symmetric n x n matrix, 64 < n <= 64 NC (NC = 2, 3), with the matrix in REGISTERS: the
 // [M,192] Gram matrices of svd_encode and of the RGB colour-space branch, 16 x 8 / 8 x 16 patches.  k_any_eig<1> walks its
@@ -471,6 +571,300 @@ __global__ __launch_bounds__(256 * NC) void k_any_tridiag_reg(double* __restrict
             if (r == n - 1 && col == n - 2) td[n + n - 2] = Ar[s][jj];
         }
     if (tid == 0) { td[n + n - 1] = 0.0; td[2 * n + n - 2] = 0.0; td[2 * n + n - 1] = 0.0; }
+}
+
+#ifndef LRF_ANY_BLK_ROWS
+#define LRF_ANY_BLK_ROWS 16 // rows per load batch of k_any_tridiag_blk, times the columns a thread owns
+#endif
+// Blocked Householder tridiagonalisation for n > 192 (round 3; oracle: any_tridiag_blocked).  The unblocked loops of
+// k_any_eig move the whole trailing matrix through the CU two or three times per step (read for the product, read + write
+// for the rank-2 update): with hundreds of matrices in flight that traffic, not latency, is the time (256 matrices of
+// 512 x 512: ~180 GB).  Here a panel of NB = 16 (n <= 512), 8 (n <= 1024) or 4 steps leaves the trailing matrix in memory as it was at the panel's
+// start (A0) and keeps the panel's reflectors V_m and their companions W_m in LDS (2 NB n doubles, 128 KB at most):
+//   row k of the current matrix   x = A0[k][.] - sum_m (V_m[k] W_m + W_m[k] V_m)
+//   its product                   A v = A0 v - sum_m (V_m (W_m . v) + W_m (V_m . v))      (ONE read pass over A0 per step)
+//   once per panel                A -= sum_m (V_m W_m^T + W_m V_m^T)                      (one read + write pass per NB steps)
+// Thread t owns the columns t, t + 256, ... and touches only those columns of A, so no global-memory hand-off between
+// threads exists; LDS carries v, the panel and the reduction partials.  Output as k_any_tridiag_reg: row k of A keeps v_k
+// (columns > k), td = d[n], e[n], tau[n].  Dynamic LDS: (2 NB (n rounded up to even) + 64 + 8 NB + 24) doubles.
+template <int NCT>
+__global__ __launch_bounds__(256) void k_any_tridiag_blk(double* __restrict__ G, int n, double* __restrict__ TD)
+{
+    constexpr int NB = NCT == 1 ? 16 : 32 / NCT, UB = LRF_ANY_BLK_ROWS / NCT; // steps per panel (64 KB of LDS at n <= 256, up to 128 KB
+                                                                             // above); rows per load batch and thread (two batches in flight)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ns = (n + 1) & ~1;                  // row stride of the panel buffers
+    double* Vp = reinterpret_cast<double*>(smem); // [NB][ns]
+    double* Wp = Vp + (size_t)NB * ns;            // [NB][ns] (+ 64 doubles of slack: row reads run past n unguarded)
+    double* Lgh = Wp + (size_t)NB * ns + 64;      // [4 waves][2 NB]
+    double* Lpart = Lgh + 8 * NB;                 // [16]: two sets of four wave partials, used in turn
+    double* Lscal = Lpart + 16;                   // [8]
+    double* A = G + (long)blockIdx.x * n * n;
+    double* td = TD + (long)blockIdx.x * 3 * n;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // block_sum's value (wave trees, then ((p0 + p1) + p2) + p3) on the DPP tree and with ONE barrier: consecutive sums use
+    // different partial slots, and between two uses of the same slot lies the barrier of the sum in between
+    auto bsum = [&](double v, int slot) __attribute__((always_inline)) {
+        v = wave_tree64(v);
+        if (lane == 0) Lpart[4 * slot + wave] = v;
+        __syncthreads();
+        return ((Lpart[4 * slot] + Lpart[4 * slot + 1]) + Lpart[4 * slot + 2]) + Lpart[4 * slot + 3];
+    };
+    // Loads are unconditional (a guarded load costs an exec-mask branch and a dozen scalar instructions — the first version of
+    // this kernel spent ~150 cycles per row on them): rows clamp to n - 1, columns to the thread's last valid one, and what a
+    // pass makes of columns it does not own is discarded where it is used (cc is zeroed for i <= k, stores are guarded).
+    int ci[NCT];
+#pragma unroll
+    for (int c = 0; c < NCT; c++) ci[c] = (tid + 256 * c < n) ? tid + 256 * c : n - 1;
+    auto load_rows = [&](int r0, double (&a)[UB][NCT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+            const int r = (r0 + u < n) ? r0 + u : n - 1; // wave-uniform
+            const double* Ar = A + (long)r * n;
+#pragma unroll
+            for (int c = 0; c < NCT; c++) {
+#if defined(LRF_BLK_ABL) && LRF_BLK_ABL == 1
+                a[u][c] = (double)(r + ci[c]);
+#else
+                a[u][c] = Ar[ci[c]];
+#endif
+            }
+        }
+    };
+    // A step is a chain of memory round trips unless they are taken off it: row k of A0 comes out of the registers of the
+    // pass before (it is the first row of the previous step's product, or of the panel update), and the first two batches of
+    // this step's product pass are requested before the reflector is computed (they do not depend on it).
+#ifdef LRF_BLK_STAMPS
+    unsigned long long st[6] = {0, 0, 0, 0, 0, 0}, tq = __builtin_amdgcn_s_memtime(), tq0 = tq;
+#define BLK_STAMP(i) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); st[i] += tn_ - tq; tq = tn_; }
+#else
+#define BLK_STAMP(i)
+#endif
+    double xrow[NCT];
+    bool have_row = false; // xrow = A0[k][own columns >= k] for the coming step
+    for (int k0 = 0; k0 < n - 2; k0 += NB) {
+        const int np = (n - 2 - k0 < NB) ? n - 2 - k0 : NB;
+        for (int j = 0; j < np; j++) {
+            const int k = k0 + j;
+            double a0[UB][NCT], a1[UB][NCT];
+            load_rows(k + 1, a0);
+            load_rows(k + 1 + UB, a1);
+            // ---- the current row k from A0 and the panel so far
+            double x[NCT];
+#pragma unroll
+            for (int c = 0; c < NCT; c++) {
+                const int i = tid + 256 * c;
+                if (have_row) x[c] = (i < n && i >= k) ? xrow[c] : 0.0;
+                else x[c] = (i < n && i >= k) ? A[(long)k * n + i] : 0.0;
+            }
+#pragma unroll 4
+            for (int m = 0; m < j; m++) {
+                const double vk = Vp[(size_t)m * ns + k], wk = Wp[(size_t)m * ns + k];
+#pragma unroll
+                for (int c = 0; c < NCT; c++) {
+                    const int i = tid + 256 * c;
+                    if (i < n && i >= k) {
+                        x[c] = fma(-vk, Wp[(size_t)m * ns + i], x[c]);
+                        x[c] = fma(-wk, Vp[(size_t)m * ns + i], x[c]);
+                    }
+                }
+            }
+            double s = 0.0;
+#pragma unroll
+            for (int c = 0; c < NCT; c++) {
+                const int i = tid + 256 * c;
+                if (i == k) { td[k] = x[c]; x[c] = 0.0; }
+                if (i == k + 1) Lscal[0] = x[c];
+                s = fma(x[c], x[c], s);
+            }
+            const double sigma = bsum(s, 0); // its barrier publishes Lscal[0]
+            if (!(sigma > LRF_SIGMA_TINY)) { // the same in every thread
+                if (tid == 0) { td[n + k] = 0.0; td[2 * n + k] = 0.0; }
+#pragma unroll
+                for (int c = 0; c < NCT; c++) {
+                    const int i = tid + 256 * c;
+                    if (i < n) { Vp[(size_t)j * ns + i] = 0.0; Wp[(size_t)j * ns + i] = 0.0; }
+                    xrow[c] = a0[0][c]; // row k + 1 of A0 (columns >= k + 1)
+                }
+                have_row = true;
+                __syncthreads();
+                continue;
+            }
+            BLK_STAMP(1)
+            const double x0 = Lscal[0];
+            const double nrm = sqrt(sigma);
+            const double alpha = (x0 >= 0.0) ? -nrm : nrm;
+            const double t = 1.0 / fma(fabs(x0), nrm, sigma);
+            double v[NCT];
+#pragma unroll
+            for (int c = 0; c < NCT; c++) {
+                const int i = tid + 256 * c;
+                v[c] = (i == k + 1) ? x0 - alpha : x[c];
+                if (i < n) {
+                    Vp[(size_t)j * ns + i] = v[c];
+                    if (i > k) A[(long)k * n + i] = v[c];
+                }
+            }
+            if (tid == 0) { td[n + k] = alpha; td[2 * n + k] = t; }
+            // ---- g_m = W_m . v, h_m = V_m . v: thread partials over its own columns, one tree per wave, four partials in LDS
+#if defined(LRF_BLK_ABL) && LRF_BLK_ABL == 2
+            for (int m = 0; m < 0; m++) {
+#else
+#pragma unroll 4
+            for (int m = 0; m < j; m++) {
+#endif
+                double sg = 0.0, sh = 0.0;
+#pragma unroll
+                for (int c = 0; c < NCT; c++) {
+                    const int i = tid + 256 * c;
+                    if (i < n) {
+                        sg = fma(Wp[(size_t)m * ns + i], v[c], sg);
+                        sh = fma(Vp[(size_t)m * ns + i], v[c], sh);
+                    }
+                }
+                sg = wave_tree64(sg);
+                sh = wave_tree64(sh);
+                if (lane == 0) { Lgh[wave * 2 * NB + 2 * m] = sg; Lgh[wave * 2 * NB + 2 * m + 1] = sh; }
+            }
+            __syncthreads(); // V_j and the partials are visible
+            BLK_STAMP(2)
+            // ---- A0 v: rows in batches of UB, two batches in flight (a read-only pass)
+            const double* Lv = Vp + (size_t)j * ns;
+            double cc[NCT];
+#pragma unroll
+            for (int c = 0; c < NCT; c++) { cc[c] = 0.0; xrow[c] = a0[0][c]; }
+            have_row = true;
+            {
+                auto matvec_rows = [&](int j0, const double (&a)[UB][NCT]) __attribute__((always_inline)) {
+                    double lv[UB]; // read without the row guard (the buffers have slack), so that the reads pair up
+#pragma unroll
+                    for (int u = 0; u < UB; u++) lv[u] = Lv[j0 + u];
+#pragma unroll
+                    for (int u = 0; u < UB; u++) {
+                        const double vj = (j0 + u < n) ? lv[u] : 0.0; // rows past n: fma(a, 0, cc) = cc (a is the clamped row, finite)
+#pragma unroll
+                        for (int c = 0; c < NCT; c++) cc[c] = fma(a[u][c], vj, cc[c]);
+                    }
+                };
+                for (int j0 = k + 1; j0 < n; j0 += 2 * UB) {
+                    matvec_rows(j0, a0);
+                    if (j0 + 2 * UB < n) load_rows(j0 + 2 * UB, a0);
+                    matvec_rows(j0 + UB, a1);
+                    if (j0 + 3 * UB < n) load_rows(j0 + 3 * UB, a1);
+                }
+            }
+            BLK_STAMP(3)
+#pragma unroll 4
+            for (int m = 0; m < j; m++) {
+                const double gm = ((Lgh[2 * m] + Lgh[2 * NB + 2 * m]) + Lgh[4 * NB + 2 * m]) + Lgh[6 * NB + 2 * m];
+                const double hm = ((Lgh[2 * m + 1] + Lgh[2 * NB + 2 * m + 1]) + Lgh[4 * NB + 2 * m + 1]) + Lgh[6 * NB + 2 * m + 1];
+#pragma unroll
+                for (int c = 0; c < NCT; c++) {
+                    const int i = tid + 256 * c;
+                    if (i < n && i > k) {
+                        cc[c] = fma(-Vp[(size_t)m * ns + i], gm, cc[c]);
+                        cc[c] = fma(-Wp[(size_t)m * ns + i], hm, cc[c]);
+                    }
+                }
+            }
+            s = 0.0;
+#pragma unroll
+            for (int c = 0; c < NCT; c++) {
+                const int i = tid + 256 * c;
+                if (!(i < n && i > k)) cc[c] = 0.0;
+                cc[c] = t * cc[c];
+                s = fma(cc[c], v[c], s);
+            }
+            const double Kc = (0.5 * t) * bsum(s, 1);
+#pragma unroll
+            for (int c = 0; c < NCT; c++) {
+                const int i = tid + 256 * c;
+                if (i < n) Wp[(size_t)j * ns + i] = fma(-Kc, v[c], cc[c]);
+            }
+            __syncthreads();
+        }
+        BLK_STAMP(4)
+        // ---- the panel's rank-2 np update of the trailing matrix (rows and columns >= kend): the thread's own columns of the
+        // panel in registers, the rows' values by broadcast LDS reads; the next batch's loads go out before this one's stores
+        const int kend = k0 + np;
+        // per reflector m and batch: the rows' V_m / W_m values (UB consecutive doubles each, broadcast reads that pair up) and the
+        // thread's own columns of V_m / W_m; every element still receives its updates in ascending m
+        auto update_rows = [&](int r0, double (&a)[UB][NCT]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int m = 0; m < NB; m++) {
+                if (m < np) {
+                    double vr[UB], wr[UB], vic[NCT], wic[NCT];
+#pragma unroll
+                    for (int u = 0; u < UB; u++) { vr[u] = Vp[(size_t)m * ns + r0 + u]; wr[u] = Wp[(size_t)m * ns + r0 + u]; }
+#pragma unroll
+                    for (int c = 0; c < NCT; c++) {
+                        const int i = tid + 256 * c;
+                        vic[c] = (i < n) ? Vp[(size_t)m * ns + i] : 0.0;
+                        wic[c] = (i < n) ? Wp[(size_t)m * ns + i] : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < UB; u++)
+#pragma unroll
+                        for (int c = 0; c < NCT; c++) a[u][c] = fma(-wr[u], vic[c], fma(-vr[u], wic[c], a[u][c]));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UB; u++) {
+                const int r = r0 + u;
+                if (r < n) {
+                    double* Ar = A + (long)r * n;
+#pragma unroll
+                    for (int c = 0; c < NCT; c++) {
+                        const int i = tid + 256 * c;
+#if defined(LRF_BLK_ABL) && LRF_BLK_ABL == 6
+                        if (i < n && i >= kend && a[u][c] == 1.2345e301) Ar[i] = a[u][c];
+#else
+                        if (i < n && i >= kend) Ar[i] = a[u][c];
+#endif
+                    }
+                }
+            }
+        };
+        {
+            double a0[UB][NCT], a1[UB][NCT];
+            load_rows(kend, a0);
+            load_rows(kend + UB, a1);
+#if defined(LRF_BLK_ABL) && LRF_BLK_ABL == 3
+            for (int r0 = kend; r0 < kend + 1; r0 += 2 * UB) {
+#else
+            for (int r0 = kend; r0 < n; r0 += 2 * UB) {
+#endif
+                update_rows(r0, a0);
+                if (r0 == kend) {
+#pragma unroll
+                    for (int c = 0; c < NCT; c++) xrow[c] = a0[0][c]; // the updated row kend: the next panel's first row
+                }
+                if (r0 + 2 * UB < n) load_rows(r0 + 2 * UB, a0);
+                update_rows(r0 + UB, a1);
+                if (r0 + 3 * UB < n) load_rows(r0 + 3 * UB, a1);
+            }
+            have_row = true;
+        }
+        __syncthreads(); // the panel buffers are rewritten by the next panel
+        BLK_STAMP(5)
+    }
+    // d[n-2], d[n-1], e[n-2] from the updated matrix (each element read by the thread that owns its column)
+#pragma unroll
+    for (int c = 0; c < NCT; c++) {
+        const int i = tid + 256 * c;
+        if (i == n - 2) { td[n - 2] = A[(long)(n - 2) * n + i]; td[n + n - 2] = A[(long)(n - 1) * n + i]; }
+        if (i == n - 1) td[n - 1] = A[(long)(n - 1) * n + i];
+    }
+    if (tid == 0) { td[n + n - 1] = 0.0; td[2 * n + n - 2] = 0.0; td[2 * n + n - 1] = 0.0; }
+#ifdef LRF_BLK_STAMPS
+    if (tid == 0 && blockIdx.x < 16384) {
+        unsigned long long* o = g_stamps + 8 * blockIdx.x;
+        o[0] = __builtin_amdgcn_s_memtime() - tq0;
+        for (int q = 1; q < 6; q++) o[q] = st[q];
+    }
+#endif
+#undef BLK_STAMP
 }
 
 // One workgroup per matrix; thread t owns the columns t, t + 256, ... (NC = ceil(n/256) <= NCT of them).

@@ -1580,7 +1580,7 @@ int lrf_host_unregister(void* p)
     return LRF_OK;
 }
 
-#if defined(LRF_STAMPS) || defined(LRF_INIT_STAMPS)
+#if defined(LRF_STAMPS) || defined(LRF_INIT_STAMPS) || defined(LRF_BLK_STAMPS)
 int lrf_debug_read_stamps(lrf_ctx* c, unsigned long long* out_host, int n)
 {
     HIP_TRY(hipStreamSynchronize(c->stream));

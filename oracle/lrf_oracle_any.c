@@ -12,10 +12,12 @@
  *   tree64(s)       wave butterfly (wave_sum / wave_tree64): for off = 32..1: s[i] += s[i + off]
  *   block_sum256(s) four wave trees, then ((p0 + p1) + p2) + p3
  *   "thread t owns columns t, t + 256, ..." partial sums, "lane l owns i = l, l + 64, ..." partial sums
- * Three tridiagonalisations, chosen by the side n = min(M, N) exactly as lrf_anyshape_host.inc does:
- *   n <= 64 or 192 < n <= 256   k_any_eig<1>, plain three-pass Householder step        (any_tridiag_plain)
+ * Tridiagonalisations, chosen by the side n = min(M, N) exactly as lrf_anyshape_host.inc does:
+ *   n <= 64                     k_any_eig<1>, plain three-pass Householder step        (any_tridiag_plain)
  *   64 < n <= 192               k_any_tridiag_reg<2 or 3>, matrix in registers          (any_tridiag_reg)
- *   n > 256                     k_any_eig<2|4|8>, update fused with the next matvec     (any_tridiag_fused)
+ *   n > 192                     k_any_tridiag_blk<1|2|4|8>, panels of 16/16/8/4 steps   (any_tridiag_blocked)
+ * (any_tridiag_fused, and any_tridiag_plain above n = 192, are the round-2 variants the library keeps behind
+ *  LRF_ANY_TRIDIAG_UNBLOCKED=1; here LRF_ORACLE_ANY_TRIDIAG=unblocked selects them.)
  */
 
 static double tree64c(const double* v)
@@ -336,6 +338,121 @@ static void any_tridiag_fused(double* A, int n, int NCT, double* d, double* e, d
     free(Lvk); free(Lvn); free(w); free(cc); free(cc2); free(rowv);
 }
 
+/* ---- k_any_tridiag_blk<NCT> (n > 192): panels of NB = 16 (n <= 512), 8 (n <= 1024), 4 Householder steps (LAPACK's dlatrd shape).  Inside a panel
+ * the trailing matrix in memory stays as it was at the panel's start (A0); step k forms its row from A0 and the panel's
+ * reflectors, x = A0[k][.] - sum_m (V_m[k] W_m + W_m[k] V_m), its product as A0 v - sum_m (V_m (W_m . v) + W_m (V_m . v)),
+ * and the rank-2 NB update is applied once per panel (two fmas per pair, not symmetrised).  Thread t owns the columns
+ * t, t + 256, ...; every thread only ever touches its own columns of A.  t = 1 / (sigma + |x0| nrm) as in k_any_tridiag_reg. */
+static void any_tridiag_blocked(double* A, int n, int NCT, int NB, double* d, double* e, double* tau)
+{
+    double tv[256], tg[256], th[256], g[16], h[16];
+    double *Vp = (double*)calloc((size_t)NB * n, sizeof(double)), *Wp = (double*)calloc((size_t)NB * n, sizeof(double)),
+           *x = (double*)malloc(sizeof(double) * n), *v = (double*)malloc(sizeof(double) * n), *p = (double*)malloc(sizeof(double) * n);
+    for (int i = 0; i < n; i++) { d[i] = 0.0; e[i] = 0.0; tau[i] = 0.0; }
+    for (int k0 = 0; k0 < n - 2; k0 += NB) {
+        const int np = (n - 2 - k0 < NB) ? n - 2 - k0 : NB;
+        for (int j = 0; j < np; j++) {
+            const int k = k0 + j;
+            for (int i = 0; i < n; i++) { /* the current row k (and the diagonal element) */
+                double xx = 0.0;
+                if (i >= k) {
+                    xx = A[(long)k * n + i];
+                    for (int m = 0; m < j; m++) {
+                        xx = fma(-Vp[(long)m * n + k], Wp[(long)m * n + i], xx);
+                        xx = fma(-Wp[(long)m * n + k], Vp[(long)m * n + i], xx);
+                    }
+                }
+                x[i] = xx;
+            }
+            d[k] = x[k];
+            x[k] = 0.0;
+            for (int tt = 0; tt < 256; tt++) {
+                double s = 0.0;
+                for (int c = 0; c < NCT; c++) {
+                    const int i = tt + 256 * c;
+                    if (i < n) s = fma(x[i], x[i], s);
+                }
+                tv[tt] = s;
+            }
+            const double sigma = block_sum256(tv);
+            if (!(sigma > LRF_SIGMA_TINY)) {
+                tau[k] = 0.0;
+                e[k] = 0.0;
+                for (int i = 0; i < n; i++) { Vp[(long)j * n + i] = 0.0; Wp[(long)j * n + i] = 0.0; }
+                continue;
+            }
+            const double x0 = x[k + 1];
+            const double nrm = sqrt(sigma);
+            const double alpha = (x0 >= 0.0) ? -nrm : nrm;
+            const double t = 1.0 / fma(fabs(x0), nrm, sigma);
+            for (int i = 0; i < n; i++) {
+                v[i] = (i == k + 1) ? x0 - alpha : x[i];
+                Vp[(long)j * n + i] = v[i];
+                if (i > k) A[(long)k * n + i] = v[i];
+            }
+            tau[k] = t;
+            e[k] = alpha;
+            for (int m = 0; m < j; m++) { /* g_m = W_m . v, h_m = V_m . v */
+                for (int tt = 0; tt < 256; tt++) {
+                    double sg = 0.0, sh = 0.0;
+                    for (int c = 0; c < NCT; c++) {
+                        const int i = tt + 256 * c;
+                        if (i < n) {
+                            sg = fma(Wp[(long)m * n + i], v[i], sg);
+                            sh = fma(Vp[(long)m * n + i], v[i], sh);
+                        }
+                    }
+                    tg[tt] = sg;
+                    th[tt] = sh;
+                }
+                g[m] = block_sum256(tg);
+                h[m] = block_sum256(th);
+            }
+            for (int i = 0; i < n; i++) {
+                double c = 0.0;
+                if (i > k) {
+                    for (int r = k + 1; r < n; r++) c = fma(A[(long)r * n + i], v[r], c);
+                    for (int m = 0; m < j; m++) {
+                        c = fma(-Vp[(long)m * n + i], g[m], c);
+                        c = fma(-Wp[(long)m * n + i], h[m], c);
+                    }
+                }
+                p[i] = c;
+            }
+            for (int tt = 0; tt < 256; tt++) {
+                double s = 0.0;
+                for (int c = 0; c < NCT; c++) {
+                    const int i = tt + 256 * c;
+                    if (i < n) {
+                        p[i] = t * p[i];
+                        s = fma(p[i], v[i], s);
+                    }
+                }
+                tv[tt] = s;
+            }
+            const double Kc = (0.5 * t) * block_sum256(tv);
+            for (int i = 0; i < n; i++) Wp[(long)j * n + i] = fma(-Kc, v[i], p[i]);
+        }
+        const int kend = k0 + np;
+        for (int r = kend; r < n; r++)
+            for (int i = kend; i < n; i++) {
+                double a = A[(long)r * n + i];
+                for (int m = 0; m < np; m++) {
+                    a = fma(-Vp[(long)m * n + r], Wp[(long)m * n + i], a);
+                    a = fma(-Wp[(long)m * n + r], Vp[(long)m * n + i], a);
+                }
+                A[(long)r * n + i] = a;
+            }
+    }
+    if (n >= 2) {
+        d[n - 2] = A[(long)(n - 2) * n + n - 2];
+        e[n - 2] = A[(long)(n - 1) * n + n - 2];
+    }
+    d[n - 1] = A[(long)(n - 1) * n + n - 1];
+    if (n == 1) d[0] = A[0];
+    free(Vp); free(Wp); free(x); free(v); free(p);
+}
+
 /* Sturm count of k_any_eig / k_init for a side n (sturm_count above is the n = 64 case): de[j] = (d'_j, e'_{j-1}^2) */
 static int any_sturm_count(const double* ds, const double* e2s, int n, double x)
 {
@@ -371,9 +488,11 @@ int lrf_oracle_any_eig(double* G, int n, int R, int rcap, const int8_t* sign, fl
            *Dp = (double*)malloc(sizeof(double) * n), *Dm = (double*)malloc(sizeof(double) * n), *x = (double*)malloc(sizeof(double) * n),
            *cf = (double*)malloc(sizeof(double) * (Rc > 0 ? Rc : 1));
     double tv[256], lanes[64];
+    const char* tdv = getenv("LRF_ORACLE_ANY_TRIDIAG"); /* developer aid: "unblocked" = the round-2 variants above n = 192 */
     if (n > 64 && n <= 192) any_tridiag_reg(G, n, n <= 128 ? 2 : 3, d, e, tau);
-    else if (NCT == 1) any_tridiag_plain(G, n, d, e, tau);
-    else any_tridiag_fused(G, n, NCT, d, e, tau);
+    else if (n <= 64) any_tridiag_plain(G, n, d, e, tau);
+    else if (tdv && tdv[0] == 'u') { if (NCT == 1) any_tridiag_plain(G, n, d, e, tau); else any_tridiag_fused(G, n, NCT, d, e, tau); }
+    else any_tridiag_blocked(G, n, NCT, NCT == 1 ? 16 : 32 / NCT, d, e, tau);
     /* Gershgorin hull, pivmin (min / max: order-free) */
     double lo = 1e300, hi = -1e300, e2m = 0.0;
     for (int i = 0; i < n; i++) {

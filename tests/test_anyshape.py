@@ -105,7 +105,8 @@ def test_repack_is_byte_identical(name):
     assert pack_anyshape(c.ref_factors(), (H, W), c.ranks, tuple(c.kwargs.get("bounds", (-16, 15))), ps) == c.encoded
 
 
-@pytest.mark.parametrize("M,N,R", [(384, 16, 5), (35, 256, 6), (100, 300, 40), (300, 100, 100), (64, 64, 3), (200, 230, 9), (330, 290, 12)])
+@pytest.mark.parametrize("M,N,R", [(384, 16, 5), (35, 256, 6), (100, 300, 40), (300, 100, 100), (64, 64, 3), (200, 230, 9), (330, 290, 12),
+                                  (256, 400, 10), (520, 515, 8)])
 def test_oracle_restated_init_agrees_with_jacobi_and_lapack(M, N, R, oracle):
     """lrf_oracle_svd_topr_any (the restatement of the GPU's eigen-solver, every tridiagonalisation variant) against the
     independent cyclic-Jacobi routine and numpy's LAPACK SVD: the same rank-R approximation to fp32 accuracy."""
@@ -252,10 +253,12 @@ def test_hip_bcd_equals_oracle_on_any_shape(M, N, R, K, bounds, oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,N,R", [(384, 16, 5), (35, 256, 6), (100, 300, 40), (300, 100, 100), (64, 64, 3), (513, 300, 7),
-                                  (20, 1024, 20), (700, 600, 30)])
+                                  (20, 1024, 20), (700, 600, 30), (230, 500, 12), (256, 256, 9), (257, 400, 5), (600, 511, 11),
+                                  (1100, 1030, 6)])
 def test_hip_init_matches_oracle_init(M, N, R, oracle):
-    """SVD initialisation on any shape: bit for bit the oracle's restatement (lrf_oracle_any.c: all three tridiagonalisation
-    variants are in the list — sides 16 / 35 / 64, 100, 300 / 600); against LAPACK (numpy) and the independent Jacobi solver
+    """SVD initialisation on any shape: bit for bit the oracle's restatement (lrf_oracle_any.c: every tridiagonalisation
+    variant is in the list — sides 16 / 35 / 64 plain, 100 in registers, and the blocked one with panels of 16 (230, 256,
+    257, 300, 511), 8 (600) and 4 steps (1030)); against LAPACK (numpy) and the independent Jacobi solver
     the rank-R product u0 v0^T agrees to fp32 accuracy, the column norms are the singular values, the default sign holds"""
     from lrf_amd import _lib
     rng = np.random.default_rng(M + N + R)
@@ -289,7 +292,8 @@ def test_hip_init_of_rank_deficient_matrices_equals_oracle(oracle):
     from lrf_amd import _lib
     ctx = _lib.context()
     rng = np.random.default_rng(3)
-    for (M, N, R) in ((200, 17, 17), (96, 256, 70), (40, 40, 45), (14, 46, 18), (31, 389, 37), (300, 150, 80)):
+    for (M, N, R) in ((200, 17, 17), (96, 256, 70), (40, 40, 45), (14, 46, 18), (31, 389, 37), (300, 150, 80), (250, 700, 100),
+                      (530, 300, 120)):  # the last two: blocked tridiagonalisation with skipped (null) steps inside its panels
         k = max(1, min(M, N) // 3)
         X = (rng.integers(0, 16, (M, k)) @ rng.integers(0, 16, (k, N))).astype(np.float32)
         sign = (rng.integers(0, 2, R) * 2 - 1).astype(np.int8)
