@@ -136,37 +136,66 @@ __global__ __launch_bounds__(256) void k_any_fold(const float* __restrict__ P, f
 
 // `uu @ bb` of qmf.py:115 for column r of one row: the K = R - 1 terms j != r, in MKL's single-output-column order
 // (oracle dot_mkl_n1) or ATen's native order.  u: the row (LDS, pitch 1), b: row r of the symmetric b (uniform address).
+// A chain of the sum in j space: cnt terms u[j] b[j] from j on in steps of STEP, added to acc in that order.  The operands of
+// eight terms are fetched together (they do not depend on the sum): taken one at a time, every term waited for its LDS read
+// and its uniform load, and the index n -> j = n + (n >= r) cost a dozen scalar instructions per term — the skipped column
+// splits each chain into two plain runs instead.
+template <int STEP>
+__device__ __forceinline__ float any_chain(float acc, const float* u, const float* __restrict__ b, int j, int cnt)
+{
+    int t = 0;
+    for (; t + 8 <= cnt; t += 8) {
+        float pq[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) pq[q] = u[j + STEP * q] * b[j + STEP * q];
+#pragma unroll
+        for (int q = 0; q < 8; q++) acc = acc + pq[q];
+        j += 8 * STEP;
+    }
+    for (; t < cnt; t++) {
+        const float pv = u[j] * b[j];
+        acc = acc + pv;
+        j += STEP;
+    }
+    return acc;
+}
+
 __device__ __forceinline__ float any_term2(const float* u, const float* __restrict__ b, int r, int R, bool native)
 {
     const int K = R - 1;
     if (K <= 0) return 0.f;
 #define ANY_J(n) ((n) < r ? (n) : (n) + 1)
-    if (native) {
-        float acc = 0.f;
-        for (int n = 0; n < K; n++) {
-            const int j = ANY_J(n);
-            const float p = u[j] * b[j];
-            acc = acc + p;
-        }
-        return acc;
+    if (native) { // one chain, n ascending: j = 0 .. r - 1, then r + 1 .. R - 1
+        float acc = any_chain<1>(0.f, u, b, 0, r);
+        return any_chain<1>(acc, u, b, r + 1, K - r);
     }
     const int j0 = ANY_J(0);
     if (K == 1) return u[j0] * b[j0];
     const int j1 = ANY_J(1);
     float odd = fmaf(u[j1], b[j1], u[j0] * b[j0]);
-    const int last_odd = ((K - 1) & 1) ? K - 1 : K - 2;
-    for (int n = last_odd; n >= 3; n -= 2) {
-        const int j = ANY_J(n);
-        const float p = u[j] * b[j];
-        odd = odd + p;
-    }
     if (K < 3) return odd;
     const int j2 = ANY_J(2);
     float even = u[j2] * b[j2];
-    for (int n = 4; n < K; n += 2) {
-        const int j = ANY_J(n);
-        const float p = u[j] * b[j];
-        even = even + p;
+    // odd n from last_odd down to 3: first the part with n >= r (j = n + 1), then n < r (j = n)
+    const int last_odd = ((K - 1) & 1) ? K - 1 : K - 2;
+    {
+        const int m = r > 3 ? r : 3, n0 = (m & 1) ? m : m + 1;             // smallest odd n >= max(r, 3)
+        const int chi = (last_odd >= n0) ? (last_odd - n0) / 2 + 1 : 0;
+        odd = any_chain<-2>(odd, u, b, last_odd + 1, chi);
+        int n1 = (r & 1) ? r - 2 : r - 1;                                  // largest odd n < r
+        if (n1 > last_odd) n1 = last_odd;
+        const int clo = (n1 >= 3) ? (n1 - 3) / 2 + 1 : 0;
+        odd = any_chain<-2>(odd, u, b, n1, clo);
+    }
+    // even n from 4 up to K - 1: first n < r (j = n), then n >= r (j = n + 1)
+    {
+        const int lim = r < K ? r : K;                                     // n < lim
+        const int n2 = ((lim - 1) & 1) ? lim - 2 : lim - 1;                // largest even n < lim
+        const int clo = (n2 >= 4) ? (n2 - 4) / 2 + 1 : 0;
+        even = any_chain<2>(even, u, b, 4, clo);
+        const int m = r > 4 ? r : 4, n3 = (m & 1) ? m + 1 : m;             // smallest even n >= max(r, 4)
+        const int chi = (n3 < K) ? (K - 1 - n3) / 2 + 1 : 0;
+        even = any_chain<2>(even, u, b, n3 + 1, chi);
     }
     return odd + even;
 #undef ANY_J

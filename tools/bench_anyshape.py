@@ -26,7 +26,10 @@ def encode(ps, ranks):
     return out
 
 
+ONLY = sys.argv[3] if len(sys.argv) > 3 else None  # "4", "16", "32" or "none": one patch size only
 for ps in ((4, 4), (16, 16), (32, 32), None):
+    if ONLY is not None and ONLY != ("none" if ps is None else str(ps[0])):
+        continue
     ranks = anyshape_ranks((H, W), ps, None, Q)
     dims = _lib.plane_dims_any(H, W, ps)
     encode(ps, ranks)
