@@ -123,6 +123,123 @@ __global__ __launch_bounds__(256) void k_any_prod(const float* __restrict__ A, l
     }
 }
 
+// The same products for contractions deeper than 32 (round 3): a 128 x 64 tile of P per workgroup, a wave 32 rows x 64
+// columns as 2 x 4 MFMA tiles (six LDS operand reads per eight MFMAs; k_any_prod: two or three per one or two), the next
+// 32-deep chunk fetched into registers under the MFMAs of the current one, loads unconditional on clamped addresses (a
+// guarded load is an exec-mask branch).  Per element still the k-ordered fma chain of its 384-block: bit-identical.
+// grid (ceil(I/128), ceil(R/64) * nblk, B)
+__global__ __launch_bounds__(256) void k_any_prod_big(const float* __restrict__ A, long a_batch, long sai, long sak,
+                                                      const float* __restrict__ Bm, long b_batch, float* __restrict__ P,
+                                                      int I, int D, int R, int nblk)
+{
+    constexpr int LSA = 145, LSB = 81; // strides 17 mod 64: operand reads (16 lanes along i / r, 4 along k) and staging stores conflict-free
+    __shared__ float As[32 * LSA];
+    __shared__ float Bs[32 * LSB];
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rt = blockIdx.y / nblk, blk = blockIdx.y - rt * nblk;
+    const int r0 = rt * 64, i0 = blockIdx.x * 128;
+    const float* Ab = A + (long)blockIdx.z * a_batch;
+    const float* Bb = Bm + (long)blockIdx.z * b_batch;
+    const int kbeg = blk * LRF_KC;
+    const int kend = (kbeg + LRF_KC < D) ? kbeg + LRF_KC : D;
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[p][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // staging roles: A 32 x 128 = 16 values per thread, B 32 x 64 = 8 per thread.  Element offsets relative to the chunk's first
+    // k are fixed per thread (rows / columns clamped once), so a chunk costs one scalar base and 24 loads; only the last,
+    // partial chunk of a block guards k.  (The host sends matrices whose offsets do not fit 32 bits to k_any_prod.)
+    float ra[16], rb[8];
+    unsigned offa[16], offb[8];
+    int kka[16], kkb[8];
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+        const int e = tid + 256 * t;
+        int kk, ii;
+        if (sak == 1) { kk = e & 31; ii = e >> 5; } else { ii = e & 127; kk = e >> 7; }
+        const int i = (i0 + ii < I) ? i0 + ii : I - 1;
+        kka[t] = kk;
+        offa[t] = (unsigned)((long)i * sai + (long)kk * sak);
+    }
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const int e = tid + 256 * t;
+        const int rr = e & 63, kk = e >> 6;
+        kkb[t] = kk;
+        offb[t] = (unsigned)(kk * R + ((r0 + rr < R) ? r0 + rr : R - 1));
+    }
+    auto fetch = [&](int k0) __attribute__((always_inline)) {
+        const float* pa = Ab + (long)k0 * sak; // wave-uniform bases
+        const float* pb = Bb + (long)k0 * R;
+        if (k0 + 32 <= kend) {
+#pragma unroll
+            for (int t = 0; t < 16; t++) ra[t] = pa[offa[t]];
+#pragma unroll
+            for (int t = 0; t < 8; t++) rb[t] = pb[offb[t]];
+        } else { // the block's last chunk: k past kend reads as zero (and is not dereferenced)
+            const int klen = kend - k0;
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                const float v = pa[(kka[t] < klen) ? offa[t] : offa[t] - (unsigned)((long)(kka[t] - (klen - 1)) * sak)];
+                ra[t] = (kka[t] < klen) ? v : 0.f;
+            }
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const float v = pb[(kkb[t] < klen) ? offb[t] : offb[t] - (unsigned)((kkb[t] - (klen - 1)) * R)];
+                rb[t] = (kkb[t] < klen) ? v : 0.f;
+            }
+        }
+    };
+    fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
+        const int klen = (kend - k0 < 32) ? kend - k0 : 32;
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const int e = tid + 256 * t;
+            int kk, ii;
+            if (sak == 1) { kk = e & 31; ii = e >> 5; } else { ii = e & 127; kk = e >> 7; }
+            As[kk * LSA + ii] = ra[t];
+        }
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            const int e = tid + 256 * t;
+            Bs[(e >> 6) * LSB + (e & 63)] = rb[t];
+        }
+        __syncthreads();
+        if (k0 + 32 < kend) fetch(k0 + 32);
+        const int steps = (klen + 3) >> 2; // entries past klen are zeros: fma(0, 0, acc) = acc
+        for (int s4 = 0; s4 < steps; s4++) {
+            const float* ar = As + (4 * s4 + lq) * LSA + 32 * wave + li;
+            const float* br = Bs + (4 * s4 + lq) * LSB + li;
+            const float a0 = ar[0], a1 = ar[16];
+            const float b0 = br[0], b1 = br[16], b2 = br[32], b3 = br[48];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b2, acc[0][2], 0, 0, 0);
+            acc[0][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b3, acc[0][3], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+            acc[1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b2, acc[1][2], 0, 0, 0);
+            acc[1][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b3, acc[1][3], 0, 0, 0);
+        }
+    }
+    float* Pb = P + (((long)blockIdx.z * nblk + blk) * I) * R;
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int r = r0 + 16 * q + li;
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int i = i0 + 32 * wave + 16 * p + 4 * lq + reg;
+                if (i < I && r < R) Pb[(long)i * R + r] = acc[p][q][reg];
+            }
+        }
+}
+
 // C[b][e] = ((P[b][0][e] + P[b][1][e]) + P[b][2][e]) + ...   e < IR;  grid (ceil(IR/256), B)
 __global__ __launch_bounds__(256) void k_any_fold(const float* __restrict__ P, float* __restrict__ C, long IR, int nblk)
 {
