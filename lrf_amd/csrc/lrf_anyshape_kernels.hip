@@ -240,6 +240,84 @@ __global__ __launch_bounds__(256) void k_any_prod_big(const float* __restrict__ 
         }
 }
 
+// Thin products (4 x 4 patches: X [24576, 16], rank 3 — x.mT @ u and u.mT @ u contract 24576 rows into a 16 x 3 or 3 x 3
+// result, x @ v contracts 16 columns for 24576 rows): k_any_prod stages 64 x 64 tiles of which a sixteenth is used.  Here the
+// MFMA operands come straight from global memory, one wave per work item, eight steps' loads in flight; per element the same
+// k-ordered chain.
+// (1) I <= 16, R <= 16, long contraction: one wave per (384-block, matrix).  grid (nblk, B), 64 threads
+__global__ __launch_bounds__(64) void k_any_prod_thin_long(const float* __restrict__ A, long a_batch, long sai, long sak,
+                                                           const float* __restrict__ Bm, long b_batch, float* __restrict__ P,
+                                                           int I, int D, int R, int nblk)
+{
+    const int lane = threadIdx.x, li = lane & 15, lq = lane >> 4;
+    const int blk = blockIdx.x;
+    const int kbeg = blk * LRF_KC, kend = (kbeg + LRF_KC < D) ? kbeg + LRF_KC : D;
+    const float* pa = A + (long)blockIdx.y * a_batch + (long)((li < I) ? li : I - 1) * sai;
+    const float* pb = Bm + (long)blockIdx.y * b_batch + ((li < R) ? li : R - 1);
+    const bool va = li < I, vb = li < R;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
+        float av[8], bv[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int k = k0 + 4 * q + lq, kc = (k < kend) ? k : kend - 1;
+            const float x = pa[(long)kc * sak], y = pb[(long)kc * R];
+            av[q] = (va && k < kend) ? x : 0.f;
+            bv[q] = (vb && k < kend) ? y : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            if (k0 + 4 * q < kend) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bv[q], acc, 0, 0, 0); // wave-uniform
+    }
+    float* Pb = P + (((long)blockIdx.y * nblk + blk) * I) * R;
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+        const int i = 4 * lq + reg;
+        if (i < I && li < R) Pb[(long)i * R + li] = acc[reg];
+    }
+}
+
+// (2) contraction D <= 64, R <= 16, many rows: a wave takes TPW consecutive 16-row tiles; the B operand (D x R) stays in
+// registers.  Single 384-block (D <= 64 < LRF_KC): P is the result.  grid (ceil(I / (16 TPW)), B), 64 threads
+template <int STEPS>
+__global__ __launch_bounds__(64) void k_any_prod_thin_short(const float* __restrict__ A, long a_batch, long sai, long sak,
+                                                            const float* __restrict__ Bm, long b_batch, float* __restrict__ P,
+                                                            int I, int D, int R, int tpw)
+{
+    const int lane = threadIdx.x, li = lane & 15, lq = lane >> 4;
+    const float* Ab = A + (long)blockIdx.y * a_batch;
+    const float* pb = Bm + (long)blockIdx.y * b_batch + ((li < R) ? li : R - 1);
+    float bv[STEPS];
+#pragma unroll
+    for (int q = 0; q < STEPS; q++) {
+        const int k = 4 * q + lq, kc = (k < D) ? k : D - 1;
+        const float y = pb[(long)kc * R];
+        bv[q] = (li < R && k < D) ? y : 0.f;
+    }
+    float* Pb = P + (long)blockIdx.y * I * R;
+    for (int t = 0; t < tpw; t++) {
+        const int i0 = (blockIdx.x * tpw + t) * 16;
+        if (i0 >= I) break; // wave-uniform
+        const int ic = (i0 + li < I) ? i0 + li : I - 1;
+        const float* pa = Ab + (long)ic * sai;
+        float av[STEPS];
+#pragma unroll
+        for (int q = 0; q < STEPS; q++) {
+            const int k = 4 * q + lq, kc = (k < D) ? k : D - 1;
+            const float x = pa[(long)kc * sak];
+            av[q] = (k < D) ? x : 0.f;
+        }
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < STEPS; q++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bv[q], acc, 0, 0, 0);
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int i = i0 + 4 * lq + reg;
+            if (i < I && li < R) Pb[(long)i * R + li] = acc[reg];
+        }
+    }
+}
+
 // C[b][e] = ((P[b][0][e] + P[b][1][e]) + P[b][2][e]) + ...   e < IR;  grid (ceil(IR/256), B)
 __global__ __launch_bounds__(256) void k_any_fold(const float* __restrict__ P, float* __restrict__ C, long IR, int nblk)
 {
@@ -342,26 +420,44 @@ __global__ __launch_bounds__(64) void k_any_gs(const float* __restrict__ a, cons
     float* Fb = F + ((long)blockIdx.y * I + row0) * R;
     const float* ab = a + ((long)blockIdx.y * I + row0) * R;
     const float* bb = bm + (long)blockIdx.y * R * R;
-    for (int e = lane; e < nrows * R; e += 64) {
-        const int row = e / R, r = e - row * R;
-        us[row * RP + r] = Fb[e];
+    // the block's rows are one contiguous run of nrows * R floats: walk it with a running (row, column) pair instead of a
+    // division per element
+    {
+        int row = lane / R, r = lane - row * R;
+        const int drow = 64 / R, dr = 64 - drow * R;
+        for (int e = lane; e < nrows * R; e += 64) {
+            us[row * RP + r] = Fb[e];
+            row += drow;
+            r += dr;
+            if (r >= R) { r -= R; row++; }
+        }
     }
     __syncthreads();
     if (lane < nrows) {
         float* u = us + lane * RP;
+        const float* al = ab + (long)lane * R;
+        float a_next = al[0];
         for (int r = 0; r < R; r++) {
             const float* brow = bb + (long)r * R;
+            const float a_cur = a_next;
+            if (r + 1 < R) a_next = al[r + 1]; // requested a column ahead: the sweep does not wait for it
             const float term2 = any_term2(u, brow, r, R, native != 0);
-            const float num = any_soft_threshold(ab[(long)lane * R + r] - term2, l1) + eps; // CoordinateDescent's eps (qmf.py:90, 117-118)
+            const float num = any_soft_threshold(a_cur - term2, l1) + eps; // CoordinateDescent's eps (qmf.py:90, 117-118)
             const float den = (brow[r] + l2) + eps;
             const float val = rintf(num / den);
             u[r] = fminf(fmaxf(val, lo), hi);
         }
     }
     __syncthreads();
-    for (int e = lane; e < nrows * R; e += 64) {
-        const int row = e / R, r = e - row * R;
-        Fb[e] = us[row * RP + r];
+    {
+        int row = lane / R, r = lane - row * R;
+        const int drow = 64 / R, dr = 64 - drow * R;
+        for (int e = lane; e < nrows * R; e += 64) {
+            Fb[e] = us[row * RP + r];
+            row += drow;
+            r += dr;
+            if (r >= R) { r -= R; row++; }
+        }
     }
 }
 
