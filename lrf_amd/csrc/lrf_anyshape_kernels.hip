@@ -335,68 +335,72 @@ __global__ __launch_bounds__(256) void k_any_fold(const float* __restrict__ P, f
 // eight terms are fetched together (they do not depend on the sum): taken one at a time, every term waited for its LDS read
 // and its uniform load, and the index n -> j = n + (n >= r) cost a dozen scalar instructions per term — the skipped column
 // splits each chain into two plain runs instead.
-template <int STEP>
-__device__ __forceinline__ float any_chain(float acc, const float* u, const float* __restrict__ b, int j, int cnt)
+template <int STEP, typename UT>
+__device__ __forceinline__ float any_chain(float acc, const UT* u, const float* __restrict__ b, int j, int cnt)
 {
     int t = 0;
     for (; t + 8 <= cnt; t += 8) {
         float pq[8];
 #pragma unroll
-        for (int q = 0; q < 8; q++) pq[q] = u[j + STEP * q] * b[j + STEP * q];
+        for (int q = 0; q < 8; q++) pq[q] = (float)u[j + STEP * q] * b[j + STEP * q];
 #pragma unroll
         for (int q = 0; q < 8; q++) acc = acc + pq[q];
         j += 8 * STEP;
     }
     for (; t < cnt; t++) {
-        const float pv = u[j] * b[j];
+        const float pv = (float)u[j] * b[j];
         acc = acc + pv;
         j += STEP;
     }
     return acc;
 }
 
-__device__ __forceinline__ float any_term2(const float* u, const float* __restrict__ b, int r, int R, bool native)
+template <typename UT>
+__device__ __forceinline__ float any_term2(const UT* u, const float* __restrict__ b, int r, int R, bool native)
 {
     const int K = R - 1;
     if (K <= 0) return 0.f;
 #define ANY_J(n) ((n) < r ? (n) : (n) + 1)
     if (native) { // one chain, n ascending: j = 0 .. r - 1, then r + 1 .. R - 1
-        float acc = any_chain<1>(0.f, u, b, 0, r);
-        return any_chain<1>(acc, u, b, r + 1, K - r);
+        float acc = any_chain<1, UT>(0.f, u, b, 0, r);
+        return any_chain<1, UT>(acc, u, b, r + 1, K - r);
     }
     const int j0 = ANY_J(0);
-    if (K == 1) return u[j0] * b[j0];
+    if (K == 1) return (float)u[j0] * b[j0];
     const int j1 = ANY_J(1);
-    float odd = fmaf(u[j1], b[j1], u[j0] * b[j0]);
+    float odd = fmaf((float)u[j1], b[j1], (float)u[j0] * b[j0]);
     if (K < 3) return odd;
     const int j2 = ANY_J(2);
-    float even = u[j2] * b[j2];
+    float even = (float)u[j2] * b[j2];
     // odd n from last_odd down to 3: first the part with n >= r (j = n + 1), then n < r (j = n)
     const int last_odd = ((K - 1) & 1) ? K - 1 : K - 2;
     {
         const int m = r > 3 ? r : 3, n0 = (m & 1) ? m : m + 1;             // smallest odd n >= max(r, 3)
         const int chi = (last_odd >= n0) ? (last_odd - n0) / 2 + 1 : 0;
-        odd = any_chain<-2>(odd, u, b, last_odd + 1, chi);
+        odd = any_chain<-2, UT>(odd, u, b, last_odd + 1, chi);
         int n1 = (r & 1) ? r - 2 : r - 1;                                  // largest odd n < r
         if (n1 > last_odd) n1 = last_odd;
         const int clo = (n1 >= 3) ? (n1 - 3) / 2 + 1 : 0;
-        odd = any_chain<-2>(odd, u, b, n1, clo);
+        odd = any_chain<-2, UT>(odd, u, b, n1, clo);
     }
     // even n from 4 up to K - 1: first n < r (j = n), then n >= r (j = n + 1)
     {
         const int lim = r < K ? r : K;                                     // n < lim
         const int n2 = ((lim - 1) & 1) ? lim - 2 : lim - 1;                // largest even n < lim
         const int clo = (n2 >= 4) ? (n2 - 4) / 2 + 1 : 0;
-        even = any_chain<2>(even, u, b, 4, clo);
+        even = any_chain<2, UT>(even, u, b, 4, clo);
         const int m = r > 4 ? r : 4, n3 = (m & 1) ? m + 1 : m;             // smallest even n >= max(r, 4)
         const int chi = (n3 < K) ? (K - 1 - n3) / 2 + 1 : 0;
-        even = any_chain<2>(even, u, b, n3 + 1, chi);
+        even = any_chain<2, UT>(even, u, b, n3 + 1, chi);
     }
     return odd + even;
 #undef ANY_J
 }
 
 // Gauss-Seidel over the R columns of 64 rows (lane = row); the rows sit in LDS with an odd pitch.
+// UT = float, or int8_t when the factor on entry holds integers of the int8 range (every sweep after the first one of a
+// bounded factorisation): a quarter of the LDS per wave, i.e. four times the waves per CU for a kernel that is a chain of
+// dependent additions per lane (at rank 102: 26 KB per wave, six waves per CU).
 // a [B][I][R], bm [B][R][R] (symmetric), F [B][I][R] updated in place.  grid (ceil(I/64), B), 64 threads,
 // dynamic LDS 64 * (R | 1) floats.
 // l1, l2: the elastic-net terms of CoordinateDescent.update_u (qmf.py:116-118; 0 for qmf_encode): numerator
@@ -409,12 +413,14 @@ __device__ __forceinline__ float any_soft_threshold(float x, float thr)
     return sg * (ax > 0.f ? ax : 0.f);
 }
 
+template <typename UT, bool BLDS>
 __global__ __launch_bounds__(64) void k_any_gs(const float* __restrict__ a, const float* __restrict__ bm, float* __restrict__ F,
                                                int I, int R, int native, float lo, float hi, float l1, float l2, float eps)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* us = reinterpret_cast<float*>(smem);
-    const int RP = R | 1, lane = threadIdx.x;
+    UT* us = reinterpret_cast<UT*>(smem);
+    // row pitch in elements: an odd number of dwords, so that the 64 lanes' reads of one column fall into 64 banks
+    const int RP = (sizeof(UT) == 4) ? (R | 1) : 4 * (((R + 3) >> 2) | 1), lane = threadIdx.x;
     const int row0 = blockIdx.x * 64;
     const int nrows = (I - row0 < 64) ? I - row0 : 64;
     float* Fb = F + ((long)blockIdx.y * I + row0) * R;
@@ -426,26 +432,48 @@ __global__ __launch_bounds__(64) void k_any_gs(const float* __restrict__ a, cons
         int row = lane / R, r = lane - row * R;
         const int drow = 64 / R, dr = 64 - drow * R;
         for (int e = lane; e < nrows * R; e += 64) {
-            us[row * RP + r] = Fb[e];
+            us[row * RP + r] = (UT)Fb[e];
             row += drow;
             r += dr;
             if (r >= R) { r -= R; row++; }
         }
     }
-    __syncthreads();
-    if (lane < nrows) {
-        float* u = us + lane * RP;
-        const float* al = ab + (long)lane * R;
-        float a_next = al[0];
-        for (int r = 0; r < R; r++) {
-            const float* brow = bb + (long)r * R;
-            const float a_cur = a_next;
-            if (r + 1 < R) a_next = al[r + 1]; // requested a column ahead: the sweep does not wait for it
+    // Row r of b goes through LDS (bs), fetched from global memory a column ahead: as uniform (scalar) loads every pair of
+    // terms waited for its own round trip — scalar loads return out of order, so each wait is for all of them (~75 cycles per
+    // term at rank 102); LDS reads return in order and sixteen terms' operands are in flight together.
+    float* bs = reinterpret_cast<float*>(smem + (((size_t)64 * RP * sizeof(UT) + 15) & ~(size_t)15));
+    constexpr int NBR = (LRF_ANY_MAX_RANK + 63) / 64;
+    float bn[NBR];
+    auto fetch_b = [&](int r) __attribute__((always_inline)) {
+        const float* brow = bb + (long)r * R;
+#pragma unroll
+        for (int t = 0; t < NBR; t++)
+            if (64 * t < R) bn[t] = brow[(lane + 64 * t < R) ? lane + 64 * t : R - 1]; // wave-uniform guard
+    };
+    if (BLDS) fetch_b(0);
+    UT* u = us + ((lane < nrows) ? lane : 0) * RP;
+    const float* al = ab + (long)((lane < nrows) ? lane : 0) * R;
+    float a_next = al[0];
+    for (int r = 0; r < R; r++) {
+        const float* brow = bs;
+        if (BLDS) {
+            __syncthreads(); // the reads of the previous column's row are over
+#pragma unroll
+            for (int t = 0; t < NBR; t++)
+                if (64 * t < R && lane + 64 * t < R) bs[lane + 64 * t] = bn[t];
+            __syncthreads();
+            if (r + 1 < R) fetch_b(r + 1);
+        } else { // ranks whose float rows fill the LDS (R > 628): uniform loads from global memory
+            brow = bb + (long)r * R;
+        }
+        const float a_cur = a_next;
+        if (r + 1 < R) a_next = al[r + 1]; // requested a column ahead: the sweep does not wait for it
+        if (lane < nrows) {
             const float term2 = any_term2(u, brow, r, R, native != 0);
             const float num = any_soft_threshold(a_cur - term2, l1) + eps; // CoordinateDescent's eps (qmf.py:90, 117-118)
             const float den = (brow[r] + l2) + eps;
             const float val = rintf(num / den);
-            u[r] = fminf(fmaxf(val, lo), hi);
+            u[r] = (UT)fminf(fmaxf(val, lo), hi);
         }
     }
     __syncthreads();
@@ -453,7 +481,7 @@ __global__ __launch_bounds__(64) void k_any_gs(const float* __restrict__ a, cons
         int row = lane / R, r = lane - row * R;
         const int drow = 64 / R, dr = 64 - drow * R;
         for (int e = lane; e < nrows * R; e += 64) {
-            Fb[e] = us[row * RP + r];
+            Fb[e] = (float)us[row * RP + r];
             row += drow;
             r += dr;
             if (r >= R) { r -= R; row++; }
