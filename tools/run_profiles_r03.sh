@@ -2,7 +2,7 @@
 # Round-3 profile set (GPU box).  usage: bash tools/run_profiles_r03.sh <tag>   (outputs under gpurun_out/<tag>/)
 #   bench lines of the three configs, rocprofv3 kernel stats of the default bench command, two PMC passes for HBM traffic,
 #   two SQ counter passes, kernel stats of the rank sweep (64 images; 256 images timed without the profiler), of the CLIC-sized
-#   and of the svd config, the config-3 R-D table.
+#   and of the svd config, the config-3 R-D table, the any-shape branches (tools/bench_anyshape.py) with their kernel stats.
 # rocprofv3 gets `python3 <script>` directly after `--` (no env / shell hop), counters in passes of their own.
 set -e
 TAG=${1:-r03_a}
@@ -25,7 +25,9 @@ rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats_rank -o run -
 LRF_SWEEP_BATCH=256 python3 $REPO/tools/dev_rank_sweep.py > $OUT/rank_sweep256.txt 2> $OUT/rank_sweep256.err
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats_svd -o run -- python3 $REPO/bench.py --config svd --steps 3 --warmup 1 > /dev/null 2> $OUT/stats_svd.err
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats_clic -o run -- python3 $REPO/bench.py --config clic --steps 3 --warmup 1 --no-extras > /dev/null 2> $OUT/stats_clic.err
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats_any -o run -- python3 $REPO/tools/bench_anyshape.py 256 20 > $OUT/anyshape_profiled.txt 2> $OUT/stats_any.err
 cd $REPO
+python tools/bench_anyshape.py 256 20 > $OUT/anyshape.txt 2> $OUT/anyshape.err
 python tools/make_traffic.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/traffic.json
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
