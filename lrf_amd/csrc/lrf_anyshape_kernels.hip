@@ -894,11 +894,7 @@ __global__ __launch_bounds__(256) void k_any_tridiag_blk(double* __restrict__ G,
             const double* Ar = A + (long)r * n;
 #pragma unroll
             for (int c = 0; c < NCT; c++) {
-#if defined(LRF_BLK_ABL) && LRF_BLK_ABL == 1
-                a[u][c] = (double)(r + ci[c]);
-#else
                 a[u][c] = Ar[ci[c]];
-#endif
             }
         }
     };
@@ -978,12 +974,8 @@ __global__ __launch_bounds__(256) void k_any_tridiag_blk(double* __restrict__ G,
             }
             if (tid == 0) { td[n + k] = alpha; td[2 * n + k] = t; }
             // ---- g_m = W_m . v, h_m = V_m . v: thread partials over its own columns, one tree per wave, four partials in LDS
-#if defined(LRF_BLK_ABL) && LRF_BLK_ABL == 2
-            for (int m = 0; m < 0; m++) {
-#else
 #pragma unroll 4
             for (int m = 0; m < j; m++) {
-#endif
                 double sg = 0.0, sh = 0.0;
 #pragma unroll
                 for (int c = 0; c < NCT; c++) {
@@ -1087,11 +1079,7 @@ __global__ __launch_bounds__(256) void k_any_tridiag_blk(double* __restrict__ G,
 #pragma unroll
                     for (int c = 0; c < NCT; c++) {
                         const int i = tid + 256 * c;
-#if defined(LRF_BLK_ABL) && LRF_BLK_ABL == 6
-                        if (i < n && i >= kend && a[u][c] == 1.2345e301) Ar[i] = a[u][c];
-#else
                         if (i < n && i >= kend) Ar[i] = a[u][c];
-#endif
                     }
                 }
             }
@@ -1100,11 +1088,7 @@ __global__ __launch_bounds__(256) void k_any_tridiag_blk(double* __restrict__ G,
             double a0[UB][NCT], a1[UB][NCT];
             load_rows(kend, a0);
             load_rows(kend + UB, a1);
-#if defined(LRF_BLK_ABL) && LRF_BLK_ABL == 3
-            for (int r0 = kend; r0 < kend + 1; r0 += 2 * UB) {
-#else
             for (int r0 = kend; r0 < n; r0 += 2 * UB) {
-#endif
                 update_rows(r0, a0);
                 if (r0 == kend) {
 #pragma unroll
