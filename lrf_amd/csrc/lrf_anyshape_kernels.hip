@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void k_any_prod_big(const float* __restrict__ 
             Bs[(e >> 6) * LSB + (e & 63)] = rb[t];
         }
         __syncthreads();
-        if (k0 + 32 < kend) fetch(k0 + 32);
+        fetch(k0 + 32 < kend ? k0 + 32 : k0); // unconditional (the last one re-reads its own chunk): exact wait counts
         const int steps = (klen + 3) >> 2; // entries past klen are zeros: fma(0, 0, acc) = acc
         for (int s4 = 0; s4 < steps; s4++) {
             const float* ar = As + (4 * s4 + lq) * LSA + 32 * wave + li;
@@ -462,12 +462,12 @@ __global__ __launch_bounds__(64) void k_any_gs(const float* __restrict__ a, cons
             for (int t = 0; t < NBR; t++)
                 if (64 * t < R && lane + 64 * t < R) bs[lane + 64 * t] = bn[t];
             __syncthreads();
-            if (r + 1 < R) fetch_b(r + 1);
+            fetch_b(r + 1 < R ? r + 1 : r); // unconditional: a guarded prefetch makes the wait counts conservative
         } else { // ranks whose float rows fill the LDS (R > 628): uniform loads from global memory
             brow = bb + (long)r * R;
         }
         const float a_cur = a_next;
-        if (r + 1 < R) a_next = al[r + 1]; // requested a column ahead: the sweep does not wait for it
+        a_next = al[r + 1 < R ? r + 1 : r]; // requested a column ahead (unconditionally): the sweep does not wait for it
         if (lane < nrows) {
             const float term2 = any_term2(u, brow, r, R, native != 0);
             const float num = any_soft_threshold(a_cur - term2, l1) + eps; // CoordinateDescent's eps (qmf.py:90, 117-118)
@@ -1011,9 +1011,9 @@ __global__ __launch_bounds__(256) void k_any_tridiag_blk(double* __restrict__ G,
                 };
                 for (int j0 = k + 1; j0 < n; j0 += 2 * UB) {
                     matvec_rows(j0, a0);
-                    if (j0 + 2 * UB < n) load_rows(j0 + 2 * UB, a0);
+                    load_rows(j0 + 2 * UB, a0); // unconditional (rows clamp): a guarded prefetch makes every wait count conservative
                     matvec_rows(j0 + UB, a1);
-                    if (j0 + 3 * UB < n) load_rows(j0 + 3 * UB, a1);
+                    load_rows(j0 + 3 * UB, a1);
                 }
             }
             BLK_STAMP(3)
@@ -1094,9 +1094,9 @@ __global__ __launch_bounds__(256) void k_any_tridiag_blk(double* __restrict__ G,
 #pragma unroll
                     for (int c = 0; c < NCT; c++) xrow[c] = a0[0][c]; // the updated row kend: the next panel's first row
                 }
-                if (r0 + 2 * UB < n) load_rows(r0 + 2 * UB, a0);
+                load_rows(r0 + 2 * UB, a0);
                 update_rows(r0 + UB, a1);
-                if (r0 + 3 * UB < n) load_rows(r0 + 3 * UB, a1);
+                load_rows(r0 + 3 * UB, a1);
             }
             have_row = true;
         }
@@ -1119,6 +1119,336 @@ __global__ __launch_bounds__(256) void k_any_tridiag_blk(double* __restrict__ G,
     }
 #endif
 #undef BLK_STAMP
+}
+
+// The blocked tridiagonalisation on the LOWER TRIANGLE only, 192 < n <= 512 (round 3; oracle: any_tridiag_sym).
+// k_any_tridiag_blk's product pass reads the whole trailing square of a symmetric matrix: at n = 512 that pass runs at the
+// HBM rate, at n = 256 at what a CU draws from the Infinity Cache.  Here an element A0[r][i], r >= i, is loaded once and
+// used twice: for the column part cc[i] += A0[r][i] v[r] and for the row part y[r] += A0[r][i] v[i].  Work is dealt by ROWS:
+// sub-tile r0 (sixteen rows) belongs to wave (r0 / 16) % 4, which walks the 64-column chunks J <= r0 / 64 of it; lane =
+// column.  A body (r0, J): sixteen row loads (the next body's are in flight), the column part as a 16-fma chain added to the
+// wave's partial Cp[wave][column] (LDS), the sixteen products a v[column] through a wave-private LDS tile to lane = (row,
+// quarter): four 16-term sums per row, combined ((q0 + q1) + q2) + q3 into Yrow[J][row] — one writer per (J, row).  The
+// owner thread of column i then takes ((Cp0 + Cp1) + Cp2) + Cp3 plus the chunks' row values in order.  Row k of the current
+// matrix is column k of the triangle: the lane that owns column k + 1 leaves what it loaded in Lx for the next step.  The
+// panel update touches the triangle only; the upper triangle keeps the reflectors (row k: v_k).  Everything else — panel
+// algebra, reductions, outputs — as k_any_tridiag_blk.  NB = 16 / NCT.  LDS at n = 512: 155 KB (one workgroup per CU).
+#define LRF_WAVE_SYNC()                                     \
+    do {                                                    \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                    \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+template <int NCT>
+__global__ __launch_bounds__(256) void k_any_tridiag_sym(double* __restrict__ G, int n, double* __restrict__ TD)
+{
+    constexpr int NB = 16 / NCT, NCH = 4 * NCT, TP = 65;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ns = ((n + 1) & ~1) + 16; // row stride of the LDS vectors: sixteen zeros behind every panel row (row reads run past n)
+    const int nch = (n + 63) >> 6;
+    double* Vp = reinterpret_cast<double*>(smem); // [NB][ns]
+    double* Wp = Vp + (size_t)NB * ns;            // [NB][ns]
+    double* Lx = Wp + (size_t)NB * ns;            // [ns]: column k of the triangle for the coming step
+    double* Yrow = Lx + ns;                       // [NCH][ns]
+    double* Cp = Yrow + (size_t)NCH * ns;         // [4][ns]
+    double* Lt = Cp + (size_t)4 * ns;             // [4][16 TP]
+    double* Lq = Lt + 4 * 16 * TP;                // [4][64]
+    double* Lgh = Lq + 256;                       // [4][2 NB]
+    double* Lpart = Lgh + 8 * NB;                 // [16]
+    double* Lscal = Lpart + 16;                   // [8]
+    double* A = G + (long)blockIdx.x * n * n;
+    double* td = TD + (long)blockIdx.x * 3 * n;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double* Ltw = Lt + wave * 16 * TP;
+    double* Lqw = Lq + wave * 64;
+    double* Cpw = Cp + (size_t)wave * ns;
+    auto bsum = [&](double v, int slot) __attribute__((always_inline)) {
+        v = wave_tree64(v);
+        if (lane == 0) Lpart[4 * slot + wave] = v;
+        __syncthreads();
+        return ((Lpart[4 * slot] + Lpart[4 * slot + 1]) + Lpart[4 * slot + 2]) + Lpart[4 * slot + 3];
+    };
+    // body (r0, J): rows r0 .. r0 + 15 (clamped), column 64 J + lane (clamped): unconditional loads
+    auto load_body = [&](int r0, int J, double (&a)[16]) __attribute__((always_inline)) {
+        const int col = 64 * J + lane, colc = col < n ? col : n - 1;
+        if (r0 + 16 <= n) { // wave-uniform: no row clamps
+            const double* p0 = A + (long)r0 * n + colc;
+#pragma unroll
+            for (int u = 0; u < 16; u++) a[u] = p0[(long)u * n];
+        } else {
+            const int rb = (r0 < n) ? r0 : n - 1;
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const int r = (rb + u < n) ? rb + u : n - 1;
+                a[u] = A[(long)r * n + colc];
+            }
+        }
+    };
+    // the wave's bodies from sub-tile row rbeg0 (a multiple of 16) on, chunks Jlo .. r0 / 64: (r0, J) -> next; r0 >= n: done
+    auto advance = [&](int& r0, int& J, int Jlo) __attribute__((always_inline)) {
+        if (J < (r0 >> 6)) J++;
+        else { r0 += 64; J = Jlo; }
+    };
+    // the wave's bodies in order, the loads of the next two in flight (one workgroup of four waves per CU: what hides the
+    // memory latency is what a wave itself has outstanding — 16 KB per wave here)
+    auto pipeline = [&](int rbeg, int Jlo, auto&& fn) __attribute__((always_inline)) {
+        int rA = rbeg + 16 * ((wave - (rbeg >> 4)) & 3), JA = Jlo;
+        if (!(rA < n)) return;
+        // every prefetch is issued whether or not its body exists (a body past the end re-reads clamped rows): with a load
+        // under a branch the compiler must assume it was not issued and waits for younger loads than the one it needs
+        double b0[16], b1[16], b2[16];
+        int rB = rA, JB = JA;
+        advance(rB, JB, Jlo);
+        load_body(rA, JA, b0);
+        load_body(rB, JB, b1);
+        for (;;) {
+            int rC = rB, JC = JB;
+            advance(rC, JC, Jlo);
+            load_body(rC, JC, b2);
+            fn(rA, JA, b0);
+            if (!(rB < n)) break;
+            int rD = rC, JD = JC;
+            advance(rD, JD, Jlo);
+            load_body(rD, JD, b0);
+            fn(rB, JB, b1);
+            if (!(rC < n)) break;
+            int rE = rD, JE = JD;
+            advance(rE, JE, Jlo);
+            load_body(rE, JE, b1);
+            fn(rC, JC, b2);
+            if (!(rD < n)) break;
+            rA = rD; JA = JD; rB = rE; JB = JE;
+        }
+    };
+#ifdef LRF_BLK_STAMPS
+    unsigned long long st[6] = {0, 0, 0, 0, 0, 0}, tq = __builtin_amdgcn_s_memtime(), tq0 = tq;
+#define SYM_STAMP(i) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); st[i] += tn_ - tq; tq = tn_; }
+#else
+#define SYM_STAMP(i)
+#endif
+    for (int e = tid; e < 2 * NB * ns; e += 256) Vp[e] = 0.0; // Vp and Wp: the padding stays zero
+    __syncthreads();
+    bool have_x = false;
+    for (int k0 = 0; k0 < n - 2; k0 += NB) {
+        const int np = (n - 2 - k0 < NB) ? n - 2 - k0 : NB;
+        for (int j = 0; j < np; j++) {
+            const int k = k0 + j;
+            // ---- row k of the current matrix: column k of the triangle and the panel so far
+            double x[NCT];
+#pragma unroll
+            for (int c = 0; c < NCT; c++) {
+                const int i = tid + 256 * c;
+                if (have_x) x[c] = (i < n && i >= k) ? Lx[i] : 0.0;
+                else x[c] = (i < n && i >= k) ? A[(long)i * n + k] : 0.0;
+            }
+#pragma unroll 4
+            for (int m = 0; m < j; m++) {
+                const double vk = Vp[(size_t)m * ns + k], wk = Wp[(size_t)m * ns + k];
+#pragma unroll
+                for (int c = 0; c < NCT; c++) {
+                    const int i = tid + 256 * c;
+                    if (i < n && i >= k) {
+                        x[c] = fma(-vk, Wp[(size_t)m * ns + i], x[c]);
+                        x[c] = fma(-wk, Vp[(size_t)m * ns + i], x[c]);
+                    }
+                }
+            }
+            double s = 0.0;
+#pragma unroll
+            for (int c = 0; c < NCT; c++) {
+                const int i = tid + 256 * c;
+                if (i == k) { td[k] = x[c]; x[c] = 0.0; }
+                if (i == k + 1) Lscal[0] = x[c];
+                s = fma(x[c], x[c], s);
+            }
+            const double sigma = bsum(s, 0); // its barrier publishes Lscal[0]
+            if (!(sigma > LRF_SIGMA_TINY)) { // the same in every thread
+                if (tid == 0) { td[n + k] = 0.0; td[2 * n + k] = 0.0; }
+#pragma unroll
+                for (int c = 0; c < NCT; c++) {
+                    const int i = tid + 256 * c;
+                    if (i < n) { Vp[(size_t)j * ns + i] = 0.0; Wp[(size_t)j * ns + i] = 0.0; }
+                }
+                have_x = false; // no pass ran: the next step reads its column from memory
+                __syncthreads();
+                continue;
+            }
+            SYM_STAMP(1)
+            const double x0 = Lscal[0];
+            const double nrm = sqrt(sigma);
+            const double alpha = (x0 >= 0.0) ? -nrm : nrm;
+            const double t = 1.0 / fma(fabs(x0), nrm, sigma);
+            double v[NCT];
+#pragma unroll
+            for (int c = 0; c < NCT; c++) {
+                const int i = tid + 256 * c;
+                v[c] = (i == k + 1) ? x0 - alpha : x[c];
+                if (i < n) {
+                    Vp[(size_t)j * ns + i] = v[c];
+                    if (i > k) A[(long)k * n + i] = v[c]; // upper triangle: the reflector, for the back-transformation
+                }
+            }
+            if (tid == 0) { td[n + k] = alpha; td[2 * n + k] = t; }
+#pragma unroll 4
+            for (int m = 0; m < j; m++) {
+                double sg = 0.0, sh = 0.0;
+#pragma unroll
+                for (int c = 0; c < NCT; c++) {
+                    const int i = tid + 256 * c;
+                    if (i < n) {
+                        sg = fma(Wp[(size_t)m * ns + i], v[c], sg);
+                        sh = fma(Vp[(size_t)m * ns + i], v[c], sh);
+                    }
+                }
+                sg = wave_tree64(sg);
+                sh = wave_tree64(sh);
+                if (lane == 0) { Lgh[wave * 2 * NB + 2 * m] = sg; Lgh[wave * 2 * NB + 2 * m + 1] = sh; }
+            }
+            for (int J = 0; J < nch; J++) Cpw[64 * J + lane < n ? 64 * J + lane : n - 1] = 0.0; // (the clamped lanes rewrite n - 1 with 0)
+            __syncthreads(); // V_j, the partials and the cleared column sums are visible
+            SYM_STAMP(2)
+            // ---- the product pass over the triangle
+            {
+                const double* Lv = Vp + (size_t)j * ns;
+                const int rbeg = (k + 1) & ~15, Jmin = (k + 1) >> 6;
+                auto body = [&](int r0, int J, double (&a)[16]) __attribute__((always_inline)) {
+                    const int col = 64 * J + lane;
+                    const bool diag = (J == (r0 >> 6)); // wave-uniform
+                    const double vim = (col < n && col > k) ? Lv[col < n ? col : n - 1] : 0.0;
+                    double lv[16];
+#pragma unroll
+                    for (int u = 0; u < 16; u++) lv[u] = Lv[r0 + u];
+                    double cl = 0.0, pr[16];
+                    if (diag) { // (v reads as zero past n: the padding of the panel rows)
+#pragma unroll
+                        for (int u = 0; u < 16; u++) {
+                            const double av = (r0 + u >= col) ? a[u] : 0.0;
+                            cl = fma(av, lv[u], cl);
+                            pr[u] = (col < r0 + u) ? a[u] * vim : 0.0;
+                        }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 16; u++) {
+                            cl = fma(a[u], lv[u], cl);
+                            pr[u] = a[u] * vim;
+                        }
+                    }
+                    if (col < n) Cpw[col] = Cpw[col] + cl;
+                    if (J == Jmin && col == k + 1) { // wave-uniform first test; one lane: column k + 1 of the triangle for the next step
+#pragma unroll
+                        for (int u = 0; u < 16; u++)
+                            if (r0 + u < n) Lx[r0 + u] = a[u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 16; u++) Ltw[u * TP + lane] = pr[u];
+                    LRF_WAVE_SYNC();
+                    const int ur = lane & 15, q = lane >> 4;
+                    double sq = 0.0;
+#pragma unroll
+                    for (int m = 0; m < 16; m++) sq = sq + Ltw[ur * TP + 16 * q + m];
+                    Lqw[16 * q + ur] = sq;
+                    LRF_WAVE_SYNC();
+                    if (lane < 16 && r0 + lane < n) Yrow[(size_t)J * ns + r0 + lane] = ((Lqw[lane] + Lqw[16 + lane]) + Lqw[32 + lane]) + Lqw[48 + lane];
+                    LRF_WAVE_SYNC();
+                };
+                pipeline(rbeg, Jmin, body);
+            }
+            have_x = true;
+            __syncthreads(); // Cp, Yrow, Lx complete
+            SYM_STAMP(3)
+            double cc[NCT];
+            {
+                const int Jmin = (k + 1) >> 6;
+#pragma unroll
+                for (int c = 0; c < NCT; c++) {
+                    const int i = tid + 256 * c;
+                    double cv = 0.0;
+                    if (i < n && i > k) {
+                        cv = ((Cp[i] + Cp[ns + i]) + Cp[2 * ns + i]) + Cp[3 * (size_t)ns + i];
+                        double yr = 0.0;
+                        for (int J = Jmin; J <= (i >> 6); J++) yr = yr + Yrow[(size_t)J * ns + i];
+                        cv = cv + yr;
+                    }
+                    cc[c] = cv;
+                }
+            }
+#pragma unroll 4
+            for (int m = 0; m < j; m++) {
+                const double gm = ((Lgh[2 * m] + Lgh[2 * NB + 2 * m]) + Lgh[4 * NB + 2 * m]) + Lgh[6 * NB + 2 * m];
+                const double hm = ((Lgh[2 * m + 1] + Lgh[2 * NB + 2 * m + 1]) + Lgh[4 * NB + 2 * m + 1]) + Lgh[6 * NB + 2 * m + 1];
+#pragma unroll
+                for (int c = 0; c < NCT; c++) {
+                    const int i = tid + 256 * c;
+                    if (i < n && i > k) {
+                        cc[c] = fma(-Vp[(size_t)m * ns + i], gm, cc[c]);
+                        cc[c] = fma(-Wp[(size_t)m * ns + i], hm, cc[c]);
+                    }
+                }
+            }
+            s = 0.0;
+#pragma unroll
+            for (int c = 0; c < NCT; c++) {
+                cc[c] = t * cc[c];
+                s = fma(cc[c], v[c], s);
+            }
+            const double Kc = (0.5 * t) * bsum(s, 1);
+#pragma unroll
+            for (int c = 0; c < NCT; c++) {
+                const int i = tid + 256 * c;
+                if (i < n) Wp[(size_t)j * ns + i] = fma(-Kc, v[c], cc[c]);
+            }
+            __syncthreads();
+        }
+        SYM_STAMP(4)
+        // ---- the panel's rank-2 np update of the triangle (rows >= columns >= kend), dealt by rows as the product pass
+        const int kend = k0 + np;
+        {
+            const int rbeg = kend & ~15, Jlo = kend >> 6;
+            auto ubody = [&](int r0, int J, double (&a)[16]) __attribute__((always_inline)) {
+                const int col = 64 * J + lane, colc = col < n ? col : n - 1;
+#pragma unroll
+                for (int m = 0; m < NB; m++) {
+                    if (m < np) {
+                        double vr[16], wr[16];
+#pragma unroll
+                        for (int u = 0; u < 16; u++) { vr[u] = Vp[(size_t)m * ns + r0 + u]; wr[u] = Wp[(size_t)m * ns + r0 + u]; }
+                        const double vic = Vp[(size_t)m * ns + colc], wic = Wp[(size_t)m * ns + colc];
+#pragma unroll
+                        for (int u = 0; u < 16; u++) a[u] = fma(-wr[u], vic, fma(-vr[u], wic, a[u]));
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    const int r = r0 + u;
+                    if (r < n && r >= kend && col < n && col >= kend && r >= col) {
+                        A[(long)r * n + col] = a[u];
+                        if (col == kend) Lx[r] = a[u]; // column kend of the updated triangle: the next panel's first row
+                    }
+                }
+            };
+            pipeline(rbeg, Jlo, ubody);
+            have_x = true;
+        }
+        __syncthreads(); // the panel buffers are rewritten by the next panel; the updated triangle and Lx are visible
+        SYM_STAMP(5)
+    }
+    // d[n-2], d[n-1], e[n-2] from the updated triangle
+#pragma unroll
+    for (int c = 0; c < NCT; c++) {
+        const int i = tid + 256 * c;
+        if (i == n - 2) { td[n - 2] = A[(long)(n - 2) * n + i]; td[n + n - 2] = A[(long)(n - 1) * n + i]; }
+        if (i == n - 1) td[n - 1] = A[(long)(n - 1) * n + i];
+    }
+    if (tid == 0) { td[n + n - 1] = 0.0; td[2 * n + n - 2] = 0.0; td[2 * n + n - 1] = 0.0; }
+#ifdef LRF_BLK_STAMPS
+    if (tid == 0 && blockIdx.x < 16384) {
+        unsigned long long* o = g_stamps + 8 * blockIdx.x;
+        o[0] = __builtin_amdgcn_s_memtime() - tq0;
+        for (int q = 1; q < 6; q++) o[q] = st[q];
+    }
+#endif
+#undef SYM_STAMP
 }
 
 // One workgroup per matrix; thread t owns the columns t, t + 256, ... (NC = ceil(n/256) <= NCT of them).

@@ -453,6 +453,154 @@ static void any_tridiag_blocked(double* A, int n, int NCT, int NB, double* d, do
     free(Vp); free(Wp); free(x); free(v); free(p);
 }
 
+/* ---- k_any_tridiag_sym<NCT> (192 < n <= 512): the blocked algorithm above on the LOWER TRIANGLE only.  A symmetric matrix
+ * read in full moves every element twice per product; here an element A0[r][i] (r >= i) is read once and used twice — for
+ * the column part cc[i] += A0[r][i] v[r] (chains over sub-tiles of sixteen rows, dealt to the four waves, below) and for
+ * the row part of row r, the sum over the columns i < r of A0[r][i] v[i]: per 64-column chunk J four quarter sums (sixteen
+ * products each, added in column order to 0.0), ((q0 + q1) + q2) + q3, and the chunks' values added in chunk order.
+ * p = cc + rowpart, then dlatrd's corrections as in any_tridiag_blocked.  Row k of the current matrix is column k of the
+ * lower triangle.  The panel update touches the lower triangle only; the upper triangle keeps the reflectors. */
+static void any_tridiag_sym(double* A, int n, int NCT, int NB, double* d, double* e, double* tau)
+{
+    double tv[256], tg[256], th[256], g[16], h[16];
+    double *Vp = (double*)calloc((size_t)NB * n, sizeof(double)), *Wp = (double*)calloc((size_t)NB * n, sizeof(double)),
+           *x = (double*)malloc(sizeof(double) * n), *v = (double*)malloc(sizeof(double) * n), *p = (double*)malloc(sizeof(double) * n);
+    for (int i = 0; i < n; i++) { d[i] = 0.0; e[i] = 0.0; tau[i] = 0.0; }
+    for (int k0 = 0; k0 < n - 2; k0 += NB) {
+        const int np = (n - 2 - k0 < NB) ? n - 2 - k0 : NB;
+        for (int j = 0; j < np; j++) {
+            const int k = k0 + j;
+            for (int i = 0; i < n; i++) { /* row k of the current matrix = column k of the lower triangle */
+                double xx = 0.0;
+                if (i >= k) {
+                    xx = A[(long)i * n + k];
+                    for (int m = 0; m < j; m++) {
+                        xx = fma(-Vp[(long)m * n + k], Wp[(long)m * n + i], xx);
+                        xx = fma(-Wp[(long)m * n + k], Vp[(long)m * n + i], xx);
+                    }
+                }
+                x[i] = xx;
+            }
+            d[k] = x[k];
+            x[k] = 0.0;
+            for (int tt = 0; tt < 256; tt++) {
+                double s = 0.0;
+                for (int c = 0; c < NCT; c++) {
+                    const int i = tt + 256 * c;
+                    if (i < n) s = fma(x[i], x[i], s);
+                }
+                tv[tt] = s;
+            }
+            const double sigma = block_sum256(tv);
+            if (!(sigma > LRF_SIGMA_TINY)) {
+                tau[k] = 0.0;
+                e[k] = 0.0;
+                for (int i = 0; i < n; i++) { Vp[(long)j * n + i] = 0.0; Wp[(long)j * n + i] = 0.0; }
+                continue;
+            }
+            const double x0 = x[k + 1];
+            const double nrm = sqrt(sigma);
+            const double alpha = (x0 >= 0.0) ? -nrm : nrm;
+            const double t = 1.0 / fma(fabs(x0), nrm, sigma);
+            for (int i = 0; i < n; i++) {
+                v[i] = (i == k + 1) ? x0 - alpha : x[i];
+                Vp[(long)j * n + i] = v[i];
+                if (i > k) A[(long)k * n + i] = v[i]; /* upper triangle: the reflector for the back-transformation */
+            }
+            tau[k] = t;
+            e[k] = alpha;
+            for (int m = 0; m < j; m++) {
+                for (int tt = 0; tt < 256; tt++) {
+                    double sg = 0.0, sh = 0.0;
+                    for (int c = 0; c < NCT; c++) {
+                        const int i = tt + 256 * c;
+                        if (i < n) {
+                            sg = fma(Wp[(long)m * n + i], v[i], sg);
+                            sh = fma(Vp[(long)m * n + i], v[i], sh);
+                        }
+                    }
+                    tg[tt] = sg;
+                    th[tt] = sh;
+                }
+                g[m] = block_sum256(tg);
+                h[m] = block_sum256(th);
+            }
+            const int Jmin = (k + 1) / 64;
+            for (int i = 0; i < n; i++) {
+                double c = 0.0;
+                if (i > k) {
+                    /* column part: rows r >= i (the diagonal included).  The rows are dealt to the four waves in sub-tiles of
+                     * sixteen (sub-tile r0 / 16 to wave (r0 / 16) % 4, from the sub-tile that holds row k + 1, inside the chunks
+                     * at or below the diagonal one): per sub-tile a chain from 0.0, a wave's sub-tiles added in order, then
+                     * ((w0 + w1) + w2) + w3 */
+                    double sw[4] = {0.0, 0.0, 0.0, 0.0};
+                    const int rbeg = (k + 1) & ~15, rdiag = 64 * (i / 64);
+                    for (int r0 = (rbeg > rdiag ? rbeg : rdiag); r0 < n; r0 += 16) {
+                        double cl = 0.0;
+                        for (int u = 0; u < 16; u++) {
+                            const int r = r0 + u;
+                            const double av = (r < n && r >= i) ? A[(long)r * n + i] : 0.0, vj = (r < n) ? v[r] : 0.0;
+                            cl = fma(av, vj, cl);
+                        }
+                        sw[(r0 >> 4) & 3] = sw[(r0 >> 4) & 3] + cl;
+                    }
+                    c = ((sw[0] + sw[1]) + sw[2]) + sw[3];
+                    /* row part of row i: chunks Jmin .. i / 64 */
+                    double yr = 0.0;
+                    for (int J = Jmin; J <= i / 64; J++) {
+                        double q[4];
+                        for (int qq = 0; qq < 4; qq++) {
+                            double sq = 0.0;
+                            for (int m = 0; m < 16; m++) {
+                                const int cc_ = 64 * J + 16 * qq + m;
+                                const double pr = (cc_ < i && cc_ > k && cc_ < n) ? A[(long)i * n + cc_] * v[cc_] : 0.0;
+                                sq = sq + pr;
+                            }
+                            q[qq] = sq;
+                        }
+                        yr = yr + (((q[0] + q[1]) + q[2]) + q[3]);
+                    }
+                    c = c + yr;
+                    for (int m = 0; m < j; m++) {
+                        c = fma(-Vp[(long)m * n + i], g[m], c);
+                        c = fma(-Wp[(long)m * n + i], h[m], c);
+                    }
+                }
+                p[i] = c;
+            }
+            for (int tt = 0; tt < 256; tt++) {
+                double s = 0.0;
+                for (int c = 0; c < NCT; c++) {
+                    const int i = tt + 256 * c;
+                    if (i < n) {
+                        p[i] = t * p[i];
+                        s = fma(p[i], v[i], s);
+                    }
+                }
+                tv[tt] = s;
+            }
+            const double Kc = (0.5 * t) * block_sum256(tv);
+            for (int i = 0; i < n; i++) Wp[(long)j * n + i] = fma(-Kc, v[i], p[i]);
+        }
+        const int kend = k0 + np;
+        for (int r = kend; r < n; r++)
+            for (int i = kend; i <= r; i++) { /* lower triangle only */
+                double a = A[(long)r * n + i];
+                for (int m = 0; m < np; m++) {
+                    a = fma(-Vp[(long)m * n + r], Wp[(long)m * n + i], a);
+                    a = fma(-Wp[(long)m * n + r], Vp[(long)m * n + i], a);
+                }
+                A[(long)r * n + i] = a;
+            }
+    }
+    if (n >= 2) {
+        d[n - 2] = A[(long)(n - 2) * n + n - 2];
+        e[n - 2] = A[(long)(n - 1) * n + n - 2];
+    }
+    d[n - 1] = A[(long)(n - 1) * n + n - 1];
+    free(Vp); free(Wp); free(x); free(v); free(p);
+}
+
 /* Sturm count of k_any_eig / k_init for a side n (sturm_count above is the n = 64 case): de[j] = (d'_j, e'_{j-1}^2) */
 static int any_sturm_count(const double* ds, const double* e2s, int n, double x)
 {
@@ -492,7 +640,9 @@ int lrf_oracle_any_eig(double* G, int n, int R, int rcap, const int8_t* sign, fl
     if (n > 64 && n <= 192) any_tridiag_reg(G, n, n <= 128 ? 2 : 3, d, e, tau);
     else if (n <= 64) any_tridiag_plain(G, n, d, e, tau);
     else if (tdv && tdv[0] == 'u') { if (NCT == 1) any_tridiag_plain(G, n, d, e, tau); else any_tridiag_fused(G, n, NCT, d, e, tau); }
-    else any_tridiag_blocked(G, n, NCT, NCT == 1 ? 16 : 32 / NCT, d, e, tau);
+    else if (tdv && tdv[0] == 'b') any_tridiag_blocked(G, n, NCT, NCT == 1 ? 16 : 32 / NCT, d, e, tau); /* round 3's first blocked form */
+    else if (n <= 512) any_tridiag_sym(G, n, NCT, 16 / NCT, d, e, tau);
+    else any_tridiag_blocked(G, n, NCT, 32 / NCT, d, e, tau);
     /* Gershgorin hull, pivmin (min / max: order-free) */
     double lo = 1e300, hi = -1e300, e2m = 0.0;
     for (int i = 0; i < n; i++) {
