@@ -13,11 +13,12 @@
  *   block_sum256(s) four wave trees, then ((p0 + p1) + p2) + p3
  *   "thread t owns columns t, t + 256, ..." partial sums, "lane l owns i = l, l + 64, ..." partial sums
  * Tridiagonalisations, chosen by the side n = min(M, N) exactly as lrf_anyshape_host.inc does:
- *   n <= 64                     k_any_eig<1>, plain three-pass Householder step        (any_tridiag_plain)
- *   64 < n <= 192               k_any_tridiag_reg<2 or 3>, matrix in registers          (any_tridiag_reg)
- *   n > 192                     k_any_tridiag_blk<1|2|4|8>, panels of 16/16/8/4 steps   (any_tridiag_blocked)
- * (any_tridiag_fused, and any_tridiag_plain above n = 192, are the round-2 variants the library keeps behind
- *  LRF_ANY_TRIDIAG_UNBLOCKED=1; here LRF_ORACLE_ANY_TRIDIAG=unblocked selects them.)
+ *   n <= 64                     k_any_eig<1>, plain three-pass Householder step              (any_tridiag_plain)
+ *   64 < n <= 192               k_any_tridiag_reg<2 or 3>, matrix in registers                (any_tridiag_reg)
+ *   192 < n <= 512              k_any_tridiag_sym<1|2>, panels of 16 / 8 steps, lower triangle (any_tridiag_sym)
+ *   n > 512                     k_any_tridiag_blk<4|8>, panels of 8 / 4 steps, full square     (any_tridiag_blocked)
+ * (LRF_ORACLE_ANY_TRIDIAG=blocked: the full-square panels also for 193..512 — the library's LRF_ANY_TRIDIAG_SQUARE=1;
+ *  =unblocked: round 2's any_tridiag_plain / any_tridiag_fused above 192 — the library's LRF_ANY_TRIDIAG_UNBLOCKED=1.)
  */
 
 static double tree64c(const double* v)
