@@ -820,7 +820,9 @@ int lrf_oracle_any_eig(double* G, int n, int R, int rcap, const int8_t* sign, fl
                 lanes[l] = ds_;
             }
             const double scl = tk * tree64c(lanes);
-            for (int i = k + 1; i < n; i++) x[i] = fma(-scl, vrow[i], x[i]);
+            /* every entry, with v = 0 up to k, as the kernel's lanes do: fma(-scl, 0, x) turns an entry -0.0 into +0.0 when
+             * scl < 0 (exact zeros occur in the unit-vector fallbacks of rank-deficient matrices) */
+            for (int i = 0; i < n; i++) x[i] = fma(-scl, (i > k) ? vrow[i] : 0.0, x[i]);
         }
         for (int l = 0; l < 64; l++) {
             double ds_ = 0.0;

@@ -285,6 +285,21 @@ def test_hip_init_matches_oracle_init(M, N, R, oracle):
 
 
 @pytest.mark.gpu
+def test_hip_init_of_constant_matrices_equals_oracle(oracle):
+    """Rank one with ranks far beyond it: every vector after the first comes from the unit-vector fallback, whose exact zeros
+    keep or lose a minus sign in the back-transformation (fma(-s, 0, -0.0)); found by tools/dev_fuzz_anyshape.py in round 3,
+    when the oracle skipped the entries up to k that the kernel's lanes multiply by zero.  Bit for bit, signs of zeros included."""
+    from lrf_amd import _lib
+    ctx = _lib.context()
+    for (M, N, R) in ((47, 29, 28), (29, 311, 21), (308, 325, 25), (474, 396, 120)):
+        X = np.full((M, N), 7, np.float32)
+        u0, v0 = ctx.svd_init(torch.from_numpy(X[None]).cuda(), R)
+        uo, vo = oracle.svd_topr_any(X, R)
+        assert np.array_equal(u0[0].cpu().numpy().view(np.int32), uo.view(np.int32)), (M, N, R)
+        assert np.array_equal(v0[0].cpu().numpy().view(np.int32), vo.view(np.int32)), (M, N, R)
+
+
+@pytest.mark.gpu
 def test_hip_init_of_rank_deficient_matrices_equals_oracle(oracle):
     """Matrices of rank a third of their side, ranks asked beyond it, with sign vectors: the eigenvalues of the null space
     form clusters (repeated ones included), where the vectors come from the Gram-Schmidt fallbacks.  Bit for bit — this is the

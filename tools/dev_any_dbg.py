@@ -12,9 +12,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     from oracle import oracle
     oracle.build()
     ctx = _lib.context(0)
-    rng = np.random.default_rng(seed)
+    rng = np.random.default_rng(abs(seed))
     k = max(1, min(M, N) // 3)
     X = (rng.integers(0, 16, (M, k)) @ rng.integers(0, 16, (k, N))).astype(np.float32)
+    if seed < 0: X = np.full((M, N), 7, np.float32)  # constant matrix
     n = min(M, N); Rc = min(R, n)
     u, v = ctx.svd_init(torch.from_numpy(X[None]).cuda(), R)
     raw = (v if N <= M else u)[0].cpu().numpy().tobytes()
