@@ -152,3 +152,21 @@ def test_encode_out_buffers_are_validated():
         ctx.decode_rgb(U[:, :-1].contiguous(), V, 32, 48, [7, 3, 3])
     with pytest.raises(ValueError):
         ctx.decode_rgb(U, V, 32, 48, [8, 3, 3])
+
+
+@pytest.mark.parametrize("ranks", [[16, 8, 8], [20, 10, 10]])
+def test_pipelined_mixed_rank_families(ranks):
+    """Pieces large enough (130 images of 512x768 = 3120 blocks) for the per-family launch plan and the family streams inside
+    a slot: the slot's kernel stream forks into the families' streams and joins before the download.  Bytes as the one-shot
+    encoder's, which itself equals the single-family run (tests/test_configs_at_size.py)."""
+    import lrf_amd
+    from lrf_amd import _lib
+    imgs = _images(260, 512, 768, 5).pin_memory()
+    U0, V0 = lrf_amd.qmf_factorize_batch(imgs.cuda(), ranks, num_iters=3)
+    pipe = _lib.Pipe(0, slots=2, sub_batch=130)
+    try:
+        for _ in range(2):
+            U, V = pipe.encode_rgb_host(imgs, ranks, 3, -16, 15)
+            assert torch.equal(U, U0.cpu()) and torch.equal(V, V0.cpu())
+    finally:
+        pipe.close()
