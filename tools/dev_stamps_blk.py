@@ -1,4 +1,5 @@
-"""Phase times of k_any_tridiag_blk from s_memtime stamps (a library built with -DLRF_BLK_STAMPS; development aid).
+"""Phase shares of k_any_tridiag_blk / k_any_tridiag_sym (whichever the side selects) from s_memtime stamps of thread 0 — a
+library built with -DLRF_BLK_STAMPS; development aid.  The tick unit of s_memtime is not assumed: read the SHARES.
 python tools/dev_stamps_blk.py B M N R"""
 import ctypes, os, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
@@ -16,7 +17,7 @@ lib.lrf_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c
 assert lib.lrf_debug_read_stamps(ctx._h, buf.ctypes.data_as(ctypes.c_void_p), B * 8) == 0
 n = min(M, N)
 tot = buf[:, 0].astype(np.float64)
-print(f"B,M,N,R={(B, M, N, R)}: k_any_tridiag_blk {np.median(tot) / 100:.0f} us per matrix (median; 100 MHz ticks), per step {np.median(tot) / 100 / (n - 2):.2f} us")
-for i, name in enumerate(("row k + corrections + sigma", "reflector, g / h trees, barrier", "product pass A0 v", "corrections, K, w", "panel update")):
+print(f"B,M,N,R={(B, M, N, R)}: tridiagonalisation {np.median(tot):.0f} ticks per matrix (median), {np.median(tot) / (n - 2):.0f} per step")
+for i, name in enumerate(("row k + corrections + sigma (+ the previous step's K, w)", "reflector, g / h trees, barrier", "product pass A0 v", "corrections, K, w of a panel's last step", "panel update")):
     v = buf[:, 1 + i].astype(np.float64)
-    print(f"  {name:36s} {np.median(v) / 100:9.1f} us  share {100 * np.median(v / tot):5.1f} %")
+    print(f"  {name:58s} share {100 * np.median(v / tot):5.1f} %")
