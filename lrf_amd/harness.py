@@ -51,3 +51,38 @@ def rd_sweep(images, qualities, encoder: Callable, decoder: Callable, **kwargs) 
             rec.update({"image": idx, "quality": float(q)})
             records.append(rec)
     return records
+
+
+def rd_sweep_batched(images, qualities, **kwargs) -> list:
+    """The same sweep for `qmf_encode` / `qmf_decode` with all images of one size in ONE call per quality
+    (`qmf_encode_batch` / `qmf_decode_batch`): images are independent, so every stream — hence bpp, PSNR, SSIM — is the one the
+    per-image loop of `rd_sweep` produces (tests/test_harness_gpu.py); the times are the batch's, divided by the images.
+    images: a uint8 tensor [B,3,H,W] or a sequence of [3,H,W] tensors of one size.  kwargs: qmf_encode's (bounds, num_iters,
+    patch, patch_size ...) except quality / rank."""
+    from .codec import qmf_decode_batch, qmf_encode_batch
+    stack = images if isinstance(images, torch.Tensor) and images.dim() == 4 else torch.stack(list(images))
+    B = stack.shape[0]
+    records = []
+    for q in qualities:
+        _sync()
+        t0 = time.perf_counter()
+        streams = qmf_encode_batch(stack, quality=float(q), **kwargs)
+        _sync()
+        t_enc = 1000 * (time.perf_counter() - t0) / B
+        t0 = time.perf_counter()
+        rec_all = qmf_decode_batch(streams).cpu()
+        _sync()
+        t_dec = 1000 * (time.perf_counter() - t0) / B
+        for idx in range(B):
+            image, encoded, reconstructed = stack[idx].cpu(), streams[idx], rec_all[idx]
+            records.append({
+                "compression ratio": compression_ratio(image, encoded),
+                "bit rate (bpp)": bits_per_pixel(image.shape[-2:], encoded),
+                "PSNR (dB)": psnr(image, reconstructed).item(),
+                "SSIM": ssim(image, reconstructed).item(),
+                "encoding time (ms)": t_enc,
+                "decoding time (ms)": t_dec,
+                "image": idx,
+                "quality": float(q),
+            })
+    return records
