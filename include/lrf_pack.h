@@ -26,6 +26,16 @@ int lrf_pack_qmf_streams(const int8_t* U, int64_t u_stride, const int8_t* V, int
 void lrf_pack_free(uint8_t* p);
 
 /*
+ * The same for the other patch sizes and for patch=False (lrf/compression/qmf.py:232-286): F[f], f = u_Y, v_Y, u_Cb, v_Cb,
+ * u_Cr, v_Cr, holds [B][rows[f]][cols[f]] int8.  whole == 0: every factor as encode_matrix does (per-column zlib-9,
+ * utils.py:354-390); whole != 0: the patch=False form, where the reference's factors keep the plane's channel axis and
+ * encode_tensor (utils.py:429-455) compresses each 3-D array [1, rows, cols] in one piece behind {"shape": ..., "dtype": "int8"}.
+ * Output and return values as lrf_pack_qmf_streams.
+ */
+int lrf_pack_qmf_streams_planes(const int8_t* const F[6], const int64_t rows[6], const int cols[6], int64_t B, int whole,
+                                const char* metadata, int64_t metadata_len, int threads, uint8_t** out, int64_t* out_len);
+
+/*
  * The reverse for decoding (lrf/compression/utils.py:393-426, decode_matrix; qmf.py:306-327): factor_blobs[b] is the second
  * payload of stream b — combine_bytes of the six encoded matrices u_Y, v_Y, u_Cb, v_Cb, u_Cr, v_Cr — of blob_len[b] bytes.
  * Writes image b's factors to U + b*u_stride ([M0,R0] [M1,R1] [M2,R2] int8 row-major back to back) and V + b*v_stride

@@ -118,6 +118,9 @@ def _pack_lib():
                                              ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int), ctypes.c_char_p,
                                              ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
                                              ctypes.POINTER(ctypes.c_int64)]
+        lib.lrf_pack_qmf_streams_planes.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int),
+                                                    ctypes.c_int64, ctypes.c_int, ctypes.c_char_p, ctypes.c_int64, ctypes.c_int,
+                                                    ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64)]
         lib.lrf_pack_free.argtypes = [ctypes.c_void_p]
         lib.lrf_pack_free.restype = None
         lib.lrf_pack_unpack_qmf_factors.argtypes = [ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_int64), ctypes.c_int64,
@@ -155,6 +158,46 @@ def pack_streams_native(Uh: np.ndarray, Vh: np.ndarray, image_hw, ranks, bounds,
                                           Vh.shape[1], B, M, R, metadata, len(metadata), int(threads), out, lens)
     if rc:
         raise RuntimeError(f"lrf_pack_qmf_streams failed ({rc})")
+    streams = []
+    for b in range(B):
+        streams.append(ctypes.string_at(out[b], lens[b]))
+        _pack_lib().lrf_pack_free(out[b])
+    return streams
+
+
+def anyshape_metadata(image_hw, ranks, bounds, patch_size, dtype_name="uint8", chroma=None) -> dict:
+    """Metadata of the patch-size / patch=False streams, keys in the reference's order (qmf.py:157-162, 233-254, 265-277)."""
+    dims = _lib.plane_dims_any(image_hw[0], image_hw[1], patch_size, chroma)
+    metadata = {"dtype": dtype_name, "color space": "YCbCr", "patch": patch_size is not None, "bounds": bounds}
+    if patch_size is not None:
+        metadata["patch size"] = patch_size
+        metadata["original size"] = [[d[0], d[1]] for d in dims]
+        metadata["padded size"] = [[d[2], d[3]] for d in dims]
+    else:
+        metadata["original size"] = [[d[0], d[1]] for d in dims]
+    metadata["rank"] = list(ranks)
+    return metadata
+
+
+def pack_anyshape_native(per_plane, image_hw, ranks, bounds, patch_size, dtype_name="uint8", chroma=None, threads: int = 0) -> list:
+    """All images of a batch of the patch-size / patch=False branches -> byte streams through liblrf_pack.so
+    (lrf_pack_qmf_streams_planes; byte-identical to pack_anyshape per image, tests/test_container_abi.py).
+    per_plane: three (u [B,M,R], v [B,N,R]) int8 numpy pairs."""
+    import ctypes
+    metadata = dict_to_bytes(anyshape_metadata(image_hw, ranks, bounds, patch_size, dtype_name, chroma))
+    arrs = []
+    for u, v in per_plane:
+        arrs += [np.ascontiguousarray(u, dtype=np.int8), np.ascontiguousarray(v, dtype=np.int8)]
+    B = arrs[0].shape[0]
+    F = (ctypes.c_void_p * 6)(*[a.ctypes.data for a in arrs])
+    rows = (ctypes.c_int64 * 6)(*[a.shape[1] for a in arrs])
+    cols = (ctypes.c_int * 6)(*[a.shape[2] for a in arrs])
+    out = (ctypes.c_void_p * B)()
+    lens = (ctypes.c_int64 * B)()
+    rc = _pack_lib().lrf_pack_qmf_streams_planes(F, rows, cols, B, 0 if patch_size is not None else 1, metadata, len(metadata), int(threads),
+                                                 out, lens)
+    if rc:
+        raise RuntimeError(f"lrf_pack_qmf_streams_planes failed ({rc})")
     streams = []
     for b in range(B):
         streams.append(ctypes.string_at(out[b], lens[b]))
@@ -308,13 +351,18 @@ def _qmf_encode_anyshape(ctx, dev, rank, quality, bounds, int_bounds, patch_size
         else:
             u, v = ctx.decompose(X, R, num_iters, int_bounds[0], int_bounds[1], sign)
         per_plane.append((u.cpu().numpy(), v.cpu().numpy()))  # [B, M, R], [B, N, R]
+    dtype_name = str(dev.dtype).split(".")[-1]
+    try:  # the containers of the whole batch on native host threads (a column, or a whole factor, per work item)
+        return pack_anyshape_native(per_plane, (H, W), ranks, bounds, patch_size, dtype_name, chroma)
+    except OSError:  # liblrf_pack.so absent or linked against another zlib: the Python container code, same bytes
+        pass
     streams = []
     for b in range(B):
         factors = []
         for u, v in per_plane:
             # patch=False keeps the plane's channel axis: the factors are 3-D there (qmf.py:281-282), 2-D with patches
             factors += [u[b:b + 1], v[b:b + 1]] if patch_size is None else [u[b], v[b]]
-        streams.append(pack_anyshape(factors, (H, W), ranks, bounds, patch_size, str(dev.dtype).split(".")[-1], chroma))
+        streams.append(pack_anyshape(factors, (H, W), ranks, bounds, patch_size, dtype_name, chroma))
     return streams
 
 
@@ -322,15 +370,7 @@ def pack_anyshape(factors, image_hw, ranks, bounds, patch_size, dtype_name="uint
     """Byte stream of the patch-size / patch=False branches (metadata keys in the reference's order, qmf.py:157-162,
     233-254, 265-277, 288-290).  factors: [u_y, v_y, u_cb, v_cb, u_cr, v_cr] int8, 2-D with patches, [1, rows, R]
     without (the reference keeps the plane's channel axis there and encode_tensor stores such tensors whole)."""
-    dims = _lib.plane_dims_any(image_hw[0], image_hw[1], patch_size, chroma)
-    metadata = {"dtype": dtype_name, "color space": "YCbCr", "patch": patch_size is not None, "bounds": bounds}
-    if patch_size is not None:
-        metadata["patch size"] = patch_size
-        metadata["original size"] = [[d[0], d[1]] for d in dims]
-        metadata["padded size"] = [[d[2], d[3]] for d in dims]
-    else:
-        metadata["original size"] = [[d[0], d[1]] for d in dims]
-    metadata["rank"] = list(ranks)
+    metadata = anyshape_metadata(image_hw, ranks, bounds, patch_size, dtype_name, chroma)
     return combine_bytes([dict_to_bytes(metadata), combine_bytes([encode_tensor(np.ascontiguousarray(f)) for f in factors])])
 
 

@@ -210,6 +210,85 @@ int lrf_pack_qmf_streams(const int8_t* U, int64_t u_stride, const int8_t* V, int
     return 0;
 }
 
+/* The streams of the other patch sizes and of patch=False (lrf/compression/qmf.py:232-286): six factor arrays per batch,
+ * F[f] = [B][rows[f]][cols[f]] int8 (u_Y, v_Y, u_Cb, v_Cb, u_Cr, v_Cr).  whole == 0: every factor as encode_matrix does
+ * (per-column zlib, utils.py:354-390); whole != 0: the patch=False form — the reference keeps the plane's channel axis, so the
+ * factors are 3-D [1, rows, cols] and encode_tensor compresses each in one piece behind {"shape": [...], "dtype": "int8"}
+ * (utils.py:429-455). */
+int lrf_pack_qmf_streams_planes(const int8_t* const F[6], const int64_t rows[6], const int cols[6], int64_t B, int whole,
+                                const char* metadata, int64_t metadata_len, int threads, uint8_t** out, int64_t* out_len)
+{
+    if (!F || !rows || !cols || !metadata || !out || !out_len || B < 1) return -1;
+    for (int f = 0; f < 6; f++)
+        if (!F[f] || rows[f] < 1 || cols[f] < 1) return -1;
+    int64_t per_image = 0; // work items per image: columns, or whole factors
+    for (int f = 0; f < 6; f++) per_image += whole ? 1 : cols[f];
+    const int64_t items = B * per_image;
+    unsigned hw = std::thread::hardware_concurrency();
+    int nt = threads > 0 ? threads : (int)(hw ? (hw > 64 ? 64 : hw) : 1);
+    if (nt > items) nt = (int)items;
+    std::vector<std::string> pieces((size_t)items);
+    std::atomic<int64_t> next(0);
+    std::atomic<int> status(0);
+    auto work = [&]() {
+        for (;;) {
+            int64_t it = next.fetch_add(1);
+            if (it >= items || status.load() != 0) return;
+            const int64_t b = it / per_image;
+            int64_t k = it - b * per_image;
+            int rc = 0;
+            for (int f = 0; f < 6; f++) {
+                const int64_t n = whole ? 1 : cols[f];
+                if (k < n) {
+                    const int8_t* A = F[f] + b * rows[f] * cols[f];
+                    if (whole) {
+                        const uLong len = (uLong)(rows[f] * cols[f]);
+                        std::vector<unsigned char> buf(compressBound(len));
+                        uLongf m = (uLongf)buf.size();
+                        if (compress2(buf.data(), &m, (const unsigned char*)A, len, 9) != Z_OK) rc = -5;
+                        else pieces[(size_t)it].assign((const char*)buf.data(), (size_t)m);
+                    } else {
+                        rc = compress_column(A, rows[f], cols[f], (int)k, pieces[(size_t)it]);
+                    }
+                    break;
+                }
+                k -= n;
+            }
+            if (rc) { status.store(rc); return; }
+        }
+    };
+    for (int64_t b = 0; b < B; b++) out[b] = nullptr;
+    if (nt > 1) worker_pool().run(nt - 1, work);
+    else work();
+    if (status.load() != 0) return status.load();
+    const std::string meta(metadata, (size_t)metadata_len);
+    for (int64_t b = 0; b < B; b++) {
+        std::vector<std::string> enc;
+        size_t at = (size_t)(b * per_image);
+        for (int f = 0; f < 6; f++) {
+            if (whole) {
+                char header[128];
+                int hl = snprintf(header, sizeof(header), "{\"shape\": [1, %lld, %d], \"dtype\": \"int8\"}", (long long)rows[f], cols[f]);
+                enc.push_back(combine({std::string(header, (size_t)hl), pieces[at]}));
+                at += 1;
+            } else {
+                enc.push_back(assemble_matrix(std::vector<std::string>(pieces.begin() + at, pieces.begin() + at + cols[f])));
+                at += (size_t)cols[f];
+            }
+        }
+        std::string stream = combine({meta, combine(enc)});
+        uint8_t* p = (uint8_t*)malloc(stream.size() ? stream.size() : 1);
+        if (!p) {
+            for (int64_t j = 0; j < b; j++) { free(out[j]); out[j] = nullptr; }
+            return -4;
+        }
+        memcpy(p, stream.data(), stream.size());
+        out[b] = p;
+        out_len[b] = (int64_t)stream.size();
+    }
+    return 0;
+}
+
 /* ---- the reverse: streams -> factor matrices (decode_matrix, utils.py:393-426) ---- */
 
 namespace {

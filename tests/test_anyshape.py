@@ -105,6 +105,21 @@ def test_repack_is_byte_identical(name):
     assert pack_anyshape(c.ref_factors(), (H, W), c.ranks, tuple(c.kwargs.get("bounds", (-16, 15))), ps) == c.encoded
 
 
+@pytest.mark.parametrize("name", SMALL + NO_INIT)
+def test_native_repack_is_byte_identical(name):
+    """liblrf_pack.so's packer for these branches (lrf_pack_qmf_streams_planes: per-column zlib with patches, whole 3-D factors
+    without) rebuilds the reference's streams from their own factors — a batch of two copies, on two threads."""
+    from lrf_amd.codec import pack_anyshape_native
+    c = Case(name)
+    ps, _, _ = _params(c)
+    H, W = c.image.shape[-2:]
+    fac = [np.asarray(f) for f in c.ref_factors()]
+    fac = [f.reshape(f.shape[-2], f.shape[-1]) for f in fac]  # patch=False fixtures carry the channel axis
+    per_plane = [(np.stack([fac[2 * i]] * 2), np.stack([fac[2 * i + 1]] * 2)) for i in range(3)]
+    out = pack_anyshape_native(per_plane, (H, W), c.ranks, tuple(c.kwargs.get("bounds", (-16, 15))), ps, threads=2)
+    assert out == [c.encoded] * 2
+
+
 @pytest.mark.parametrize("M,N,R", [(384, 16, 5), (35, 256, 6), (100, 300, 40), (300, 100, 100), (64, 64, 3), (200, 230, 9), (330, 290, 12),
                                   (256, 400, 10), (520, 515, 8)])
 def test_oracle_restated_init_agrees_with_jacobi_and_lapack(M, N, R, oracle):

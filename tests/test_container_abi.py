@@ -102,7 +102,7 @@ def test_native_packer_matches_reference_streams():
     header = open(os.path.join(ROOT, "include", "lrf_pack.h")).read()
     declared = set(re.findall(r"\b(lrf_pack_[a-z0-9_]+)\s*\(", header))
     lib = ctypes.CDLL(os.path.join(ROOT, "lrf_amd", "liblrf_pack.so"))
-    assert declared == {"lrf_pack_qmf_streams", "lrf_pack_free", "lrf_pack_zlib_version", "lrf_pack_unpack_qmf_factors"}
+    assert declared == {"lrf_pack_qmf_streams", "lrf_pack_qmf_streams_planes", "lrf_pack_free", "lrf_pack_zlib_version", "lrf_pack_unpack_qmf_factors"}
     for name in declared:
         assert hasattr(lib, name)
     for name in ("s1_r7", "odd_q7", "tiny_rank1", "tiny_q20", "zero_q7", "nat_q7"):
