@@ -557,7 +557,14 @@ def _factors_native(streams: Sequence[bytes]):
 
 
 def qmf_decode_batch(streams: Sequence[bytes], device=None) -> torch.Tensor:
-    """Decodes streams of equal geometry and ranks -> uint8 CUDA tensor [B,3,H,W]."""
+    """Decodes streams of equal geometry and ranks -> uint8 CUDA tensor [B,3,H,W].  Streams of the other branches (another
+    patch size, patch=False, another chroma scale, the RGB colour space) are decoded one by one and stacked."""
+    m_first = bytes_to_dict(separate_bytes(streams[0], 2)[0])
+    H0, W0 = (m_first["original size"][0] if m_first["color space"] == "YCbCr" else (0, 0))
+    if m_first["color space"] != "YCbCr" or not m_first["patch"] or list(m_first["patch size"]) != [8, 8] \
+            or list(m_first["original size"][1]) != [H0 // 2, W0 // 2]:
+        one = _qmf_decode_rgbspace if m_first["color space"] == "RGB" else _qmf_decode_anyshape
+        return torch.stack([one(s) for s in streams])
     got = _factors_native(streams)
     metas, Uh, Vh = got if got is not None else _factors_python(streams)
     m0 = metas[0]

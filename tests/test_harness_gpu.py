@@ -21,3 +21,16 @@ def test_batched_sweep_equals_the_per_image_loop():
         m = many[key(r)]
         for k in ("compression ratio", "bit rate (bpp)", "PSNR (dB)", "SSIM"):
             assert r[k] == m[k], (key(r), k, r[k], m[k])  # the same byte streams, the same pixels
+
+
+def test_batched_sweep_on_another_patch_size():
+    """the any-shape branches through the same sweep (qmf_encode_batch packs natively, the decoder goes stream by stream)"""
+    import lrf_amd
+    imgs = [config3_image(i)[:, :64, :96].contiguous() for i in (1, 22)]
+    one = lrf_amd.rd_sweep(imgs, (10, 25), lrf_amd.qmf_encode, lrf_amd.qmf_decode, patch_size=(16, 16))
+    many = lrf_amd.rd_sweep_batched(torch.stack(imgs), (10, 25), patch_size=(16, 16))
+    key = lambda r: (r["image"], r["quality"])
+    many = {key(r): r for r in many}
+    for r in one:
+        for k in ("bit rate (bpp)", "PSNR (dB)"):
+            assert r[k] == many[key(r)][k], (key(r), k)
