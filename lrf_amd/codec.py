@@ -331,26 +331,47 @@ def _qmf_encode_anyshape(ctx, dev, rank, quality, bounds, int_bounds, patch_size
     H, W = dev.shape[-2:]
     dims = _lib.plane_dims_any(H, W, patch_size, chroma)
     ranks = anyshape_ranks((H, W), patch_size, rank, quality, chroma)
-    per_plane, soff = [], 0
-    for c in range(3):
-        X = ctx.planes_any(dev, patch_size, c, chroma)
+    # Small calls: the three planes on three contexts / streams.  These kernels give a matrix to one workgroup, so one image
+    # keeps a CU or two busy per plane and its latency is the SUM of the planes' chains unless they run side by side (one
+    # 512x768 image without patches: 57 -> 45 ms); a large batch fills the chip by itself (three streams: no gain).
+    side_by_side = B <= 8 and torch.cuda.is_available()
+    offs = [sum(ranks[:c]) for c in range(3)]
+
+    def one_plane(pctx, c):
+        X = pctx.planes_any(dev, patch_size, c, chroma)
         R = ranks[c]
         sign = None
         if init_sign is not None:
-            sg = torch.as_tensor(init_sign, dtype=torch.int8).reshape(-1, sum(ranks))[:, soff:soff + R]
+            sg = torch.as_tensor(init_sign, dtype=torch.int8).reshape(-1, sum(ranks))[:, offs[c]:offs[c] + R]
             sign = sg.expand(B, R).contiguous().cuda(dev.device)
-        soff += R
         if init is not None:
             u0 = torch.as_tensor(init[c][0], dtype=torch.float32).reshape(-1, dims[c][4], R).expand(B, -1, -1).contiguous().cuda(dev.device)
             v0 = torch.as_tensor(init[c][1], dtype=torch.float32).reshape(-1, dims[c][5], R).expand(B, -1, -1).contiguous().cuda(dev.device)
             u, v = (u0.cpu().to(torch.int8), v0.cpu().to(torch.int8)) if num_iters == 0 else \
-                ctx.bcd(X, u0, v0, num_iters, int_bounds[0], int_bounds[1])
+                pctx.bcd(X, u0, v0, num_iters, int_bounds[0], int_bounds[1])
         elif num_iters == 0:  # the float factors go straight through torch's truncating cast (qmf.py:258-260)
-            u0, v0 = ctx.svd_init(X, R, sign)
+            u0, v0 = pctx.svd_init(X, R, sign)
             u, v = u0.cpu().to(torch.int8), v0.cpu().to(torch.int8)
         else:
-            u, v = ctx.decompose(X, R, num_iters, int_bounds[0], int_bounds[1], sign)
-        per_plane.append((u.cpu().numpy(), v.cpu().numpy()))  # [B, M, R], [B, N, R]
+            u, v = pctx.decompose(X, R, num_iters, int_bounds[0], int_bounds[1], sign)
+        return u, v, X  # X: kept alive until its stream has been waited for
+
+    if side_by_side:
+        ctxs, lanes = _plane_lanes(dev.device)
+        cur = torch.cuda.current_stream(dev.device)
+        pending = []
+        for c in range(3):
+            lanes[c].wait_stream(cur)
+            with torch.cuda.stream(lanes[c]):
+                pending.append(one_plane(ctxs[c], c))
+        for c in range(3):
+            cur.wait_stream(lanes[c])
+        per_plane = [(u.cpu().numpy(), v.cpu().numpy()) for u, v, _ in pending]  # [B, M, R], [B, N, R]
+    else:
+        per_plane = []
+        for c in range(3):
+            u, v, _ = one_plane(ctx, c)
+            per_plane.append((u.cpu().numpy(), v.cpu().numpy()))
     dtype_name = str(dev.dtype).split(".")[-1]
     try:  # the containers of the whole batch on native host threads (a column, or a whole factor, per work item)
         return pack_anyshape_native(per_plane, (H, W), ranks, bounds, patch_size, dtype_name, chroma)
@@ -364,6 +385,18 @@ def _qmf_encode_anyshape(ctx, dev, rank, quality, bounds, int_bounds, patch_size
             factors += [u[b:b + 1], v[b:b + 1]] if patch_size is None else [u[b], v[b]]
         streams.append(pack_anyshape(factors, (H, W), ranks, bounds, patch_size, dtype_name, chroma))
     return streams
+
+
+_PLANE_LANES = {}
+
+
+def _plane_lanes(device):
+    """three contexts and three streams per (host thread, device) for the plane-parallel small calls of _qmf_encode_anyshape"""
+    import threading
+    key = (threading.get_ident(), torch.device(device).index or 0)
+    if key not in _PLANE_LANES:
+        _PLANE_LANES[key] = ([_lib.Context(key[1]) for _ in range(3)], [torch.cuda.Stream(device=key[1]) for _ in range(3)])
+    return _PLANE_LANES[key]
 
 
 def pack_anyshape(factors, image_hw, ranks, bounds, patch_size, dtype_name="uint8", chroma=None) -> bytes:
