@@ -1125,11 +1125,11 @@ __global__ __launch_bounds__(256) void k_any_tridiag_blk(double* __restrict__ G,
 // k_any_tridiag_blk's product pass reads the whole trailing square of a symmetric matrix: at n = 512 that pass runs at the
 // HBM rate, at n = 256 at what a CU draws from the Infinity Cache.  Here an element A0[r][i], r >= i, is loaded once and
 // used twice: for the column part cc[i] += A0[r][i] v[r] and for the row part y[r] += A0[r][i] v[i].  Work is dealt by ROWS:
-// sub-tile r0 (sixteen rows) belongs to wave (r0 / 16) % 4, which walks the 64-column chunks J <= r0 / 64 of it; lane =
+// sub-tile r0 (sixteen rows) belongs to wave (r0 / 16) % NW, which walks the 64-column chunks J <= r0 / 64 of it; lane =
 // column.  A body (r0, J): sixteen row loads (the next body's are in flight), the column part as a 16-fma chain added to the
 // wave's partial Cp[wave][column] (LDS), the sixteen products a v[column] through a wave-private LDS tile to lane = (row,
 // quarter): four 16-term sums per row, combined ((q0 + q1) + q2) + q3 into Yrow[J][row] — one writer per (J, row).  The
-// owner thread of column i then takes ((Cp0 + Cp1) + Cp2) + Cp3 plus the chunks' row values in order.  Row k of the current
+// owner thread of column i then takes the waves' partials in wave order plus the chunks' row values in order.  Row k of the current
 // matrix is column k of the triangle: the lane that owns column k + 1 leaves what it loaded in Lx for the next step.  The
 // panel update touches the triangle only; the upper triangle keeps the reflectors (row k: v_k).  Everything else — panel
 // algebra, reductions, outputs — as k_any_tridiag_blk.  NB = 16 / NCT.  LDS at n = 512: 155 KB (one workgroup per CU).
@@ -1139,10 +1139,10 @@ __global__ __launch_bounds__(256) void k_any_tridiag_blk(double* __restrict__ G,
         __builtin_amdgcn_wave_barrier();                    \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
     } while (0)
-template <int NCT>
-__global__ __launch_bounds__(256) void k_any_tridiag_sym(double* __restrict__ G, int n, double* __restrict__ TD)
+template <int NCT, int NW>
+__global__ __launch_bounds__(64 * NW) void k_any_tridiag_sym(double* __restrict__ G, int n, double* __restrict__ TD)
 {
-    constexpr int NB = 16 / NCT, NCH = 4 * NCT, TP = 65;
+    constexpr int NB = 8, NCH = 4 * NCT, TP = 65; // NW waves: 4, or 8 for n <= 256 (two per SIMD; the threads past 256 own no column)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ns = ((n + 1) & ~1) + 16; // row stride of the LDS vectors: sixteen zeros behind every panel row (row reads run past n)
     const int nch = (n + 63) >> 6;
@@ -1150,10 +1150,10 @@ __global__ __launch_bounds__(256) void k_any_tridiag_sym(double* __restrict__ G,
     double* Wp = Vp + (size_t)NB * ns;            // [NB][ns]
     double* Lx = Wp + (size_t)NB * ns;            // [ns]: column k of the triangle for the coming step
     double* Yrow = Lx + ns;                       // [NCH][ns]
-    double* Cp = Yrow + (size_t)NCH * ns;         // [4][ns]
-    double* Lt = Cp + (size_t)4 * ns;             // [4][16 TP]
-    double* Lq = Lt + 4 * 16 * TP;                // [4][64]
-    double* Lgh = Lq + 256;                       // [4][2 NB]
+    double* Cp = Yrow + (size_t)NCH * ns;         // [NW][ns]
+    double* Lt = Cp + (size_t)NW * ns;            // [NW][16 TP]
+    double* Lq = Lt + NW * 16 * TP;               // [NW][64]
+    double* Lgh = Lq + 64 * NW;                   // [4][2 NB]
     double* Lpart = Lgh + 8 * NB;                 // [16]
     double* Lscal = Lpart + 16;                   // [8]
     double* A = G + (long)blockIdx.x * n * n;
@@ -1165,7 +1165,7 @@ __global__ __launch_bounds__(256) void k_any_tridiag_sym(double* __restrict__ G,
     double* Cpw = Cp + (size_t)wave * ns;
     auto bsum = [&](double v, int slot) __attribute__((always_inline)) {
         v = wave_tree64(v);
-        if (lane == 0) Lpart[4 * slot + wave] = v;
+        if (lane == 0 && wave < 4) Lpart[4 * slot + wave] = v; // (waves past the fourth own no column: their sums are zero)
         __syncthreads();
         return ((Lpart[4 * slot] + Lpart[4 * slot + 1]) + Lpart[4 * slot + 2]) + Lpart[4 * slot + 3];
     };
@@ -1188,12 +1188,12 @@ __global__ __launch_bounds__(256) void k_any_tridiag_sym(double* __restrict__ G,
     // the wave's bodies from sub-tile row rbeg0 (a multiple of 16) on, chunks Jlo .. r0 / 64: (r0, J) -> next; r0 >= n: done
     auto advance = [&](int& r0, int& J, int Jlo) __attribute__((always_inline)) {
         if (J < (r0 >> 6)) J++;
-        else { r0 += 64; J = Jlo; }
+        else { r0 += 16 * NW; J = Jlo; }
     };
     // the wave's bodies in order, the loads of the next two in flight (one workgroup of four waves per CU: what hides the
     // memory latency is what a wave itself has outstanding — 16 KB per wave here)
     auto pipeline = [&](int rbeg, int Jlo, auto&& fn) __attribute__((always_inline)) {
-        int rA = rbeg + 16 * ((wave - (rbeg >> 4)) & 3), JA = Jlo;
+        int rA = rbeg + 16 * ((wave - (rbeg >> 4)) & (NW - 1)), JA = Jlo;
         if (!(rA < n)) return;
         // every prefetch is issued whether or not its body exists (a body past the end re-reads clamped rows): with a load
         // under a branch the compiler must assume it was not issued and waits for younger loads than the one it needs
@@ -1227,7 +1227,7 @@ __global__ __launch_bounds__(256) void k_any_tridiag_sym(double* __restrict__ G,
 #else
 #define SYM_STAMP(i)
 #endif
-    for (int e = tid; e < 2 * NB * ns; e += 256) Vp[e] = 0.0; // Vp and Wp: the padding stays zero
+    for (int e = tid; e < 2 * NB * ns; e += 64 * NW) Vp[e] = 0.0; // Vp and Wp: the padding stays zero
     __syncthreads();
     bool have_x = false;
     for (int k0 = 0; k0 < n - 2; k0 += NB) {
@@ -1303,7 +1303,7 @@ __global__ __launch_bounds__(256) void k_any_tridiag_sym(double* __restrict__ G,
                 }
                 sg = wave_tree64(sg);
                 sh = wave_tree64(sh);
-                if (lane == 0) { Lgh[wave * 2 * NB + 2 * m] = sg; Lgh[wave * 2 * NB + 2 * m + 1] = sh; }
+                if (lane == 0 && wave < 4) { Lgh[wave * 2 * NB + 2 * m] = sg; Lgh[wave * 2 * NB + 2 * m + 1] = sh; }
             }
             for (int J = 0; J < nch; J++) Cpw[64 * J + lane < n ? 64 * J + lane : n - 1] = 0.0; // (the clamped lanes rewrite n - 1 with 0)
             __syncthreads(); // V_j, the partials and the cleared column sums are visible
@@ -1365,7 +1365,9 @@ __global__ __launch_bounds__(256) void k_any_tridiag_sym(double* __restrict__ G,
                     const int i = tid + 256 * c;
                     double cv = 0.0;
                     if (i < n && i > k) {
-                        cv = ((Cp[i] + Cp[ns + i]) + Cp[2 * ns + i]) + Cp[3 * (size_t)ns + i];
+                        cv = Cp[i];
+#pragma unroll
+                        for (int w = 1; w < NW; w++) cv = cv + Cp[(size_t)w * ns + i]; // the waves' partials in wave order
                         double yr = 0.0;
                         for (int J = Jmin; J <= (i >> 6); J++) yr = yr + Yrow[(size_t)J * ns + i];
                         cv = cv + yr;

@@ -15,7 +15,7 @@
  * Tridiagonalisations, chosen by the side n = min(M, N) exactly as lrf_anyshape_host.inc does:
  *   n <= 64                     k_any_eig<1>, plain three-pass Householder step              (any_tridiag_plain)
  *   64 < n <= 192               k_any_tridiag_reg<2 or 3>, matrix in registers                (any_tridiag_reg)
- *   192 < n <= 512              k_any_tridiag_sym<1|2>, panels of 16 / 8 steps, lower triangle (any_tridiag_sym)
+ *   192 < n <= 512              k_any_tridiag_sym<1,8> / <2,4>, panels of 8 steps, lower triangle (any_tridiag_sym)
  *   n > 512                     k_any_tridiag_blk<4|8>, panels of 8 / 4 steps, full square     (any_tridiag_blocked)
  * (LRF_ORACLE_ANY_TRIDIAG=blocked: the full-square panels also for 193..512 — the library's LRF_ANY_TRIDIAG_SQUARE=1;
  *  =unblocked: round 2's any_tridiag_plain / any_tridiag_fused above 192 — the library's LRF_ANY_TRIDIAG_UNBLOCKED=1.)
@@ -461,7 +461,7 @@ static void any_tridiag_blocked(double* A, int n, int NCT, int NB, double* d, do
  * products each, added in column order to 0.0), ((q0 + q1) + q2) + q3, and the chunks' values added in chunk order.
  * p = cc + rowpart, then dlatrd's corrections as in any_tridiag_blocked.  Row k of the current matrix is column k of the
  * lower triangle.  The panel update touches the lower triangle only; the upper triangle keeps the reflectors. */
-static void any_tridiag_sym(double* A, int n, int NCT, int NB, double* d, double* e, double* tau)
+static void any_tridiag_sym(double* A, int n, int NCT, int NB, int NW, double* d, double* e, double* tau)
 {
     double tv[256], tg[256], th[256], g[16], h[16];
     double *Vp = (double*)calloc((size_t)NB * n, sizeof(double)), *Wp = (double*)calloc((size_t)NB * n, sizeof(double)),
@@ -531,10 +531,10 @@ static void any_tridiag_sym(double* A, int n, int NCT, int NB, double* d, double
                 double c = 0.0;
                 if (i > k) {
                     /* column part: rows r >= i (the diagonal included).  The rows are dealt to the four waves in sub-tiles of
-                     * sixteen (sub-tile r0 / 16 to wave (r0 / 16) % 4, from the sub-tile that holds row k + 1, inside the chunks
-                     * at or below the diagonal one): per sub-tile a chain from 0.0, a wave's sub-tiles added in order, then
-                     * ((w0 + w1) + w2) + w3 */
-                    double sw[4] = {0.0, 0.0, 0.0, 0.0};
+                     * sixteen (sub-tile r0 / 16 to wave (r0 / 16) % NW — eight waves for n <= 256, four above —, from the sub-tile
+                     * that holds row k + 1, inside the chunks at or below the diagonal one): per sub-tile a chain from 0.0, a
+                     * wave's sub-tiles added in order, then the waves' sums in wave order */
+                    double sw[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
                     const int rbeg = (k + 1) & ~15, rdiag = 64 * (i / 64);
                     for (int r0 = (rbeg > rdiag ? rbeg : rdiag); r0 < n; r0 += 16) {
                         double cl = 0.0;
@@ -543,9 +543,10 @@ static void any_tridiag_sym(double* A, int n, int NCT, int NB, double* d, double
                             const double av = (r < n && r >= i) ? A[(long)r * n + i] : 0.0, vj = (r < n) ? v[r] : 0.0;
                             cl = fma(av, vj, cl);
                         }
-                        sw[(r0 >> 4) & 3] = sw[(r0 >> 4) & 3] + cl;
+                        sw[(r0 >> 4) & (NW - 1)] = sw[(r0 >> 4) & (NW - 1)] + cl;
                     }
-                    c = ((sw[0] + sw[1]) + sw[2]) + sw[3];
+                    c = sw[0];
+                    for (int w = 1; w < NW; w++) c = c + sw[w];
                     /* row part of row i: chunks Jmin .. i / 64 */
                     double yr = 0.0;
                     for (int J = Jmin; J <= i / 64; J++) {
@@ -642,7 +643,7 @@ int lrf_oracle_any_eig(double* G, int n, int R, int rcap, const int8_t* sign, fl
     else if (n <= 64) any_tridiag_plain(G, n, d, e, tau);
     else if (tdv && tdv[0] == 'u') { if (NCT == 1) any_tridiag_plain(G, n, d, e, tau); else any_tridiag_fused(G, n, NCT, d, e, tau); }
     else if (tdv && tdv[0] == 'b') any_tridiag_blocked(G, n, NCT, NCT == 1 ? 16 : 32 / NCT, d, e, tau); /* round 3's first blocked form */
-    else if (n <= 512) any_tridiag_sym(G, n, NCT, 16 / NCT, d, e, tau);
+    else if (n <= 512) any_tridiag_sym(G, n, NCT, 8, NCT == 1 ? 8 : 4, d, e, tau);
     else any_tridiag_blocked(G, n, NCT, 32 / NCT, d, e, tau);
     /* Gershgorin hull, pivmin (min / max: order-free) */
     double lo = 1e300, hi = -1e300, e2m = 0.0;
