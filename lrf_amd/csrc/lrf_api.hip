@@ -23,6 +23,7 @@
 #include "lrf_midrank_kernels.hip"
 #include "lrf_bcdw_kernel.hip"
 #include "lrf_bcdw16_kernel.hip"
+#include "lrf_bcdw32_kernel.hip"
 #include "lrf_anyshape_kernels.hip"
 
 // the planes qmf_encode forms hold YCbCr samples, 0 or in [0.114, 255.5]: all below 2^8 and exact on the grid 2^(8-35)
@@ -33,6 +34,7 @@
 #define LRF_TABLE_SETS 6 // descriptor-table sets a context keeps resident (upload_tables)
 #define LRF_BCDW_MIN_BLOCKS 1024 // smaller rank <= 8 runs iterate on the workgroup kernel k_bcd (run_bcd)
 #define LRF_BCDW16_MIN_BLOCKS 1024 // likewise for rank <= 16 runs and k_bcd_w16
+#define LRF_BCDW32_MIN_BLOCKS 1024 // likewise for rank 17..32 runs and k_bcd_w32
 
 static thread_local char g_err[512] = "";
 
@@ -300,6 +302,7 @@ static int table_rp(const Tables& t) { return table_rmax(t) <= 16 ? 16 : LRF_RPB
 // the second table set (vf16 ...): the regions of the two pitches would overlap in one buffer.
 struct FamRun {
     int plane0, nplanes, block0, nblocks, rmax, fam, pitch;
+    int rmin;        // smallest rank of the run (k_bcd_w32 takes runs whose ranks are all 17..32)
     bool any_native; // some plane of the run is small enough for ATen's native order of `uu @ bb` ((R-1) M < 400)
 };
 static int fam_of_rank(int R) { return R <= 8 ? 0 : (R <= 16 ? 1 : 2); }
@@ -318,12 +321,13 @@ static std::vector<FamRun> plan_runs(const Tables& t)
     for (int p = 0; p < (int)t.planes.size(); p++) {
         const PlaneDesc& pd = t.planes[p];
         const int fam = split ? fam_of_rank(pd.R) : (rmax_t > 16 ? 2 : fam_of_rank(rmax_t));
-        if (runs.empty() || runs.back().fam != fam) runs.push_back(FamRun{p, 0, pd.blk0, 0, 1, fam, fam == 2 ? LRF_RPB : 16, false});
+        if (runs.empty() || runs.back().fam != fam) runs.push_back(FamRun{p, 0, pd.blk0, 0, 1, fam, fam == 2 ? LRF_RPB : 16, pd.R, false});
         FamRun& r = runs.back();
         r.any_native = r.any_native || pd.native_t2_u != 0;
         r.nplanes++;
         r.nblocks += pd.nblk;
         r.rmax = pd.R > r.rmax ? pd.R : r.rmax;
+        r.rmin = pd.R < r.rmin ? pd.R : r.rmin;
     }
     return runs;
 }
@@ -537,6 +541,9 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
         HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_mid<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MidLds<0>)));
         HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_mid<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MidLds<1>)));
         HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_mid<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MidLds<2>)));
+#define LRF_W32_ATTR(NP) HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_w32<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, LRF_BCDW32_LDS))
+        LRF_W32_ATTR(9); LRF_W32_ATTR(10); LRF_W32_ATTR(11); LRF_W32_ATTR(12); LRF_W32_ATTR(13); LRF_W32_ATTR(14); LRF_W32_ATTR(15); LRF_W32_ATTR(16);
+#undef LRF_W32_ATTR
         c->attr_done |= 1u << 2;
     }
     // the b tables of the initial V
@@ -555,6 +562,8 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
     // 17..32 (k_bcd_mid) replace the reference's dependent chain by independent fmas, bit for bit
     const long mx_b = abs(lo) > abs(hi) ? abs(lo) : abs(hi);
     static const bool exact_off = getenv("LRF_GENERIC_GS") && getenv("LRF_GENERIC_GS")[0] == '1'; // developer comparison aid
+    static const bool w32_off = getenv("LRF_NO_BCDW32") && getenv("LRF_NO_BCDW32")[0] == '1'; // developer comparison aid: k_bcd_mid<0> instead
+    static const long w32_min = getenv("LRF_BCDW32_MIN_BLOCKS") ? atol(getenv("LRF_BCDW32_MIN_BLOCKS")) : LRF_BCDW32_MIN_BLOCKS; // developer aid
     static const long w16_min = getenv("LRF_BCDW16_MIN_BLOCKS") ? atol(getenv("LRF_BCDW16_MIN_BLOCKS")) : LRF_BCDW16_MIN_BLOCKS; // developer aid
     for (int it = 0; it < K; it++) {
         {
@@ -577,7 +586,25 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
 #define LRF_LAUNCH_MID(MODE)                                                                                         \
     hipLaunchKernelGGL((k_bcd_mid<MODE>), dim3(nbr), dim3(256), sizeof(MidLds<MODE>), rs, X, pl, blr, (const float*)fb.vf, \
                        (const float*)fb.wf, (const float*)fb.bf, U0, U, fb.pp, fb.qp, gpr)
-                if (r.fam == 2) {
+                if (r.fam == 2 && mode == 0 && wave_variant && !w32_off && gpr.exact_int && 64 * mx_b * mx_b <= 32767 && r.rmin >= 17 &&
+                    nbr >= w32_min) {
+                    // ranks 17..32, iterations >= 2, exact-integer bounds with |b| within int16: one wave per block, lane = row
+                    // Gauss-Seidel on int16 pairs (lrf_bcdw32_kernel.hip)
+#define LRF_LAUNCH_W32(NP)                                                                                           \
+    hipLaunchKernelGGL((k_bcd_w32<NP>), dim3((nbr + LRF_BCDW32_WAVES - 1) / LRF_BCDW32_WAVES), dim3(64 * LRF_BCDW32_WAVES), LRF_BCDW32_LDS, \
+                       rs, X, pl, blr, (const float*)fb.vf, (const float*)fb.bf, U, fb.pp, fb.qp, gpr, nbr)
+                    switch ((r.rmax + 1) >> 1) {
+                    case 9: LRF_LAUNCH_W32(9); break;
+                    case 10: LRF_LAUNCH_W32(10); break;
+                    case 11: LRF_LAUNCH_W32(11); break;
+                    case 12: LRF_LAUNCH_W32(12); break;
+                    case 13: LRF_LAUNCH_W32(13); break;
+                    case 14: LRF_LAUNCH_W32(14); break;
+                    case 15: LRF_LAUNCH_W32(15); break;
+                    default: LRF_LAUNCH_W32(16); break;
+                    }
+#undef LRF_LAUNCH_W32
+                } else if (r.fam == 2) {
                     if (mode == 1) LRF_LAUNCH_MID(1);
                     else if (mode == 2) LRF_LAUNCH_MID(2);
                     else LRF_LAUNCH_MID(0);

@@ -1,0 +1,386 @@
+// lrf_bcdw32_kernel.hip — k_bcd_w32: the BCD half-iteration (U update + partials of the V update) of iterations >= 2 for
+// ranks 17..32 with one *wave* per (matrix, 384-row block) and no workgroup barrier — k_bcd_w16's frame for the rank
+// family the reference's quality sweep reaches beyond quality 25 (lrf/factorization/qmf.py:93-126, 128-139;
+// experiments/comparison/eval.py:83).  Included by lrf_api.hip after lrf_bcdw16_kernel.hip.  Replaces k_bcd_mid<0>
+// (four waves per block, sixteen rows x four lanes in the Gauss-Seidel, three workgroup barriers per sub-tile) where the
+// exact-integer conditions below hold; k_bcd_mid keeps the first iteration (float old U), the caller's-U0 mode and the
+// wider bounds.
+//
+// Per 64-row sub-tile, one wave:
+//   1. the prefetched X sub-tile (64 VGPRs) goes to the wave's XOR-swizzled LDS tile, the next one is requested;
+//   2. a^T = V^T X^T on the f32 matrix cores, two rank tiles: 128 v_mfma_f32_16x16x4_f32 in eight independent chains (each the
+//      k-ordered fma chain of the reference's sgemm), the eight D tiles become lane = row by 32 v_permlane swaps;
+//   3. Gauss-Seidel with LANE = ROW (all 64 lanes on 64 rows) in EXACT INTEGERS.  From the second iteration on u and
+//      b = v.mT @ v are integers and every partial sum of `uu @ bb` stays below 2^24 (host check (R-1) 64 mx^3 < 2^24), so
+//      the reference's fp32 sum is the integer sum in any order.  The row lives as sixteen int16 PAIRS W[p] = (w[2p],
+//      w[2p+1]), updated in place; column r's sum is the dot product of W with row r of the symmetric table (diagonal
+//      zero): sixteen v_dot2c_i32_i16 — two terms per instruction — whose table operand is ONE VGPR (the row's sixteen
+//      pair-dwords, one ds_read_b32 per column, lane l reading dword l & 15) behind the DPP row_newbcast modifier.  Only
+//      the dot product with the pair that holds the column just solved sits on the column-to-column chain:
+//      dot2 -> cvt -> a - T -> + eps -> * (1/den) -> rndne -> med3 -> magic add -> perm into W.  The quotient is
+//      num * (1/den) with gs_row's tie test; a wave with a lane too close to call repeats the sub-tile's solve with the
+//      IEEE division (rare).  Needs |b| <= 32767, i.e. 64 mx^2 <= 32767 (mx <= 22): checked by the host.
+//   4. the new row leaves as int8 (global memory: R bytes per row; LDS: 32 bytes per row);
+//   5. a' += X^T u on the f32 matrix cores (128 MFMAs: four strided column tiles per ds_read_b128, two rank tiles; the
+//      reference's k-ordered chain over the block's rows) and b' += u^T u on the INT8 matrix cores: the sixteen bytes
+//      u[4 e + lq][16 t + li] a lane has just read for the f32 operand ARE an operand of v_mfma_i32_16x16x64_i8 (the k
+//      index is summed over, so any fixed bijection rows <-> (lane group, byte) serves): four instructions instead of 64.
+// 20 KB of LDS per wave (X tile 16 KB, int8 u tile 2 KB, int16 table 2 KB): two 4-wave workgroups fill a CU's 160 KB.
+
+#define LRF_BCDW32_WAVES 4
+#define LRF_BCDW32_WAVE_LDS (64 * 64 * 4 + 64 * 32 + 32 * 16 * 4)
+#define LRF_BCDW32_LDS (LRF_BCDW32_WAVES * LRF_BCDW32_WAVE_LDS)
+
+typedef short w32_s16x2 __attribute__((ext_vector_type(2)));
+
+// acc += dot2(tab[lane N of each 16-lane row], w): both int16 pairs
+template <int N>
+__device__ __forceinline__ void w32_dot2_bc16(int& acc, int tab, int w)
+{
+    asm("v_dot2c_i32_i16_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(tab), "v"(w), "n"(N));
+}
+template <int N>
+__device__ __forceinline__ float w32_mul_bc16(float tab, float x)
+{
+    float out;
+    asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(out) : "v"(tab), "v"(x), "n"(N));
+    return out;
+}
+
+// bytes (b0, b1, b2, b3) of d -> the int16 pairs (b0, b1) and (b2, b3), sign-extended
+__device__ __forceinline__ void w32_bytes_to_pairs(unsigned d, int& lo, int& hi)
+{
+    w32_s16x2 l = __builtin_bit_cast(w32_s16x2, __builtin_amdgcn_perm(0u, d, 0x010C000Cu)); // (b0 << 8, b1 << 8)
+    w32_s16x2 h = __builtin_bit_cast(w32_s16x2, __builtin_amdgcn_perm(0u, d, 0x030C020Cu)); // (b2 << 8, b3 << 8)
+    l = l >> 8;
+    h = h >> 8;
+    lo = __builtin_bit_cast(int, l);
+    hi = __builtin_bit_cast(int, h);
+}
+
+// One column of the solve.  `row` = the table row of column RR (lane l: pair-dword l & 15).  NP = pairs in use.
+template <int NP, int RR, bool FAST, int... Ps>
+__device__ __forceinline__ void w32_col(const float a_r, int (&W)[16], const int row, const float rdv, const float dnv,
+                                        const GsParams& gp, bool& unsafe, std::integer_sequence<int, Ps...>)
+{
+    constexpr int PN = RR >= 1 ? (RR - 1) >> 1 : -1; // the pair that holds the column solved last
+    int accA = 0, accB = 0;
+    // the pairs whose values are older: two chains, off the column-to-column dependency
+    ((Ps != PN ? w32_dot2_bc16<Ps>((Ps & 1) ? accB : accA, row, W[Ps]) : (void)0), ...);
+    int s = accA + accB;
+    if constexpr (PN >= 0) w32_dot2_bc16<(PN >= 0 ? PN : 0)>(s, row, W[PN >= 0 ? PN : 0]);
+    const float num = (a_r - (float)s) + LRF_EPS;
+    float val;
+    if (FAST) {
+        const float q = w32_mul_bc16<RR & 15>(rdv, num);
+        const float nq = rintf(q);
+        const bool inside = fabsf(q) < gp.flimit;
+        unsafe |= inside && !(fabsf(q - nq) <= gp.fthr);
+        val = nq; // beyond flimit the clamp decides either way
+    } else {
+        val = rintf(num / get_bc16<RR & 15>(dnv));
+    }
+    const float u = __builtin_amdgcn_fmed3f(val, gp.lo, gp.hi);
+    const unsigned ub = __float_as_uint(u + 12582912.0f); // low 16 bits: u as int16
+    W[RR >> 1] = (int)((RR & 1) ? __builtin_amdgcn_perm(ub, (unsigned)W[RR >> 1], 0x05040100u)
+                                : __builtin_amdgcn_perm(ub, (unsigned)W[RR >> 1], 0x03020504u));
+}
+
+// All columns of one row.  tabl: this lane's column of the wave's LDS table (tabl[16 * r] = pair-dword l & 15 of row r);
+// rd0 / rd1: lane l = 1 / den[l & 15] and 1 / den[16 + (l & 15)] (1 for columns past R); dn0 / dn1: den likewise.
+template <int NP, bool FAST, int... Rs>
+__device__ __forceinline__ bool w32_solve(const float (&a)[32], int (&W)[16], const int* tabl, const float rd0, const float rd1,
+                                          const float dn0, const float dn1, const GsParams& gp, std::integer_sequence<int, Rs...>)
+{
+    bool unsafe = false;
+    int rows[2 * NP + 2];
+    rows[0] = tabl[0];
+    rows[1] = tabl[16];
+    ((rows[Rs + 2] = tabl[16 * (Rs + 2 < 32 ? Rs + 2 : 31)],
+      w32_col<NP, Rs, FAST>(a[Rs], W, rows[Rs], Rs < 16 ? rd0 : rd1, Rs < 16 ? dn0 : dn1, gp, unsafe, std::make_integer_sequence<int, NP>{})),
+     ...);
+    return unsafe;
+}
+
+// acc[T][i] (lane (li, lq)) = a[16T + li][4lq + i]  ->  out[4j + i] (lane L) = a[L][4j + i]   (w16_tiles_to_rows on a slice)
+__device__ __forceinline__ void w32_tiles_to_rows(const f32x4& a0, const f32x4& a1, const f32x4& a2, const f32x4& a3, float* out)
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        unsigned t0 = __float_as_uint(a0[i]), t1 = __float_as_uint(a1[i]);
+        unsigned t2 = __float_as_uint(a2[i]), t3 = __float_as_uint(a3[i]);
+        auto s01 = __builtin_amdgcn_permlane16_swap(t0, t1, false, false);
+        auto s23 = __builtin_amdgcn_permlane16_swap(t2, t3, false, false);
+        auto s02 = __builtin_amdgcn_permlane32_swap(s01[0], s23[0], false, false);
+        auto s13 = __builtin_amdgcn_permlane32_swap(s01[1], s23[1], false, false);
+        out[i] = __uint_as_float(s02[0]);
+        out[4 + i] = __uint_as_float(s13[0]);
+        out[8 + i] = __uint_as_float(s02[1]);
+        out[12 + i] = __uint_as_float(s13[1]);
+    }
+}
+
+// NP: pairs of rank columns in use (ceil(R / 2), 9..16); an odd R solves one padding column whose table row, a and result are zero
+template <int NP>
+__global__ __launch_bounds__(64 * LRF_BCDW32_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_bcd_w32(const float* __restrict__ X, const PlaneDesc* __restrict__ planes, const BlockDesc* __restrict__ blocks,
+               const float* __restrict__ Vf, const float* __restrict__ Bf, int8_t* __restrict__ U, float* __restrict__ Ppart,
+               float* __restrict__ Qpart, GsParams gp, int nblocks)
+{
+    extern __shared__ __attribute__((aligned(16))) float bcdw32_lds[]; // LRF_BCDW32_LDS bytes, per wave: X tile, int8 u, table
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int blk = blockIdx.x * LRF_BCDW32_WAVES + wave;
+    if (blk >= nblocks) return; // the waves of a workgroup never synchronise with each other
+    float* Xs = reinterpret_cast<float*>(reinterpret_cast<char*>(bcdw32_lds) + wave * LRF_BCDW32_WAVE_LDS);
+    int8_t* us8 = reinterpret_cast<int8_t*>(Xs + 64 * 64);
+    int* tab16 = reinterpret_cast<int*>(us8 + 64 * 32);
+    const BlockDesc bd = blocks[blk];
+    const PlaneDesc pd = planes[bd.plane];
+    const int R = pd.R; // 2 NP - 1 or 2 NP
+    const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
+    const float* Xp = X + pd.x_off + (long)bd.row0 * 64;
+    const float* Vp = Vf + (long)bd.plane * 64 * LRF_RPB;
+    const float* gt = Bf + (long)bd.plane * LRF_GTB_STRIDE;
+    int8_t* Ub = U + pd.u_off + (long)bd.row0 * R;
+    int nrows = pd.M - bd.row0;
+    if (nrows > LRF_KC) nrows = LRF_KC;
+    const int nsub = (nrows + 63) >> 6;
+
+    // A operand of a^T = V^T X^T, resident: va[t][s] = V[4s + lq][16 t + li] (columns >= R of the table are zero)
+    float va[2][16];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int s = 0; s < 16; s++) va[t][s] = Vp[(4 * s + lq) * LRF_RPB + 16 * t + li];
+    // the symmetric int16 table, diagonal zero: dword (r, p) = (b[r][2p], b[r][2p+1]); lane l builds dwords l, l + 64, ...
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int idx = e * 64 + lane, r = idx >> 4, c0 = 2 * (idx & 15), c1 = c0 + 1;
+        float b0 = 0.f, b1 = 0.f;
+        if (r < R && c0 < R && c0 != r) b0 = gt[c0 * LRF_GTB_LD + (r < c0 ? r : r - 1)]; // b[r][c0]: gt row c lists b[j][c], j != c
+        if (r < R && c1 < R && c1 != r) b1 = gt[c1 * LRF_GTB_LD + (r < c1 ? r : r - 1)];
+        tab16[idx] = ((int)b0 & 0xffff) | ((int)b1 << 16);
+    }
+    // 1 / den and den of the columns li and 16 + li (padding columns: 1)
+    const float dn0 = (li < R) ? gt[li * LRF_GTB_LD + LRF_GTB_DEN] : 1.f;
+    const float dn1 = (16 + li < R) ? gt[(16 + li) * LRF_GTB_LD + LRF_GTB_DEN] : 1.f;
+    const float rd0 = 1.0f / dn0, rd1 = 1.0f / dn1;
+    const int* tabl = tab16 + li;
+
+    // prefetch registers: xq[T][q] = X[r0 + 16T + 4q + lq][4li .. +3] (each load instruction: four whole rows, 1 KB);
+    // upre = the old int8 row of this lane: dword d from byte offset min(4d, R - 4).  Rows past the block's end: its last row.
+    f32x4 xq[4][4];
+    unsigned upre[8];
+    auto issue_x = [&](int t, int T0, int T1) {
+        const int r0 = t * 64;
+#pragma unroll
+        for (int T = T0; T < T1; T++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                int row = r0 + 16 * T + 4 * q + lq;
+                row = row < nrows ? row : nrows - 1;
+                xq[T][q] = *reinterpret_cast<const f32x4*>(Xp + (long)row * 64 + 4 * li);
+            }
+        }
+    };
+    auto issue_u = [&](int t) {
+        int row = t * 64 + lane;
+        row = row < nrows ? row : nrows - 1;
+        const int8_t* up = Ub + (long)row * R;
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
+            const int off = 4 * d < R - 4 ? 4 * d : R - 4; // wave-uniform
+            upre[d] = *reinterpret_cast<const u32_unaligned*>(up + off);
+        }
+    };
+    // the partial dword (index R / 4 when R is not a multiple of 4) was loaded from offset R - 4: its row bytes sit in its
+    // upper part.  Bytes at or past R hold neighbouring bytes of the row: harmless (their table entries are zero) and
+    // never stored (the solve writes every pair in use; the pairs past NP are cleared)
+    const int part_dw = (R & 3) ? (R >> 2) : 99, part_sh = 8 * (4 - (R & 3));
+
+    // B operand of a^T: X[16T + li][4s + lq] lives at byte (16T + li) * 256 + ((16 s) ^ (16 li)) + 4 lq of the tile
+    const char* xrow_b = reinterpret_cast<const char*>(Xs) + li * 256 + 4 * lq;
+    const int g16 = 16 * li;
+    // A operand of a' = X^T u, all four column tiles at once: chunk li of row 4s + lq (k_bcd_w)
+    const float* xp[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) xp[e] = &Xs[lq * 64 + 4 * (li ^ (4 * e + lq))];
+    // B operand of a' = X^T u and both operands of b' = u^T u: u[4s + lq][16 t + li], a byte of the int8 tile
+    const int8_t* ub8 = us8 + lq * 32 + li;
+
+    f32x4 accP[4][2];
+    i32x4 accQ[2][2];
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int t = 0; t < 2; t++) accP[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) accQ[i][j] = (i32x4){0, 0, 0, 0};
+
+    issue_x(0, 0, 4);
+    issue_u(0);
+    for (int t = 0; t < nsub; t++) {
+        const int r0 = t * 64;
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- 1. sub-tile -> LDS, next sub-tile's loads into the same registers (in bursts, as in k_bcd_w)
+#pragma unroll
+        for (int T = 0; T < 4; T++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int m = 16 * T + 4 * q + lq;
+                *reinterpret_cast<f32x4*>(&Xs[m * 64 + 4 * (li ^ (4 * q + lq))]) = xq[T][q];
+            }
+        int W0[16];
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
+            const unsigned w = (d == part_dw) ? (upre[d] >> part_sh) : upre[d];
+            w32_bytes_to_pairs(w, W0[2 * d], W0[2 * d + 1]);
+        }
+#pragma unroll
+        for (int p = NP; p < 16; p++) W0[p < 16 ? p : 15] = 0;
+        const int tn = t + 1;
+        const bool more = tn < nsub;
+        if (more) {
+            issue_x(tn, 0, 2);
+            issue_u(tn);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- 2. a^T = V^T X^T: eight independent chains of 16 MFMAs, then lane = row
+        float a[32];
+        {
+            f32x4 acc[4][2];
+#pragma unroll
+            for (int T = 0; T < 4; T++)
+#pragma unroll
+                for (int tt = 0; tt < 2; tt++) acc[T][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int h = 0; h < 4; h++) { // the operand reads in four quarters of 16 registers
+                float bx[4][4];
+#pragma unroll
+                for (int s = 0; s < 4; s++)
+#pragma unroll
+                    for (int T = 0; T < 4; T++)
+                        bx[s][T] = *reinterpret_cast<const float*>(xrow_b + T * 16 * 256 + ((16 * (4 * h + s)) ^ g16));
+#pragma unroll
+                for (int s = 0; s < 4; s++)
+#pragma unroll
+                    for (int T = 0; T < 4; T++)
+#pragma unroll
+                        for (int tt = 0; tt < 2; tt++)
+                            acc[T][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[tt][4 * h + s], bx[s][T], acc[T][tt], 0, 0, 0);
+            }
+            w32_tiles_to_rows(acc[0][0], acc[1][0], acc[2][0], acc[3][0], a);
+            w32_tiles_to_rows(acc[0][1], acc[1][1], acc[2][1], acc[3][1], a + 16);
+        }
+        if (more) issue_x(tn, 2, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- 3. Gauss-Seidel, lane = row, exact integers
+        int W[16];
+#pragma unroll
+        for (int p = 0; p < 16; p++) W[p] = W0[p];
+        if (__any(w32_solve<NP, true>(a, W, tabl, rd0, rd1, dn0, dn1, gp, std::make_integer_sequence<int, 2 * NP>{}))) {
+            // rare: repeat with the reference's IEEE division
+#pragma unroll
+            for (int p = 0; p < 16; p++) W[p] = W0[p];
+            w32_solve<NP, false>(a, W, tabl, rd0, rd1, dn0, dn1, gp, std::make_integer_sequence<int, 2 * NP>{});
+        }
+        // int16 pairs -> bytes: dword d = columns 4d .. 4d+3 (rows past the block's end: zero)
+        const int row = r0 + lane;
+        unsigned o[8];
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
+            o[d] = __builtin_amdgcn_perm((unsigned)W[2 * d + 1], (unsigned)W[2 * d], 0x06040200u);
+            if (row >= nrows) o[d] = 0u;
+        }
+        if (more) issue_x(tn, 3, 4);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- 4. the int8 row to LDS (operand of the partial products) and to global memory (R bytes)
+        *reinterpret_cast<uint4*>(us8 + lane * 32) = make_uint4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<uint4*>(us8 + lane * 32 + 16) = make_uint4(o[4], o[5], o[6], o[7]);
+        if (row < nrows) {
+            int8_t* uo = Ub + (long)row * R;
+#pragma unroll
+            for (int d = 0; d < 4; d++) *reinterpret_cast<u32_unaligned*>(uo + 4 * d) = o[d]; // R >= 16
+#pragma unroll
+            for (int d = 4; d < 8; d++)
+                if (4 * d + 4 <= R) *reinterpret_cast<u32_unaligned*>(uo + 4 * d) = o[d]; // wave-uniform
+            if (R & 3) { // bytes R-4 .. R-1: the tail of the last full dword and the head of the partial one
+                const int dl = R >> 2; // 4 .. 7
+                unsigned lo_w = o[3], hi_w = o[4];
+#pragma unroll
+                for (int d = 4; d < 8; d++)
+                    if (d == dl) {
+                        lo_w = o[d - 1];
+                        hi_w = o[d];
+                    }
+                *reinterpret_cast<u32_unaligned*>(uo + R - 4) = __builtin_amdgcn_alignbyte(hi_w, lo_w, (unsigned)(R & 3));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- 5. a' += X^T u (four strided column tiles per LDS read, two rank tiles), b' += u^T u on the int8 matrix cores
+        {
+            int ui[2][16];
+#pragma unroll
+            for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+                for (int s = 0; s < 16; s++) ui[tt][s] = (int)ub8[128 * s + 16 * tt];
+            i32x4 qa[2];
+#pragma unroll
+            for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    const unsigned p01 = __builtin_amdgcn_perm((unsigned)ui[tt][4 * d + 1], (unsigned)ui[tt][4 * d], 0x0C0C0400u);
+                    const unsigned p23 = __builtin_amdgcn_perm((unsigned)ui[tt][4 * d + 3], (unsigned)ui[tt][4 * d + 2], 0x04000C0Cu);
+                    qa[tt][d] = (int)(p01 | p23);
+                }
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) accQ[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(qa[i], qa[j], accQ[i][j], 0, 0, 0);
+#pragma unroll
+            for (int h = 0; h < 4; h++) {
+                f32x4 px[4];
+#pragma unroll
+                for (int s = 0; s < 4; s++) px[s] = *reinterpret_cast<const f32x4*>(xp[s & 3] + 256 * (4 * h + s));
+#pragma unroll
+                for (int s = 0; s < 4; s++)
+#pragma unroll
+                    for (int tt = 0; tt < 2; tt++) {
+                        const float pu = (float)ui[tt][4 * h + s];
+#pragma unroll
+                        for (int c = 0; c < 4; c++) accP[c][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(px[s][c], pu, accP[c][tt], 0, 0, 0);
+                    }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // a' partial: tile c holds the columns 4 i + c: D[i = 4*lq + reg][j = li (r)] -> a'[4 i + c][16 t + li]
+    const long slot = (long)pd.blk0 + bd.blk;
+    float* Pp = Ppart + slot * 64 * LRF_RPB;
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) Pp[(4 * (4 * lq + reg) + c) * LRF_RPB + 16 * tt + li] = accP[c][tt][reg];
+    // b' partial: D[i = 4*lq + reg][j = li] of tile (ti, tj), exact integers (below 384 mx^2)
+    float* Qp = Qpart + slot * LRF_RPB * LRF_RPB;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) Qp[(16 * i + 4 * lq + reg) * LRF_RPB + 16 * j + li] = (float)accQ[i][j][reg];
+}

@@ -183,3 +183,31 @@ def test_wave_kernel_for_ranks_9_to_16_equals_workgroup_kernel_and_oracle(oracle
         for c in range(3):
             u, v = oracle.qmf_decompose(X[c], ranks[c], 4, bounds)
             assert np.array_equal(got[2 * c], u.astype(np.int8)) and np.array_equal(got[2 * c + 1], v.astype(np.int8)), (ranks, bounds, c)
+
+
+@pytest.mark.parametrize("hw_b", [(173, 264, 272), (512, 768, 48)])
+def test_wave_kernel_for_ranks_17_to_32_equals_workgroup_kernel_and_oracle(oracle, hw_b):
+    """k_bcd_w32 (one wave per 384-row block, lane = row Gauss-Seidel on int16 pairs; lrf_bcdw32_kernel.hip) takes the
+    iterations >= 2 of a run whose planes all have ranks 17..32 once the run has 1024 blocks, k_bcd_mid below that: 272
+    ragged 173x264 images (4 blocks each, the last sub-tile of a block 22 rows) and 48 images of 512x768 (24 blocks each)
+    against chunks of 8 of the same images, bit for bit, and against the oracle on one image; every rank 17..32 appears in
+    some plane (odd ranks solve a padding column; ranks that are not multiples of four load and store a partial dword),
+    with the default and a narrow asymmetric bound."""
+    import lrf_amd
+    from lrf_amd.codec import split_factors
+    H, W, B = hw_b
+    g = torch.Generator().manual_seed(6)
+    base = torch.rand(B, 3, H // 8, W // 8, generator=g) * 255
+    imgs = (torch.nn.functional.interpolate(base, size=(H, W), mode="bilinear", align_corners=False)
+            + torch.randn(B, 3, H, W, generator=g) * 6).clamp(0, 255).to(torch.uint8).cuda()
+    for ranks, bounds in (((17, 18, 19), (-16, 15)), ((20, 21, 22), (-3, 5)), ((23, 24, 25), (-16, 15)), ((26, 27, 28), (-16, 15)),
+                          ((29, 30, 31), (-16, 15)), ((32, 17, 32), (-3, 5)), ((32, 32, 32), (-16, 15)), ((21, 21, 21), (-22, 22))):
+        U, V = lrf_amd.qmf_factorize_batch(imgs, ranks, num_iters=4, bounds=bounds)
+        for b0 in (0, B - 8):
+            Us, Vs = lrf_amd.qmf_factorize_batch(imgs[b0:b0 + 8].clone(), ranks, num_iters=4, bounds=bounds)
+            assert torch.equal(U[b0:b0 + 8], Us) and torch.equal(V[b0:b0 + 8], Vs), (ranks, bounds, b0)
+        X = oracle.rgb_to_planes(imgs[B - 1].cpu().numpy())
+        got = split_factors(U[B - 1].cpu().numpy(), V[B - 1].cpu().numpy(), (H, W), ranks)
+        for c in range(3):
+            u, v = oracle.qmf_decompose(X[c], ranks[c], 4, bounds)
+            assert np.array_equal(got[2 * c], u.astype(np.int8)) and np.array_equal(got[2 * c + 1], v.astype(np.int8)), (ranks, bounds, c)
