@@ -541,7 +541,7 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
         HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_mid<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MidLds<0>)));
         HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_mid<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MidLds<1>)));
         HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_mid<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MidLds<2>)));
-#define LRF_W32_ATTR(NP) HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_w32<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, LRF_BCDW32_LDS))
+#define LRF_W32_ATTR(NP) HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_w32<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, LRF_BCDW32_LDS(NP)))
         LRF_W32_ATTR(9); LRF_W32_ATTR(10); LRF_W32_ATTR(11); LRF_W32_ATTR(12); LRF_W32_ATTR(13); LRF_W32_ATTR(14); LRF_W32_ATTR(15); LRF_W32_ATTR(16);
 #undef LRF_W32_ATTR
         c->attr_done |= 1u << 2;
@@ -591,7 +591,7 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
                     // ranks 17..32, iterations >= 2, exact-integer bounds with |b| within int16: one wave per block, lane = row
                     // Gauss-Seidel on int16 pairs (lrf_bcdw32_kernel.hip)
 #define LRF_LAUNCH_W32(NP)                                                                                           \
-    hipLaunchKernelGGL((k_bcd_w32<NP>), dim3((nbr + LRF_BCDW32_WAVES - 1) / LRF_BCDW32_WAVES), dim3(64 * LRF_BCDW32_WAVES), LRF_BCDW32_LDS, \
+    hipLaunchKernelGGL((k_bcd_w32<NP>), dim3((nbr + LRF_BCDW32_WAVES - 1) / LRF_BCDW32_WAVES), dim3(64 * LRF_BCDW32_WAVES), LRF_BCDW32_LDS(NP), \
                        rs, X, pl, blr, (const float*)fb.vf, (const float*)fb.bf, U, fb.pp, fb.qp, gpr, nbr)
                     switch ((r.rmax + 1) >> 1) {
                     case 9: LRF_LAUNCH_W32(9); break;

@@ -28,10 +28,20 @@
 // 20 KB of LDS per wave (X tile 16 KB, int8 u tile 2 KB, int16 table 2 KB): two 4-wave workgroups fill a CU's 160 KB.
 
 #define LRF_BCDW32_WAVES 4
-#define LRF_BCDW32_WAVE_LDS (64 * 64 * 4 + 64 * 32 + 32 * 16 * 4)
-#define LRF_BCDW32_LDS (LRF_BCDW32_WAVES * LRF_BCDW32_WAVE_LDS)
+#define LRF_BCDW32_WAVE_LDS(NP) (64 * 64 * 4 + 64 * 32 + 2 * (NP) * 16 * 4) // the table rows past 2 NP are never read
+#define LRF_BCDW32_LDS(NP) (LRF_BCDW32_WAVES * LRF_BCDW32_WAVE_LDS(NP))
 
 typedef short w32_s16x2 __attribute__((ext_vector_type(2)));
+
+// diagnostic stamps of this kernel: -DLRF_STAMPS -DLRF_W32_STAMPS (tools/dev_stamps_w32.py; never the shipped library)
+#if defined(LRF_STAMPS) && defined(LRF_W32_STAMPS)
+#define W32STAMP(var) STAMP(var)
+#define W32STAMP_ADD(acc, a, b) STAMP_ADD(acc, a, b)
+#else
+#undef LRF_W32_STAMPS
+#define W32STAMP(var)
+#define W32STAMP_ADD(acc, a, b)
+#endif
 
 // acc += dot2(tab[lane N of each 16-lane row], w): both int16 pairs
 template <int N>
@@ -59,9 +69,14 @@ __device__ __forceinline__ void w32_bytes_to_pairs(unsigned d, int& lo, int& hi)
 }
 
 // One column of the solve.  `row` = the table row of column RR (lane l: pair-dword l & 15).  NP = pairs in use.
+// FAST: q~ = num * (1/den); q~ + 1.5 * 2^23 rounds it to the nearest-even integer n in the mantissa (|q~| < 2^22; beyond
+// that the bit pattern still orders like q~, so the integer clamp decides), the clamp is a v_med3_i32 on the bit pattern
+// against (magic + lo, magic + hi) and the low 16 bits are the int16 to store.  emax gathers |q~ - n|: above gp.fthr for
+// some column (or a |q~| >= 2^22, where n is not its rounding) the caller repeats the sub-tile with the IEEE division
+// (gs_row's argument: q~ is within 3 ulp of fl(num / den), so unless it sits that close to a tie both round alike).
 template <int NP, int RR, bool FAST, int... Ps>
 __device__ __forceinline__ void w32_col(const float a_r, int (&W)[16], const int row, const float rdv, const float dnv,
-                                        const GsParams& gp, bool& unsafe, std::integer_sequence<int, Ps...>)
+                                        const GsParams& gp, const int lob, const int hib, float& emax, std::integer_sequence<int, Ps...>)
 {
     constexpr int PN = RR >= 1 ? (RR - 1) >> 1 : -1; // the pair that holds the column solved last
     int accA = 0, accB = 0;
@@ -70,18 +85,19 @@ __device__ __forceinline__ void w32_col(const float a_r, int (&W)[16], const int
     int s = accA + accB;
     if constexpr (PN >= 0) w32_dot2_bc16<(PN >= 0 ? PN : 0)>(s, row, W[PN >= 0 ? PN : 0]);
     const float num = (a_r - (float)s) + LRF_EPS;
-    float val;
+    unsigned ub;
     if (FAST) {
         const float q = w32_mul_bc16<RR & 15>(rdv, num);
-        const float nq = rintf(q);
-        const bool inside = fabsf(q) < gp.flimit;
-        unsafe |= inside && !(fabsf(q - nq) <= gp.fthr);
-        val = nq; // beyond flimit the clamp decides either way
+        const float t = q + 12582912.0f;
+        emax = fmaxf(emax, fabsf(q - (t - 12582912.0f)));
+        int c;
+        asm("v_med3_i32 %0, %1, %2, %3" : "=v"(c) : "v"(__float_as_int(t)), "s"(lob), "v"(hib));
+        ub = (unsigned)c;
     } else {
-        val = rintf(num / get_bc16<RR & 15>(dnv));
+        const float val = rintf(num / get_bc16<RR & 15>(dnv));
+        const float u = __builtin_amdgcn_fmed3f(val, gp.lo, gp.hi);
+        ub = __float_as_uint(u + 12582912.0f); // low 16 bits: u as int16
     }
-    const float u = __builtin_amdgcn_fmed3f(val, gp.lo, gp.hi);
-    const unsigned ub = __float_as_uint(u + 12582912.0f); // low 16 bits: u as int16
     W[RR >> 1] = (int)((RR & 1) ? __builtin_amdgcn_perm(ub, (unsigned)W[RR >> 1], 0x05040100u)
                                 : __builtin_amdgcn_perm(ub, (unsigned)W[RR >> 1], 0x03020504u));
 }
@@ -92,14 +108,15 @@ template <int NP, bool FAST, int... Rs>
 __device__ __forceinline__ bool w32_solve(const float (&a)[32], int (&W)[16], const int* tabl, const float rd0, const float rd1,
                                           const float dn0, const float dn1, const GsParams& gp, std::integer_sequence<int, Rs...>)
 {
-    bool unsafe = false;
+    float emax = 0.f;
+    const int lob = 0x4B400000 + (int)gp.lo, hib = 0x4B400000 + (int)gp.hi;
     int rows[2 * NP + 2];
     rows[0] = tabl[0];
     rows[1] = tabl[16];
-    ((rows[Rs + 2] = tabl[16 * (Rs + 2 < 32 ? Rs + 2 : 31)],
-      w32_col<NP, Rs, FAST>(a[Rs], W, rows[Rs], Rs < 16 ? rd0 : rd1, Rs < 16 ? dn0 : dn1, gp, unsafe, std::make_integer_sequence<int, NP>{})),
+    ((rows[Rs + 2] = tabl[16 * (Rs + 2 < 2 * NP ? Rs + 2 : 2 * NP - 1)],
+      w32_col<NP, Rs, FAST>(a[Rs], W, rows[Rs], Rs < 16 ? rd0 : rd1, Rs < 16 ? dn0 : dn1, gp, lob, hib, emax, std::make_integer_sequence<int, NP>{})),
      ...);
-    return unsafe;
+    return FAST && !(emax <= gp.fthr);
 }
 
 // acc[T][i] (lane (li, lq)) = a[16T + li][4lq + i]  ->  out[4j + i] (lane L) = a[L][4j + i]   (w16_tiles_to_rows on a slice)
@@ -132,7 +149,7 @@ void k_bcd_w32(const float* __restrict__ X, const PlaneDesc* __restrict__ planes
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int blk = blockIdx.x * LRF_BCDW32_WAVES + wave;
     if (blk >= nblocks) return; // the waves of a workgroup never synchronise with each other
-    float* Xs = reinterpret_cast<float*>(reinterpret_cast<char*>(bcdw32_lds) + wave * LRF_BCDW32_WAVE_LDS);
+    float* Xs = reinterpret_cast<float*>(reinterpret_cast<char*>(bcdw32_lds) + wave * LRF_BCDW32_WAVE_LDS(NP));
     int8_t* us8 = reinterpret_cast<int8_t*>(Xs + 64 * 64);
     int* tab16 = reinterpret_cast<int*>(us8 + 64 * 32);
     const BlockDesc bd = blocks[blk];
@@ -160,7 +177,7 @@ void k_bcd_w32(const float* __restrict__ X, const PlaneDesc* __restrict__ planes
         float b0 = 0.f, b1 = 0.f;
         if (r < R && c0 < R && c0 != r) b0 = gt[c0 * LRF_GTB_LD + (r < c0 ? r : r - 1)]; // b[r][c0]: gt row c lists b[j][c], j != c
         if (r < R && c1 < R && c1 != r) b1 = gt[c1 * LRF_GTB_LD + (r < c1 ? r : r - 1)];
-        tab16[idx] = ((int)b0 & 0xffff) | ((int)b1 << 16);
+        if (r < 2 * NP) tab16[idx] = (int)(((unsigned)(int)b0 & 0xffffu) | ((unsigned)(int)b1 << 16));
     }
     // 1 / den and den of the columns li and 16 + li (padding columns: 1)
     const float dn0 = (li < R) ? gt[li * LRF_GTB_LD + LRF_GTB_DEN] : 1.f;
@@ -172,7 +189,9 @@ void k_bcd_w32(const float* __restrict__ X, const PlaneDesc* __restrict__ planes
     // upre = the old int8 row of this lane: dword d from byte offset min(4d, R - 4).  Rows past the block's end: its last row.
     f32x4 xq[4][4];
     unsigned upre[8];
-    auto issue_x = [&](int t, int T0, int T1) {
+    // `live` false (no next sub-tile): the registers are cleared instead — a load under a bare `if` would keep their old
+    // values alive across the whole body (76 spilled registers at NP = 16)
+    auto issue_x = [&](int t, int T0, int T1, bool live) {
         const int r0 = t * 64;
 #pragma unroll
         for (int T = T0; T < T1; T++) {
@@ -180,18 +199,20 @@ void k_bcd_w32(const float* __restrict__ X, const PlaneDesc* __restrict__ planes
             for (int q = 0; q < 4; q++) {
                 int row = r0 + 16 * T + 4 * q + lq;
                 row = row < nrows ? row : nrows - 1;
-                xq[T][q] = *reinterpret_cast<const f32x4*>(Xp + (long)row * 64 + 4 * li);
+                if (live) xq[T][q] = *reinterpret_cast<const f32x4*>(Xp + (long)row * 64 + 4 * li);
+                else xq[T][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
     };
-    auto issue_u = [&](int t) {
+    auto load_u = [&](int t, unsigned (&w)[8], bool live) {
         int row = t * 64 + lane;
         row = row < nrows ? row : nrows - 1;
         const int8_t* up = Ub + (long)row * R;
 #pragma unroll
         for (int d = 0; d < 8; d++) {
             const int off = 4 * d < R - 4 ? 4 * d : R - 4; // wave-uniform
-            upre[d] = *reinterpret_cast<const u32_unaligned*>(up + off);
+            if (live) w[d] = *reinterpret_cast<const u32_unaligned*>(up + off);
+            else w[d] = 0u;
         }
     };
     // the partial dword (index R / 4 when R is not a multiple of 4) was loaded from offset R - 4: its row bytes sit in its
@@ -220,11 +241,21 @@ void k_bcd_w32(const float* __restrict__ X, const PlaneDesc* __restrict__ planes
 #pragma unroll
         for (int j = 0; j < 2; j++) accQ[i][j] = (i32x4){0, 0, 0, 0};
 
-    issue_x(0, 0, 4);
-    issue_u(0);
+#ifdef LRF_W32_STAMPS
+    unsigned long long c_w1 = 0, c_w2 = 0, c_w3 = 0, c_w4 = 0, c_w5 = 0, c_w6 = 0, c_w7 = 0;
+#endif
+    W32STAMP(t_begin);
+    issue_x(0, 0, 4, true);
+    load_u(0, upre, true);
     for (int t = 0; t < nsub; t++) {
         const int r0 = t * 64;
+        W32STAMP(s0);
+#ifdef LRF_W32_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         __builtin_amdgcn_sched_barrier(0);
+        W32STAMP(s1);
+        W32STAMP_ADD(c_w1, s0, s1); // wait for the prefetch
         // ---- 1. sub-tile -> LDS, next sub-tile's loads into the same registers (in bursts, as in k_bcd_w)
 #pragma unroll
         for (int T = 0; T < 4; T++)
@@ -233,26 +264,32 @@ void k_bcd_w32(const float* __restrict__ X, const PlaneDesc* __restrict__ planes
                 const int m = 16 * T + 4 * q + lq;
                 *reinterpret_cast<f32x4*>(&Xs[m * 64 + 4 * (li ^ (4 * q + lq))]) = xq[T][q];
             }
-        int W0[16];
+        int W[16];
+        auto row_to_pairs = [&](const unsigned (&w8)[8]) {
 #pragma unroll
-        for (int d = 0; d < 8; d++) {
-            const unsigned w = (d == part_dw) ? (upre[d] >> part_sh) : upre[d];
-            w32_bytes_to_pairs(w, W0[2 * d], W0[2 * d + 1]);
-        }
+            for (int d = 0; d < 8; d++) {
+                const unsigned w = (d == part_dw) ? (w8[d] >> part_sh) : w8[d];
+                w32_bytes_to_pairs(w, W[2 * d], W[2 * d + 1]);
+            }
 #pragma unroll
-        for (int p = NP; p < 16; p++) W0[p < 16 ? p : 15] = 0;
+            for (int p = NP; p < 16; p++) W[p < 16 ? p : 15] = 0;
+        };
+        row_to_pairs(upre);
         const int tn = t + 1;
         const bool more = tn < nsub;
-        if (more) {
-            issue_x(tn, 0, 2);
-            issue_u(tn);
-        }
+        issue_x(tn, 0, 1, more);
+        load_u(tn, upre, more);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_sched_barrier(0);
+        W32STAMP(s2);
+        W32STAMP_ADD(c_w2, s1, s2); // LDS stores, old row -> pairs, prefetch issue
         // ---- 2. a^T = V^T X^T: eight independent chains of 16 MFMAs, then lane = row
         float a[32];
+#ifdef LRF_W32_STAMPS
+        unsigned long long s3 = 0;
+#endif
         {
             f32x4 acc[4][2];
 #pragma unroll
@@ -275,19 +312,28 @@ void k_bcd_w32(const float* __restrict__ X, const PlaneDesc* __restrict__ planes
                         for (int tt = 0; tt < 2; tt++)
                             acc[T][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[tt][4 * h + s], bx[s][T], acc[T][tt], 0, 0, 0);
             }
+#ifdef LRF_W32_STAMPS
+            asm volatile("" ::"v"(acc[3][1][3]), "v"(acc[0][0][0]));
+            s3 = stamp_now();
+            W32STAMP_ADD(c_w3, s2, s3); // operand reads + 128 MFMAs
+#endif
             w32_tiles_to_rows(acc[0][0], acc[1][0], acc[2][0], acc[3][0], a);
             w32_tiles_to_rows(acc[0][1], acc[1][1], acc[2][1], acc[3][1], a + 16);
         }
-        if (more) issue_x(tn, 2, 3);
+        issue_x(tn, 1, 2, more);
         __builtin_amdgcn_sched_barrier(0);
+#ifdef LRF_W32_STAMPS
+        asm volatile("" ::"v"(a[31]), "v"(a[0]));
+        W32STAMP(s4);
+        W32STAMP_ADD(c_w4, s3, s4); // tiles -> rows
+#endif
         // ---- 3. Gauss-Seidel, lane = row, exact integers
-        int W[16];
-#pragma unroll
-        for (int p = 0; p < 16; p++) W[p] = W0[p];
         if (__any(w32_solve<NP, true>(a, W, tabl, rd0, rd1, dn0, dn1, gp, std::make_integer_sequence<int, 2 * NP>{}))) {
-            // rare: repeat with the reference's IEEE division
-#pragma unroll
-            for (int p = 0; p < 16; p++) W[p] = W0[p];
+            // rare: repeat with the reference's IEEE division; the old row is read again (its stores come after the solve)
+            // rather than kept in sixteen registers across the solve
+            unsigned wr[8];
+            load_u(t, wr, true);
+            row_to_pairs(wr);
             w32_solve<NP, false>(a, W, tabl, rd0, rd1, dn0, dn1, gp, std::make_integer_sequence<int, 2 * NP>{});
         }
         // int16 pairs -> bytes: dword d = columns 4d .. 4d+3 (rows past the block's end: zero)
@@ -298,8 +344,13 @@ void k_bcd_w32(const float* __restrict__ X, const PlaneDesc* __restrict__ planes
             o[d] = __builtin_amdgcn_perm((unsigned)W[2 * d + 1], (unsigned)W[2 * d], 0x06040200u);
             if (row >= nrows) o[d] = 0u;
         }
-        if (more) issue_x(tn, 3, 4);
+        issue_x(tn, 2, 4, more);
         __builtin_amdgcn_sched_barrier(0);
+#ifdef LRF_W32_STAMPS
+        asm volatile("" ::"v"(o[7]), "v"(o[0]));
+        W32STAMP(s5);
+        W32STAMP_ADD(c_w5, s4, s5); // Gauss-Seidel + pack
+#endif
         // ---- 4. the int8 row to LDS (operand of the partial products) and to global memory (R bytes)
         *reinterpret_cast<uint4*>(us8 + lane * 32) = make_uint4(o[0], o[1], o[2], o[3]);
         *reinterpret_cast<uint4*>(us8 + lane * 32 + 16) = make_uint4(o[4], o[5], o[6], o[7]);
@@ -326,6 +377,8 @@ void k_bcd_w32(const float* __restrict__ X, const PlaneDesc* __restrict__ planes
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_sched_barrier(0);
+        W32STAMP(s6);
+        W32STAMP_ADD(c_w6, s5, s6); // u -> LDS, int8 stores
         // ---- 5. a' += X^T u (four strided column tiles per LDS read, two rank tiles), b' += u^T u on the int8 matrix cores
         {
             int ui[2][16];
@@ -362,10 +415,22 @@ void k_bcd_w32(const float* __restrict__ X, const PlaneDesc* __restrict__ planes
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+#ifdef LRF_W32_STAMPS
+        asm volatile("" ::"v"(accP[3][1][3]), "v"(accP[0][0][0]), "v"(accQ[1][1][3]));
+        W32STAMP(s7);
+        W32STAMP_ADD(c_w7, s6, s7); // P / Q MFMAs
+#endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+#ifdef LRF_W32_STAMPS
+    if (lane == 0 && blk < 16384) {
+        W32STAMP(t_end);
+        unsigned long long* o = g_stamps + 8 * blk;
+        o[0] = t_end - t_begin; o[1] = c_w1; o[2] = c_w2; o[3] = c_w3; o[4] = c_w4; o[5] = c_w5; o[6] = c_w6; o[7] = c_w7;
+    }
+#endif
     // a' partial: tile c holds the columns 4 i + c: D[i = 4*lq + reg][j = li (r)] -> a'[4 i + c][16 t + li]
     const long slot = (long)pd.blk0 + bd.blk;
     float* Pp = Ppart + slot * 64 * LRF_RPB;
