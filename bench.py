@@ -20,6 +20,13 @@ Next to `value` (inputs and outputs in HBM) the line carries SURVEY 8(d)'s host-
 Either way rank 0 refuses to print a line unless the process group really has --gpus ranks (`rccl_ranks` in the line).
 `value` is the HBM-resident rate (`value_definition`); the timed region of K steps is repeated `timed_regions` times and
 `ms_per_step` / `value` are the MEDIAN region's (min / max beside it).
+Before torch is imported every rank binds itself to the CPUs of its GPU's NUMA node (lrf_amd/placement.py; `ranks[].numa`
+says what happened; LRF_BENCH_NO_BIND=1 turns it off).  LRF_BENCH_FORCE_DIST=1 initialises the process group at world
+size 1 too, so that the RCCL calls of the N > 1 path (init with device_id, float64 all_reduce(MAX) on a device tensor,
+barrier, all_gather, destroy) can be executed on a one-GPU box (tests/test_a_two_rank_gpu.py).
+SURVEY 8(d) also asks for the rate to final BYTES (lrf.qmf_encode returns bytes, lrf/compression/qmf.py:288-292):
+`end_to_end_bytes_mpix_s` (page-locked uint8 batch -> zlib-9 byte streams in host memory, through the pipelined encoder
+and liblrf_pack.so on `packer_threads` host threads) and `zlib_ms_per_step` (the container packing alone).
 """
 import argparse
 import json
@@ -93,6 +100,14 @@ def _usable_cores():
     return cores
 
 
+_JOB_CORES = None
+
+
+def _usable_cores_job():
+    """usable cores of the whole job as seen when the process started (before any NUMA binding of this rank)"""
+    return _JOB_CORES if _JOB_CORES is not None else _usable_cores()
+
+
 def cpu_baseline(images_u8, H, W, ranks, budget_s=12.0, budget_all_s=10.0):
     """The oracle (CPU port of the reference arithmetic) on a bounded sample of the same batch: one thread (`value`),
     then one thread per usable core (`all_cores`; the oracle is C behind ctypes, which releases the GIL, so plain
@@ -136,13 +151,12 @@ def cpu_baseline(images_u8, H, W, ranks, budget_s=12.0, budget_all_s=10.0):
             "cpu": _cpu_model(), "host_cores": os.cpu_count()}
 
 
-def host_to_host(torch, dist, _lib, dev_index, images, H, W, ranks, steps, warmup, world, cdev, repeats=5):
+def host_to_host(torch, dist, _lib, dev_index, images, host, H, W, ranks, steps, warmup, use_dist, cdev, repeats=5):
     """SURVEY 8(d)'s metric: uint8 batch in page-locked host memory -> int8 factors back in host memory, through the
     pipelined encoder (lrf_pipe: sub-batches on an upload stream and two kernel streams, H2D / kernels / D2H overlapped).
     With N > 1 every rank runs the leg on its own page-locked buffers (allocated by this rank's thread, the one bound
     to its GPU) between two barriers; the whole-job rate is all ranks' pixels over the slowest rank's time."""
     B = images.shape[0]
-    host = images.cpu().pin_memory()
     dims = _lib.plane_dims(H, W)
     Uh = torch.empty((B, sum(d[4] * r for d, r in zip(dims, ranks))), dtype=torch.int8, pin_memory=True)
     Vh = torch.empty((B, 64 * sum(ranks)), dtype=torch.int8, pin_memory=True)
@@ -152,7 +166,7 @@ def host_to_host(torch, dist, _lib, dev_index, images, H, W, ranks, steps, warmu
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     def region(fn):
@@ -162,7 +176,7 @@ def host_to_host(torch, dist, _lib, dev_index, images, H, W, ranks, steps, warmu
             fn()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             t = torch.tensor([dt], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -185,7 +199,7 @@ def host_to_host(torch, dist, _lib, dev_index, images, H, W, ranks, steps, warmu
     pipe.close()
     del dst
     px = float(B * H * W)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([px], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         px = float(t.item())
@@ -200,6 +214,60 @@ def host_to_host(torch, dist, _lib, dev_index, images, H, W, ranks, steps, warmu
             "frac_of_h2d_copy_alone": round(dt_copy / dt, 4),
             "pipe": {"slots": slots, "sub_batch": sub or "auto",
                      "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}}, (Uh, Vh)
+
+
+def bytes_out_leg(torch, dist, lrf_amd, host, Uh, Vh, H, W, ranks, threads, use_dist, cdev, repeats=3):
+    """SURVEY 8(d) "and also end-to-end": the page-locked uint8 batch -> the reference's byte streams (one per image) in
+    host memory.  The factorisation streams through the pipelined encoder; the container of each finished piece (metadata
+    JSON, per-column zlib level 9, length-prefixed blobs: lrf/compression/utils.py:246-455) is packed by liblrf_pack.so on
+    `threads` host threads while the GPU works on the next piece.  Also the packing alone, on factors already in host
+    memory.  With N > 1 every rank runs the leg on its own share of the host's cores; the whole-job rate is all ranks'
+    pixels over the slowest rank's time."""
+    from lrf_amd.codec import pack_streams_native
+    B = host.shape[0]
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+
+    def timed(fn):
+        sync_all()
+        t0 = time.perf_counter()
+        out = fn()
+        dt = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([dt], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, out
+
+    def encode():
+        return lrf_amd.qmf_encode_batch(host, rank=ranks[0], bounds=BOUNDS, num_iters=NUM_ITERS, pack_workers=threads)
+
+    encode()  # warm: packer threads started, pipe buffers allocated
+    e2e = [timed(encode) for _ in range(repeats)]
+    streams = e2e[-1][1]
+    dt = timed_stats([d for d, _ in e2e])[1]
+    Un, Vn = Uh.numpy(), Vh.numpy()
+    packs = [timed(lambda: pack_streams_native(Un, Vn, (H, W), ranks, BOUNDS, (8, 8), "uint8", threads=threads)) for _ in range(repeats)]
+    assert packs[-1][1] == streams, "the pipelined encoder's streams differ from the streams packed from the one-shot factors"
+    dt_pack = timed_stats([d for d, _ in packs])[1]
+    px = float(B * H * W)
+    nbytes = float(sum(len(x) for x in streams))
+    if use_dist:
+        t = torch.tensor([px, nbytes], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        px, nbytes = float(t[0].item()), float(t[1].item())
+    return {"end_to_end_bytes_mpix_s": round(px / dt / 1e6, 1), "end_to_end_bytes_ms_per_step": round(dt * 1e3, 3),
+            "zlib_ms_per_step": round(dt_pack * 1e3, 3), "packer_threads": threads,
+            "zlib_core_seconds_per_step": round(dt_pack * threads, 4),
+            "bits_per_pixel": round(nbytes * 8 / px, 4),
+            "end_to_end_note": "page-locked uint8 batch -> one zlib-9 byte stream per image in host memory (what lrf.qmf_encode "
+                               "returns), median of %d calls, slowest rank; zlib_ms_per_step = liblrf_pack.so alone on the "
+                               "finished factors of the batch (per-column zlib level 9 is host work and the user-visible "
+                               "bottleneck: compare host_to_host_ms_per_step; it scales with the host cores the job may use — "
+                               "packer_threads is this rank's share of the cgroup quota / affinity mask)" % repeats}
 
 
 def decode_leg(torch, _lib, ctx, U, V, H, W, ranks, steps):
@@ -304,6 +372,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the host->host, decode and CPU legs")
     args = ap.parse_args()
     assert args.gpus >= 1 and args.steps >= 1 and args.regions >= 1
+    global _JOB_CORES
+    _JOB_CORES = _usable_cores()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher: start the ranks ourselves, BEFORE torch is imported or a GPU touched in this process
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
@@ -312,12 +382,27 @@ def main():
     if os.environ.get("LRF_BENCH_SELF_LAUNCHED") == "1":
         print(f"[bench] rank {os.environ.get('RANK')} of {os.environ.get('WORLD_SIZE')} started (pid {os.getpid()})", file=sys.stderr, flush=True)
 
-    import torch
-    import torch.distributed as dist
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    rehearsal_env = os.environ.get("LRF_BENCH_REHEARSAL") == "1"
+    # CPU placement BEFORE torch is imported: the threads torch / HIP / liblrf_pack.so start and the page-locked buffers this
+    # thread touches first then sit on the NUMA node of this rank's GPU (lrf_amd/placement.py, loaded by path: importing
+    # the package would import torch)
+    if os.environ.get("LRF_BENCH_NO_BIND") == "1" or rehearsal_env:
+        binding = {"bound": False, "reason": "off (LRF_BENCH_NO_BIND / rehearsal)", "numa_node": -1, "cpus": _usable_cores()}
+    else:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("lrf_placement", os.path.join(ROOT, "lrf_amd", "placement.py"))
+        placement = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(placement)
+        binding = placement.bind_to_gpu_numa(local_rank)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    # host threads of this rank's container packer: its share of the cores the job may use (cgroup quota / affinity)
+    packer_threads = max(1, min(_usable_cores(), _usable_cores_job() // max(local_world, 1)))
+
+    import torch
+    import torch.distributed as dist
     assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}: the launcher's rank count and --gpus must agree"
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     # LRF_BENCH_REHEARSAL=1: development aid for boxes with fewer GPUs than ranks — ranks share the visible GPUs and the
@@ -330,8 +415,14 @@ def main():
     dev = torch.device("cuda", dev_index)
     cdev = torch.device("cpu") if rehearsal else dev  # where the collective payloads live
     backend = None
-    if world > 1:
+    force_dist = os.environ.get("LRF_BENCH_FORCE_DIST") == "1"
+    use_dist = world > 1 or force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:  # forced: a process group of one rank, so that the RCCL code path of the N > 1 runs executes here
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         backend = "gloo" if rehearsal else "nccl"
         if rehearsal:
             dist.init_process_group("gloo")
@@ -370,7 +461,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     # Set-up, before the W warm-up steps: the first call allocates the workspace and uploads the descriptor tables
@@ -385,15 +476,17 @@ def main():
     # the launching stream: an event pair costs stream time (0.15 ms per step when all 22 launches are bracketed).
     ctx.profile_kernels([_lib.LRF_K_BCD])
     ctx.profile_reset()
-    region_s = []
+    region_s, own_s = [], []
     for _ in range(args.regions):  # each region: barrier + synchronize, EXACTLY --steps steps, synchronize + barrier
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
+        torch.cuda.synchronize()
+        own_s.append(time.perf_counter() - t0)  # this rank's own steps, before it waits for the others
         barrier()
         dt_r = time.perf_counter() - t0
-        if world > 1:  # the slowest rank's time is the job's time
+        if use_dist:  # the slowest rank's time is the job's time
             t = torch.tensor([dt_r], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt_r = float(t.item())
@@ -409,23 +502,33 @@ def main():
     ctx.profile(False)
     dt_min, dt, dt_max = timed_stats(region_s)
     rank_stats = None
-    if world > 1:
-        stats = torch.tensor([float(B * H * W * args.steps), float(dev_index)], dtype=torch.float64, device=cdev)
+    own_ms = timed_stats(own_s)[1] / args.steps * 1e3
+    my_stats = [float(B * H * W * args.steps), float(dev_index), own_ms, float(binding.get("numa_node", -1)),
+                float(binding.get("cpus", 0)), 1.0 if binding.get("bound") else 0.0, float(packer_threads)]
+    if use_dist:
+        stats = torch.tensor(my_stats, dtype=torch.float64, device=cdev)
         gathered = [torch.zeros_like(stats) for _ in range(world)]
         dist.all_gather(gathered, stats)  # final metrics gather (the only payload collective)
-        total_px = sum(float(s[0]) for s in gathered)
-        rank_stats = [{"rank": r, "device": int(s[1]), "pixels_per_region": float(s[0])} for r, s in enumerate(gathered)]
+        gathered = [[float(v) for v in s.tolist()] for s in gathered]
     else:
-        total_px = float(B * H * W * args.steps)
+        gathered = [my_stats]
+    total_px = sum(s[0] for s in gathered)
+    rank_stats = [{"rank": r, "device": int(s[1]), "pixels_per_region": s[0], "ms_per_step": round(s[2], 4),
+                   "numa": {"node": int(s[3]), "cpus": int(s[4]), "bound": bool(s[5])}, "packer_threads": int(s[6])}
+                  for r, s in enumerate(gathered)]
+    rank_stats[rank]["numa"]["reason"] = binding.get("reason", "")
 
     extras = {}
     h2h_pair = None
-    if not args.no_extras and args.config != "svd":  # every rank takes part in the (collective-timed) host->host leg
+    if not args.no_extras and args.config != "svd":  # every rank takes part in the (collective-timed) host->host legs
         Ud, Vd = U.cpu(), V.cpu()
-        h2h, h2h_pair = host_to_host(torch, dist, _lib, dev_index, images, H, W, RANKS, min(args.steps, 10), args.warmup,
-                                     world, cdev)
+        host = images.cpu().pin_memory()
+        h2h, h2h_pair = host_to_host(torch, dist, _lib, dev_index, images, host, H, W, RANKS, min(args.steps, 10), args.warmup,
+                                     use_dist, cdev)
         assert torch.equal(h2h_pair[0], Ud) and torch.equal(h2h_pair[1], Vd), "pipelined factors differ from the one-shot ones"
         extras.update(h2h)
+        extras.update(bytes_out_leg(torch, dist, lrf_amd, host, Ud, Vd, H, W, RANKS, packer_threads, use_dist, cdev))
+        del host
 
     if rank == 0:
         value = total_px / dt / 1e6
@@ -500,8 +603,8 @@ def main():
             "kernels_note": "per-kernel breakdown from a separate untimed pass with every launch bracketed by events; "
                             "roofline.avg_launch_ms is measured inside the timed regions (events on the BCD launches only)",
         }
-        if rank_stats:
-            out["ranks"] = rank_stats
+        out["ranks"] = rank_stats
+        out["forced_dist"] = force_dist
         out.update(extras)
         if world == 1 and not args.no_extras and args.config != "svd":
             out.update(decode_leg(torch, _lib, ctx, U, V, H, W, RANKS, args.steps))
@@ -509,7 +612,7 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(images[:min(B, 256)].cpu().numpy(), H, W, RANKS)
                 out["cpu_baseline"]["reference_torch_cpu"] = REFERENCE_TORCH_CPU.get(args.config)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -34,7 +34,7 @@
 #define LRF_TABLE_SETS 6 // descriptor-table sets a context keeps resident (upload_tables)
 #define LRF_BCDW_MIN_BLOCKS 1024 // smaller rank <= 8 runs iterate on the workgroup kernel k_bcd (run_bcd)
 #define LRF_BCDW16_MIN_BLOCKS 1024 // likewise for rank <= 16 runs and k_bcd_w16
-#define LRF_BCDW32_MIN_BLOCKS 1024 // likewise for rank 17..32 runs and k_bcd_w32
+#define LRF_BCDW32_MIN_BLOCKS 512  // likewise for rank 17..32 runs and k_bcd_w32 (32 images: 1.32 -> 1.11 ms at (20,10,10))
 
 static thread_local char g_err[512] = "";
 
@@ -119,7 +119,7 @@ struct lrf_ctx {
     // Kernel families of one call on streams of their own (run_init / run_bcd): the runs of plan_runs touch disjoint planes, so
     // the whole chain of a run — initialisation, b table, K x (U update, V update) — is independent of the other runs'; the
     // first run stays on `stream`, the others fork behind the Gram pass and are joined at the end of run_bcd.  Created on
-    // first use (a call with 3072 blocks or more that mixes rank families); never while kernel profiling is on.
+    // first use (a call with 1024 blocks or more — 768 with a rank above 16 — that mixes rank families); never while kernel profiling is on.
     hipStream_t fam_stream[2] = {nullptr, nullptr};
     hipEvent_t fam_fork = nullptr, fam_join[2] = {nullptr, nullptr};
     bool fam_parallel = false;   // set by the fused entry points whose run_init is followed by run_bcd at once
@@ -296,7 +296,7 @@ static int table_rp(const Tables& t) { return table_rmax(t) <= 16 ? 16 : LRF_RPB
 // A run: consecutive planes (and their blocks) that iterate on one kernel family — 0: rank <= 8 (k_bcd_w), 1: rank <= 16
 // (k_bcd<., 16>), 2: rank <= 32 (k_bcd_mid) — with that family's table pitch (16 or LRF_RPB).  A small call takes ONE family,
 // the one its largest rank needs: its launches are latency chains per block and a second launch per iteration costs more than
-// a faster kernel saves (64 x 512x768 at (16,8,8): 1.39 -> 1.51 ms).  From 3072 blocks on (128 Kodak-sized images) every plane
+// a faster kernel saves.  From 1024 blocks on (768 with a rank above 16: plan_runs) every plane
 // goes to its own family (256 images: (16,8,8) 4.05 -> 3.78 ms, (20,10,10) 7.07 -> see DESIGN.md); the planes of the fused
 // encode are ordered by channel, so that is at most three runs.  Pitch-16 runs of a call whose table pitch is LRF_RPB use
 // the second table set (vf16 ...): the regions of the two pitches would overlap in one buffer.
@@ -315,7 +315,11 @@ static std::vector<FamRun> plan_runs(const Tables& t)
 {
     static const bool no_split = getenv("LRF_NO_FAMILY_SPLIT") && getenv("LRF_NO_FAMILY_SPLIT")[0] == '1'; // developer comparison aid
     const int rmax_t = table_rmax(t);
-    static const long min_blocks = getenv("LRF_FAMILY_SPLIT_BLOCKS") ? atol(getenv("LRF_FAMILY_SPLIT_BLOCKS")) : 3072; // developer aid
+    // since the families of a call run side by side on streams of their own (round 3) the split pays from 1024 blocks on
+    // (64 x 512x768: (16,8,8) 0.93 -> 0.89 ms, (20,10,10) 2.04 -> 1.36 with k_bcd_w32 on the luma run); calls with a rank above
+    // 16 split from 768 blocks (32 images: (20,10,10) 1.32 -> 1.11 ms).  It was 3072 while the runs shared one stream.
+    static const long env_blocks = getenv("LRF_FAMILY_SPLIT_BLOCKS") ? atol(getenv("LRF_FAMILY_SPLIT_BLOCKS")) : -1; // developer aid
+    const long min_blocks = env_blocks >= 0 ? env_blocks : (rmax_t > 16 ? 768 : 1024);
     const bool split = !no_split && bcd_wave_variant() && rmax_t <= LRF_BIG_TO_ANY_RANK && (long)t.blocks.size() >= min_blocks;
     std::vector<FamRun> runs;
     for (int p = 0; p < (int)t.planes.size(); p++) {

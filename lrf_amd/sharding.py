@@ -26,8 +26,8 @@ def collective_device() -> torch.device:
 def gather_metrics(local: torch.Tensor, n_items: int) -> torch.Tensor:
     """local: [n_local, k] float32 metrics of this rank's block (in block order) -> [n_items, k] on every rank
     (on collective_device())."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return local
+    if not (dist.is_available() and dist.is_initialized()):
+        return local  # (a process group of ONE rank still runs the collective: the N > 1 code path, executed)
     world, rank = dist.get_world_size(), dist.get_rank()
     per = (n_items + world - 1) // world
     k = local.shape[1]

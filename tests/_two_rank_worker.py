@@ -28,8 +28,14 @@ def metrics_of(images, streams):
 
 def main():
     n, H, W, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
-    dist.init_process_group("gloo")  # RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT from the environment
+    # RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT from the environment; LRF_WORKER_BACKEND=nccl: RCCL with the payload on
+    # the GPU (one rank per GPU: on this one-GPU box a world of one rank), as the multi-GPU runs do
+    backend = os.environ.get("LRF_WORKER_BACKEND", "gloo")
     torch.cuda.set_device(0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo")
     import lrf_amd
     from lrf_amd.sharding import encode_sharded, shard_range
     data = dataset(n, H, W)
@@ -37,6 +43,9 @@ def main():
                                     metrics_of, 3)
     lo, hi = shard_range(n, dist.get_rank(), dist.get_world_size())
     assert len(streams) == hi - lo and tuple(table.shape) == (n, 3)
+    from lrf_amd.sharding import collective_device
+    assert collective_device().type == ("cuda" if backend == "nccl" else "cpu") and table.device.type == collective_device().type
+    table = table.cpu()
     with open(f"{out}.rank{dist.get_rank()}", "w") as f:
         json.dump({"table": table.tolist(), "span": [lo, hi], "first_stream_len": len(streams[0]) if streams else None}, f)
     dist.barrier()
