@@ -34,6 +34,7 @@
 #define LRF_TABLE_SETS 6 // descriptor-table sets a context keeps resident (upload_tables)
 #define LRF_BCDW_MIN_BLOCKS 1024 // smaller rank <= 8 runs iterate on the workgroup kernel k_bcd (run_bcd)
 #define LRF_BCDW16_MIN_BLOCKS 1024 // likewise for rank <= 16 runs and k_bcd_w16
+#define LRF_SHARE_MIN_BLOCKS 3072   // LRF_SHARES=2|3: a rank <= 8 call of this many blocks runs as two image shares (run_two_shares)
 #define LRF_BCDW32_MIN_BLOCKS 512  // likewise for rank 17..32 runs and k_bcd_w32 (32 images: 1.32 -> 1.11 ms at (20,10,10))
 
 static thread_local char g_err[512] = "";
@@ -125,6 +126,9 @@ struct lrf_ctx {
     bool fam_parallel = false;   // set by the fused entry points whose run_init is followed by run_bcd at once
     bool fam_forked = false;     // run_init forked: run_bcd uses the same streams and joins
     hipEvent_t planes_done = nullptr; // set by a pipe: recorded after the planes kernel of lrf_qmf_encode_rgb_u8 (input buffer free)
+    // two image shares of one large call on two streams (run_two_shares; an experiment, off unless LRF_SHARES=2 or 3): per
+    // share the events Gram done / initial tables done / U update done / V update done
+    hipEvent_t share_ev[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
 };
 
 static int ensure(lrf_ctx* c, DevBuf& b, size_t bytes)
@@ -249,6 +253,11 @@ struct Tables {
     std::vector<PlaneDesc> planes;
     std::vector<BlockDesc> blocks;
     std::vector<GramChunk> gchunks;
+    // image shares (encode_rgb_prepare / run_two_shares): the table is ordered share by share; share s owns the images
+    // [share_img0[s], share_img0[s+1]) and the planes [share_plane0[s], share_plane0[s+1])
+    int shares = 1;
+    long share_img0[3] = {0, 0, 0};
+    int share_plane0[3] = {0, 0, 0};
 };
 
 static void add_plane(Tables& t, long x_off, long u_off, long v_off, long u0_off, long v0_off, int M, int R, int sign_off)
@@ -663,6 +672,135 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
     return fam_join_streams(c, runs.size());
 }
 
+// ---- experiment (off by default): two image shares of one large call on two streams -----------------------------------
+// A large rank <= 8 call is a chain of 3 + 2 K launches, each waiting for the last workgroup of its predecessor: the chip
+// drains and refills 2 K + 2 times, and three of the kernels (k_init, k_bprep, k_vupdate) are latency chains per matrix that
+// leave it mostly idle.  Cut into two image shares A, B the same launches can interleave on TWO streams:
+//   LRF_SHARES=2  heavy (the caller's stream): planes A, Gram A, planes B, Gram B, then U-update A1, B1, A2, B2, ...
+//                 latency (the context's own): init A, b-table A, init B, b-table B, then V-update A1, B1, A2, ...
+//                 with an event per dependency (Gram s -> init s; b-table / V-update s -> next U-update s; U-update s -> V-update s):
+//                 the streaming kernels never overlap each other, the latency kernels of one share run under the U update of the other;
+//   LRF_SHARES=3  each share's whole chain on a stream of its own (one fork, one join).
+// Arithmetic, tables and outputs are those of run_init + run_bcd (same kernels on sub-ranges of the same tables): bit-identical.
+// Measured: both are SLOWER or no faster than the single stream on this runtime, which is why
+// neither is the default.
+static int run_two_shares(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_t H, int64_t W, const ImageGeom& g, const Tables& t, int K,
+                          int lo, int hi, const int8_t* sign_dev, int8_t* U, int8_t* V)
+{
+    const PlaneDesc* pl = (const PlaneDesc*)c->planes.p;
+    const BlockDesc* bl = (const BlockDesc*)c->blocks.p;
+    float* X = (float*)c->x.p;
+    if (!(c->attr_done & (1u << 0))) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_init<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InitLds<8>)));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_init<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InitLds<16>)));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_init<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InitLds<64>)));
+        c->attr_done |= 1u << 0;
+    }
+    if (!(c->attr_done & (1u << 1))) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_w<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LRF_BCDW_LDS));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_w<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LRF_BCDW_LDS));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_w<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LRF_BCDW_LDS));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_w16<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LRF_BCDW16_LDS));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_w16<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LRF_BCDW16_LDS));
+        c->attr_done |= 1u << 1;
+    }
+    if (!c->fam_stream[0]) HIP_TRY(hipStreamCreateWithFlags(&c->fam_stream[0], hipStreamNonBlocking));
+    for (int sh = 0; sh < 2; sh++)
+        for (int j = 0; j < 4; j++)
+            if (!c->share_ev[sh][j]) HIP_TRY(hipEventCreateWithFlags(&c->share_ev[sh][j], hipEventDisableTiming));
+    static const bool indep = getenv("LRF_SHARES") && atoi(getenv("LRF_SHARES")) == 3;
+    // hs[s]: the stream of share s's streaming kernels (planes, Gram, U update); ls[s]: of its latency kernels
+    hipStream_t hs[2] = {c->stream, indep ? c->fam_stream[0] : c->stream};
+    hipStream_t ls[2] = {indep ? c->stream : c->fam_stream[0], c->fam_stream[0]};
+    if (indep) {
+        if (!c->fam_fork) HIP_TRY(hipEventCreateWithFlags(&c->fam_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(c->fam_fork, c->stream));
+        HIP_TRY(hipStreamWaitEvent(c->fam_stream[0], c->fam_fork, 0));
+    }
+    auto link = [&](hipEvent_t ev, hipStream_t from, hipStream_t to) -> int { // `to` continues behind what `from` has queued
+        if (from == to) return LRF_OK;
+        HIP_TRY(hipEventRecord(ev, from));
+        HIP_TRY(hipStreamWaitEvent(to, ev, 0));
+        return LRF_OK;
+    };
+    enum { EV_GRAM = 0, EV_TABLES = 1, EV_U = 2, EV_V = 3 };
+    struct Share { int plane0, nplanes, block0, nblocks, gch0, ngch; long img0, nimg; } shr[2];
+    for (int sh = 0; sh < 2; sh++) {
+        Share& s = shr[sh];
+        s.plane0 = t.share_plane0[sh];
+        s.nplanes = t.share_plane0[sh + 1] - s.plane0;
+        s.block0 = t.planes[s.plane0].blk0;
+        s.gch0 = t.planes[s.plane0].gch0;
+        s.nblocks = 0;
+        s.ngch = 0;
+        for (int p = s.plane0; p < s.plane0 + s.nplanes; p++) {
+            s.nblocks += t.planes[p].nblk;
+            s.ngch += t.planes[p].ngch;
+        }
+        s.img0 = t.share_img0[sh];
+        s.nimg = t.share_img0[sh + 1] - s.img0;
+    }
+    GsParams gp = make_gs(lo, hi);
+    hipStream_t caller = c->stream;
+    int rc = LRF_OK;
+    for (int sh = 0; sh < 2 && !rc; sh++) {
+        const Share& s = shr[sh];
+        c->stream = hs[sh]; // lrf_qmf_planes_from_rgb_u8 and Prof launch / record on c->stream
+        rc = lrf_qmf_planes_from_rgb_u8(c, rgb + (size_t)s.img0 * 3 * H * W, s.nimg, H, W, X + s.img0 * g.img_floats);
+        if (!rc && sh == 1 && c->planes_done) {
+            if (hs[1] != caller) rc = link(c->share_ev[1][EV_GRAM], hs[1], caller);
+            if (!rc && hipEventRecord(c->planes_done, caller) != hipSuccess) rc = set_err(LRF_EHIP, "hipEventRecord failed");
+        }
+        if (!rc) {
+            Prof p(c, LRF_K_GRAM);
+            hipLaunchKernelGGL(k_gram64<true>, dim3((unsigned)s.ngch), dim3(256), 0, hs[sh], X, pl, (const GramChunk*)c->gchunks.p + s.gch0,
+                               (const int*)c->gexp.p, LRF_PLANES_GRAM_EXP, (ulonglong2*)c->gpart.p);
+        }
+        c->stream = caller;
+        if (rc) break;
+        LAUNCH_CHECK();
+        if ((rc = link(c->share_ev[sh][EV_GRAM], hs[sh], ls[sh]))) break;
+        hipLaunchKernelGGL(k_init<8>, dim3(s.nplanes), dim3(256), sizeof(InitLds<8>), ls[sh], (const ulonglong2*)c->gpart.p, (const int*)c->gexp.p,
+                           LRF_PLANES_GRAM_EXP, pl, sign_dev, (float*)c->vf.p, (float*)c->wf.p, c->init_sweeps, 16, s.plane0);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_bprep, dim3(s.nplanes), dim3(256), 0, ls[sh], pl, (const float*)c->vf.p, (float*)c->bf.p, s.plane0);
+        LAUNCH_CHECK();
+    }
+    if (rc) return rc;
+    for (int it = 0; it < K; it++) {
+        const int last = it == K - 1 ? 1 : 0;
+        for (int sh = 0; sh < 2; sh++) {
+            const Share& s = shr[sh];
+            const BlockDesc* blr = bl + s.block0;
+            if ((rc = link(c->share_ev[sh][it == 0 ? EV_TABLES : EV_V], ls[sh], hs[sh]))) return rc;
+            {
+                c->stream = hs[sh];
+                Prof p(c, LRF_K_BCD);
+                c->stream = caller;
+                const dim3 grid((unsigned)((s.nblocks + LRF_BCDW_WAVES - 1) / LRF_BCDW_WAVES)), block(64 * LRF_BCDW_WAVES);
+                if (it == 0)
+                    hipLaunchKernelGGL((k_bcd_w<1>), grid, block, LRF_BCDW_LDS, hs[sh], (const float*)X, pl, blr, (const float*)c->vf.p,
+                                       (const float*)c->wf.p, (const float*)c->bf.p, (const float*)nullptr, U, (float*)c->ppart.p,
+                                       (float*)c->qpart.p, gp, s.nblocks);
+                else
+                    hipLaunchKernelGGL((k_bcd_w<0>), grid, block, LRF_BCDW_LDS, hs[sh], (const float*)X, pl, blr, (const float*)c->vf.p,
+                                       (const float*)c->wf.p, (const float*)c->bf.p, (const float*)nullptr, U, (float*)c->ppart.p,
+                                       (float*)c->qpart.p, gp, s.nblocks);
+                c->stream = hs[sh];
+            }
+            c->stream = caller;
+            LAUNCH_CHECK();
+            if ((rc = link(c->share_ev[sh][EV_U], hs[sh], ls[sh]))) return rc;
+            hipLaunchKernelGGL(k_vupdate<8>, dim3(s.nplanes), dim3(256), 0, ls[sh], pl, (const float*)c->ppart.p, (const float*)c->qpart.p,
+                               (float*)c->vf.p, (float*)c->bf.p, V, gp, last, s.plane0);
+            LAUNCH_CHECK();
+        }
+    }
+    for (int sh = 0; sh < 2; sh++)
+        if ((rc = link(c->share_ev[sh][EV_V], ls[sh], caller))) return rc;
+    return LRF_OK;
+}
+
 // ---- C ABI ------------------------------------------------------------------------------------
 #include "lrf_anyshape_host.inc"
 
@@ -728,6 +866,9 @@ void lrf_ctx_destroy(lrf_ctx* c)
         if (c->fam_join[i]) (void)hipEventDestroy(c->fam_join[i]);
     }
     if (c->fam_fork) (void)hipEventDestroy(c->fam_fork);
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 4; j++)
+            if (c->share_ev[i][j]) (void)hipEventDestroy(c->share_ev[i][j]);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -1097,11 +1238,25 @@ static int encode_rgb_prepare(lrf_ctx* c, int64_t B, int64_t H, int64_t W, const
         ep.u0c[ch + 1] = ep.u0c[ch] + B * (long)g.p[ch].M * R[ch];
         ep.v0c[ch + 1] = ep.v0c[ch] + B * 64L * R[ch];
     }
-    for (int ch = 0; ch < 3; ch++)
-        for (int64_t b = 0; b < B; b++)
-            add_plane(ep.t, b * g.img_floats + g.p[ch].xoff, b * ep.u_img + ep.uoff[ch], b * ep.v_img + ep.voff[ch],
-                      ep.u0c[ch] + b * (long)g.p[ch].M * R[ch], ep.v0c[ch] + b * 64L * R[ch], g.p[ch].M, R[ch],
-                      with_sign ? (int)(b * s_img + soff[ch]) : -1);
+    // Two image shares (run_two_shares; an experiment: LRF_SHARES=2 or 3) for a large call whose planes all iterate on
+    // k_bcd_w: the first half of the images, then the second, each luma first
+    long nblk_img = 0;
+    for (int ch = 0; ch < 3; ch++) nblk_img += (g.p[ch].M + LRF_KC - 1) / LRF_KC;
+    static const int shares_mode = getenv("LRF_SHARES") ? atoi(getenv("LRF_SHARES")) : 0;
+    const bool two = shares_mode >= 2 && bcd_wave_variant() && R[0] <= 8 && R[1] <= 8 && R[2] <= 8 && B >= 2 && B * nblk_img >= LRF_SHARE_MIN_BLOCKS;
+    ep.t.shares = two ? 2 : 1;
+    ep.t.share_img0[0] = 0;
+    ep.t.share_img0[1] = two ? B / 2 : B;
+    ep.t.share_img0[2] = B;
+    for (int sh = 0; sh < ep.t.shares; sh++) {
+        ep.t.share_plane0[sh] = (int)ep.t.planes.size();
+        for (int ch = 0; ch < 3; ch++)
+            for (int64_t b = ep.t.share_img0[sh]; b < ep.t.share_img0[sh + 1]; b++)
+                add_plane(ep.t, b * g.img_floats + g.p[ch].xoff, b * ep.u_img + ep.uoff[ch], b * ep.v_img + ep.voff[ch],
+                          ep.u0c[ch] + b * (long)g.p[ch].M * R[ch], ep.v0c[ch] + b * 64L * R[ch], g.p[ch].M, R[ch],
+                          with_sign ? (int)(b * s_img + soff[ch]) : -1);
+    }
+    for (int sh = ep.t.shares; sh <= 2; sh++) ep.t.share_plane0[sh] = (int)ep.t.planes.size();
     return upload_tables(c, ep.t);
 }
 
@@ -1118,6 +1273,8 @@ int lrf_qmf_encode_rgb_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_t H, 
     const long u_img = ep.u_img, v_img = ep.v_img;
     const long *uoff = ep.uoff, *voff = ep.voff, *u0c = ep.u0c, *v0c = ep.v0c;
     float* X = (float*)c->x.p;
+    // two image shares (experiment): only while no kernel carries profiling events (those are recorded on the caller's stream)
+    if (t.shares == 2 && !c->profile) return run_two_shares(c, rgb, B, H, W, g, t, K, lo, hi, sign, U, V);
     if ((rc = lrf_qmf_planes_from_rgb_u8(c, rgb, B, H, W, X))) return rc;
     if (c->planes_done) HIP_TRY(hipEventRecord(c->planes_done, c->stream)); // the RGB bytes are not read again
     if (table_rmax(t) > LRF_BIG_TO_ANY_RANK) {
