@@ -29,22 +29,39 @@ def qmf_ranks(image_hw, rank=None, quality=None):
 
 
 def _check_hip_branch(color_space, scale_factor, patch, patch_size, bounds, dtype, kwargs):
+    """Splits qmf_encode's **kwargs (lrf/compression/qmf.py:127, forwarded to QMF(...) at :189, 208, 256, 280) into the loop
+    parameters of the tuned path and the options only the general solver takes (`qmf_opts`: l2, l1_ratio, eps, num_levels)."""
     if color_space == "YCbCr" and not (len(scale_factor) == 2 and min(scale_factor) > 0):
         raise ValueError("scale_factor must be two positive numbers")
     if dtype is not torch.int8:
         raise NotImplementedError("HIP path stores int8 factors only")
     num_iters = kwargs.pop("num_iters", 10)
     init_sign = kwargs.pop("init_sign", None)
-    kwargs.pop("init", None)  # RGB and any-shape branches: explicit (u0, v0) fp32 initial factors (tests)
+    kwargs.pop("init", None)  # explicit (u0, v0) fp32 initial factors (tests)
     kwargs.pop("verbose", None)
-    extra = {k: v for k, v in kwargs.items() if not (k in ("l2", "l1_ratio") and v in (0, (0, 0))) and
-             not (k == "eps" and v == 1e-16)}
-    if extra:
-        raise NotImplementedError(f"QMF options {sorted(extra)} are not on the HIP path")
+    for dup in ("factor", "project"):  # the reference passes these itself: a caller's copy is a duplicate keyword there too
+        if dup in kwargs:
+            raise TypeError(f"QMF() got multiple values for keyword argument '{dup}'")
+    qmf_opts = {}
+    l2 = kwargs.pop("l2", 0)
+    l2p = tuple(l2) if isinstance(l2, (tuple, list)) else (l2, l2)
+    if any(v != 0 for v in l2p):
+        qmf_opts["l2"] = l2
+        qmf_opts["l1_ratio"] = kwargs.pop("l1_ratio", 0)
+    else:
+        kwargs.pop("l1_ratio", None)  # without an l2 weight the l1 share multiplies zero (qmf.py:154-157)
+    eps = kwargs.pop("eps", 1e-16)
+    if eps != 1e-16:
+        qmf_opts["eps"] = eps
+    num_levels = kwargs.pop("num_levels", None)
+    if num_levels:
+        qmf_opts["num_levels"] = num_levels
+    if kwargs:
+        raise TypeError(f"CoordinateDescent.__init__() got an unexpected keyword argument '{sorted(kwargs)[0]}'")
     if num_iters < 0:
         raise ValueError("num_iters must be >= 0")
     lo, hi = math.ceil(bounds[0]), math.floor(bounds[1])
-    return num_iters, lo, hi, init_sign
+    return num_iters, lo, hi, init_sign, qmf_opts
 
 
 def qmf_factorize_batch(images: torch.Tensor, ranks: Sequence[int], num_iters: int = 10, bounds=(-16, 15),
@@ -112,7 +129,8 @@ def _pack_lib():
     if _PACK_LIB is None:
         import ctypes
         import os
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblrf_pack.so")
+        # LRF_PACK_LIB: another build of lrf_pack.cpp (the sanitizer builds of tools/run_sanitizers.sh)
+        path = os.environ.get("LRF_PACK_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblrf_pack.so")
         lib = ctypes.CDLL(path)
         lib.lrf_pack_qmf_streams.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                              ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int), ctypes.c_char_p,
@@ -276,13 +294,17 @@ def qmf_encode(image: torch.Tensor, rank=None, quality=None, color_space: str = 
     lrf.qmf_encode (lrf/compression/qmf.py:116-292)."""
     assert (rank, quality) != (None, None), "Either 'rank' or 'quality' must be specified."
     assert color_space in ("RGB", "YCbCr"), "`color_space` must be one of 'RGB' or 'YCbCr'."
-    num_iters, lo, hi, init_sign = _check_hip_branch(color_space, scale_factor, patch, patch_size, bounds, dtype,
-                                                     dict(kwargs))
+    num_iters, lo, hi, init_sign, qmf_opts = _check_hip_branch(color_space, scale_factor, patch, patch_size, bounds, dtype,
+                                                               dict(kwargs))
     if image.dtype != torch.uint8:
         raise NotImplementedError("HIP path takes uint8 images")
     H, W = image.shape[-2:]
     ctx = _lib.context(image.device.index if image.is_cuda else None)
     dev = (image if image.is_cuda else image.cuda(ctx.device)).unsqueeze(0)
+    if qmf_opts:  # l2 / l1_ratio / eps / num_levels: the general solver behind the same driver (qmf.py:256 forwards them to QMF)
+        return _qmf_encode_general(ctx, dev, color_space, rank, quality, bounds, tuple(patch_size) if patch else None, num_iters,
+                                   init_sign, kwargs.get("init"), _lib.chroma_size(H, W, scale_factor) if color_space == "YCbCr" else None,
+                                   qmf_opts)
     if color_space == "RGB":
         return _qmf_encode_rgbspace(ctx, dev, rank, quality, bounds, (lo, hi), tuple(patch_size) if patch else None, num_iters, init_sign,
                                     kwargs.get("init"))
@@ -385,6 +407,66 @@ def _qmf_encode_anyshape(ctx, dev, rank, quality, bounds, int_bounds, patch_size
             factors += [u[b:b + 1], v[b:b + 1]] if patch_size is None else [u[b], v[b]]
         streams.append(pack_anyshape(factors, (H, W), ranks, bounds, patch_size, dtype_name, chroma))
     return streams
+
+
+def _qmf_encode_general(ctx, dev, color_space, rank, quality, bounds, patch_size, num_iters, init_sign, init, chroma, qmf_opts):
+    """qmf_encode with QMF options beyond the tuned configuration — `l2`, `l1_ratio`, `eps`, `num_levels`, which the
+    reference forwards to QMF(rank, bounds, factor=(0, 1), **kwargs) per matrix (lrf/compression/qmf.py:189, 208, 256, 280) —
+    for one image dev [1,3,H,W]: the same matrices as the other branches (any patch size, patch=False, both colour spaces),
+    each through lrf_amd.QMF's general path (lrf_qmf_decompose_ex_f32), the float factors through torch's cast to int8
+    (qmf.py:258-260) and the same container.  `init`: per matrix an (u0, v0) pair replacing the SVD initialisation (tests)."""
+    from .factorization import QMF
+    H, W = dev.shape[-2:]
+    if color_space == "RGB":
+        if isinstance(rank, (list, tuple)) or isinstance(quality, (list, tuple)):
+            raise ValueError("color_space='RGB' takes a scalar rank / quality")
+        Hp, Wp, M, N = _lib.rgbspace_dims_any(H, W, patch_size)
+        if rank is None:
+            assert quality >= 0 and quality <= 100, "'quality' must be between 0 and 100."
+            R = max(round(min(M, N) * quality / 100), 1)
+        else:
+            R = rank
+        X = ctx.rgbspace_matrix_any(dev, patch_size)
+        mats = [X[0]] if patch_size is None else [X]  # [3, H, W]: three matrices in one call; [1, M, N]: one
+        ranks = [R]
+    else:
+        ranks = anyshape_ranks((H, W), patch_size, rank, quality, chroma)
+        mats = [ctx.planes_any(dev, patch_size, c, chroma) for c in range(3)]
+    offs = [sum(ranks[:c]) for c in range(len(ranks))]
+    factors = []
+    for c, (Xc, R) in enumerate(zip(mats, ranks)):
+        nb = Xc.shape[0]
+        sign = None
+        if init_sign is not None:
+            sign = torch.as_tensor(init_sign, dtype=torch.int8).reshape(-1, sum(ranks))[:, offs[c]:offs[c] + R].expand(nb, R).contiguous()
+        opts = dict(qmf_opts)
+        num_levels = opts.pop("num_levels", None)
+        if init is not None:  # the reference's initial factors (fixtures): straight into the general loop
+            u0 = torch.as_tensor(init[c][0], dtype=torch.float32).reshape(nb, Xc.shape[1], R)
+            v0 = torch.as_tensor(init[c][1], dtype=torch.float32).reshape(nb, Xc.shape[2], R)
+            w0 = None if len(init[c]) < 3 else torch.as_tensor(init[c][2], dtype=torch.float32).reshape(1, 2).expand(nb, 2)
+            if num_iters == 0:
+                u, v = u0, v0
+            else:
+                u, v, _ = ctx.decompose_ex(Xc, R, num_iters, bounds, opts.get("l2", 0), opts.get("l1_ratio", 0), (0, 1), None,
+                                           init=(u0, v0), eps=opts.get("eps", 1e-16), w_init=w0)
+        else:
+            u, v, _ = QMF(rank=R, num_iters=num_iters, bounds=bounds, num_levels=num_levels, factor=(0, 1), init_sign=sign,
+                          **opts).decompose(Xc)
+        u8, v8 = u.cpu().to(torch.int8).numpy(), v.cpu().to(torch.int8).numpy()  # the affine pair w is dropped, as at qmf.py:257
+        if color_space == "RGB":
+            factors += [u8[0], v8[0]] if patch_size is not None else [u8, v8]
+        else:
+            factors += [u8[0:1], v8[0:1]] if patch_size is None else [u8[0], v8[0]]
+    dtype_name = str(dev.dtype).split(".")[-1]
+    if color_space == "RGB":
+        metadata = {"dtype": dtype_name, "color space": "RGB", "patch": patch_size is not None, "bounds": bounds}
+        if patch_size is not None:
+            metadata.update({"patch size": patch_size, "original size": [H, W], "padded size": [Hp, Wp], "rank": ranks[0]})
+        else:
+            metadata["rank"] = ranks[0]
+        return combine_bytes([dict_to_bytes(metadata), combine_bytes([encode_tensor(np.ascontiguousarray(f)) for f in factors])])
+    return pack_anyshape(factors, (H, W), ranks, bounds, patch_size, dtype_name, chroma)
 
 
 _PLANE_LANES = {}

@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "liblrf_oracle.so")
+# LRF_ORACLE_SO: another build of the same sources (the sanitizer build of `make -C oracle san`, tools/run_sanitizers.sh)
+_SO = os.environ.get("LRF_ORACLE_SO") or os.path.join(_HERE, "_build", "liblrf_oracle.so")
 _lib = None
 
 c_long = ctypes.c_long

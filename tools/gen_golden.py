@@ -561,3 +561,144 @@ def gen_threads(n_threads=8):
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "threads":
     gen_threads()
+
+
+# ---- the byte-identity RATE ------------------------------------------------------------------------
+# "With the reference's LAPACK column signs the encoder emits the reference's byte stream" was shown on 14 fixtures; this
+# measures how often that holds on a population: >= 100 (image, parameters) cases — the 24 config-3 stand-in images
+# (smooth + crops of the natural figure) at rank 7 / quality 20 / quality 32, random and other smooth 512x768 images, a few of
+# 1365x2048 — the 1-thread reference against the oracle with the reference's signs: identical streams, or how far apart
+# (factor entries, PSNR, stream size).  Writes tests/golden/identity_rate.json (records + summary; no streams kept).
+def identity_cases():
+    cases = []
+    for i in range(24):
+        spec = dict(kind="config3", idx=i)
+        cases += [(f"c3_{i:02d}_r7", spec, dict(rank=7)), (f"c3_{i:02d}_q20", spec, dict(quality=20)), (f"c3_{i:02d}_q32", spec, dict(quality=32))]
+    for k in range(20):
+        cases.append((f"rnd_{k:02d}", dict(kind="randint", seed=100 + k, H=512, W=768), dict(rank=7) if k % 2 == 0 else dict(quality=7)))
+    for k in range(6):
+        cases.append((f"smooth_{k}", dict(kind="smooth", seed=300 + k, H=512, W=768), dict(quality=7)))
+    cases += [("clic_rnd_0", dict(kind="randint", seed=400, H=1365, W=2048), dict(rank=7)),
+              ("clic_rnd_1", dict(kind="randint", seed=401, H=1365, W=2048), dict(quality=7)),
+              ("clic_smooth_0", dict(kind="smooth", seed=402, H=1365, W=2048), dict(rank=7)),
+              ("clic_smooth_1", dict(kind="smooth", seed=403, H=1365, W=2048), dict(quality=20))]
+    return cases
+
+
+def identity_image(spec, natural=None):
+    if spec["kind"] == "config3":
+        return config3_image(spec["idx"], natural)
+    return make_image(spec)
+
+
+def gen_identity():
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    from oracle import oracle
+    from lrf_amd.codec import pack_image  # host-side container code only: no GPU call
+    ns = ref_loader.load()
+    torch.set_num_threads(1)
+    natural = make_image(dict(kind="natural"))
+    records = []
+    for name, spec, kw in identity_cases():
+        img = identity_image(spec, natural)
+        enc = ns.cqmf.qmf_encode(img, **kw)
+        meta = json.loads(ns.cutils.separate_bytes(enc, 2)[0].decode())
+        ref_fac = [ns.cutils.decode_tensor(f).numpy() for f in ns.cutils.separate_bytes(ns.cutils.separate_bytes(enc, 2)[1], 6)]
+        dec = ns.cqmf.qmf_decode(enc)
+        psnr_ref = (20 * torch.log10(255 / torch.sqrt(torch.mean((img.float() - dec.float()) ** 2)))).item()
+        ycbcr = ns.cutils.rgb_to_ycbcr(img.float())
+        chans = ns.cutils.chroma_downsampling(ycbcr, scale_factor=(0.5, 0.5), mode="area")
+        X = oracle.rgb_to_planes(img.numpy())
+        fac, signs = [], []
+        for c, ch in enumerate(chans):
+            x = ns.cqmf.patchify(ns.cutils.pad_image(ch, (8, 8), mode="reflect"), (8, 8))
+            _, v0, _ = ns.fqmf.SVDInit(rank=meta["rank"][c])(x.unsqueeze(0).float())
+            signs.append([int(v) for v in wsign(v0[0].numpy())])
+            u, v = oracle.qmf_decompose(X[c], meta["rank"][c], 10, (-16, 15), sign=np.array(signs[-1], np.int8))
+            fac += [u.astype(np.int8), v.astype(np.int8)]
+        H, W = img.shape[-2:]
+        stream = pack_image(fac, (H, W), meta["rank"], (-16, 15), (8, 8), "uint8")
+        ident = stream == enc
+        ndiff = sum(int((a != b).sum()) for a, b in zip(fac, ref_fac))
+        ntot = sum(a.size for a in ref_fac)
+        out = oracle.planes_to_rgb(fac[0::2], fac[1::2], H, W)
+        psnr_or = float(20 * np.log10(255 / np.sqrt(np.mean((img.numpy().astype(np.float32) - out.astype(np.float32)) ** 2))))
+        rec = dict(name=name, spec=spec, kwargs=kw, ranks=meta["rank"], signs=signs, identical=bool(ident), differing_entries=ndiff, entries=ntot,
+                   ref_len=len(enc), oracle_len=len(stream), ref_psnr=psnr_ref, oracle_psnr=psnr_or,
+                   ref_sha256=hashlib.sha256(enc).hexdigest(), oracle_sha256=hashlib.sha256(stream).hexdigest())
+        records.append(rec)
+        print(name, "identical" if ident else f"DIFF entries {ndiff}/{ntot} = {ndiff / ntot:.4f}, dPSNR {psnr_or - psnr_ref:+.4f} dB, "
+              f"size {len(stream)} vs {len(enc)}", flush=True)
+    n = len(records)
+    nid = sum(r["identical"] for r in records)
+    diff = [r for r in records if not r["identical"]]
+    summary = dict(cases=n, identical=nid, rate=nid / n,
+                   max_entry_fraction=max((r["differing_entries"] / r["entries"] for r in diff), default=0.0),
+                   max_abs_psnr_diff_db=max((abs(r["oracle_psnr"] - r["ref_psnr"]) for r in diff), default=0.0),
+                   max_size_fraction=max((abs(r["oracle_len"] - r["ref_len"]) / r["ref_len"] for r in diff), default=0.0),
+                   mean_psnr_diff_db=float(np.mean([r["oracle_psnr"] - r["ref_psnr"] for r in records])),
+                   mean_size_ratio=float(np.mean([r["oracle_len"] / r["ref_len"] for r in records])),
+                   by_params={})
+    for key in ("rank=7", "quality=7", "quality=20", "quality=32"):
+        k, v = key.split("=")
+        sel = [r for r in records if r["kwargs"].get(k) == int(v)]
+        if sel:
+            summary["by_params"][key] = dict(cases=len(sel), identical=sum(r["identical"] for r in sel))
+    with open(os.path.join(OUT, "identity_rate.json"), "w") as f:
+        json.dump(dict(what="1-thread reference qmf_encode vs the oracle with the reference's LAPACK column signs (tools/gen_golden.py identity)",
+                       torch=torch.__version__, summary=summary, records=records), f, indent=1)
+    print(summary)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "identity":
+    gen_identity()
+
+
+# ---- qmf_encode(**kwargs) reaching the general solver (lrf/compression/qmf.py:127, 256) ---------------
+QMFKW_CASES = [
+    # name, image spec, encoder kwargs (l2 / l1_ratio / eps / num_levels are forwarded to QMF(...))
+    ("kw_l2_q20", dict(kind="smooth", seed=51, H=64, W=96), dict(quality=20, l2=0.5, l1_ratio=0.3)),
+    ("kw_levels_r3", dict(kind="smooth", seed=52, H=64, W=96), dict(rank=3, num_levels=12)),
+    ("kw_nopatch_l2", dict(kind="smooth", seed=54, H=40, W=56), dict(quality=15, patch=False, l2=(1.0, 0.25))),
+    ("kw_p4_eps", dict(kind="randint", seed=55, H=48, W=64), dict(quality=30, patch_size=(4, 4), eps=1e-3, l2=0.05)),
+    ("kw_rgb_l2", dict(kind="randint", seed=53, H=48, W=64), dict(rank=4, color_space="RGB", l2=(0.1, 0.2), l1_ratio=0.5)),
+]
+
+
+def gen_qmfkw():
+    """Stored per case: the reference's stream, decoded image hash, PSNR, and per matrix its initial factors (u0, v0, w0) as
+    SVDInit(rank, num_levels) returns them (scaled when num_levels is given)."""
+    torch.set_num_threads(1)
+    ns = ref_loader.load()
+    index = {}
+    for name, spec, kw in QMFKW_CASES:
+        img = make_image(spec)
+        enc = ns.cqmf.qmf_encode(img, **kw)
+        dec = ns.cqmf.qmf_decode(enc)
+        psnr = (20 * torch.log10(255 / torch.sqrt(torch.mean((img.float() - dec.float()) ** 2)))).item()
+        meta = json.loads(ns.cutils.separate_bytes(enc, 2)[0].decode())
+        arrays = dict(encoded=np.frombuffer(enc, np.uint8), psnr=np.float64(psnr), spec=np.array(json.dumps(spec)), kwargs=np.array(json.dumps(kw)),
+                      image=img.numpy(), decoded_sha256=np.array(hashlib.sha256(dec.numpy().tobytes()).hexdigest()))
+        ps = tuple(kw.get("patch_size", (8, 8)))
+        if kw.get("color_space", "YCbCr") == "RGB":
+            mats = [ns.cqmf.patchify(ns.cutils.pad_image(img.float(), ps, mode="reflect"), ps)]
+            ranks = [meta["rank"]]
+        else:
+            ycbcr = ns.cutils.rgb_to_ycbcr(img.float())
+            chans = ns.cutils.chroma_downsampling(ycbcr, scale_factor=(0.5, 0.5), mode="area")
+            mats = [ns.cqmf.patchify(ns.cutils.pad_image(ch, ps, mode="reflect"), ps) if kw.get("patch", True) else ch[0] for ch in chans]
+            ranks = meta["rank"]
+        for c, (x, R) in enumerate(zip(mats, ranks)):
+            u0, v0, w0 = ns.fqmf.SVDInit(rank=R, num_levels=kw.get("num_levels"))(x.unsqueeze(0).float())
+            arrays[f"u0_{c}"], arrays[f"v0_{c}"], arrays[f"w0_{c}"] = u0[0].numpy(), v0[0].numpy(), w0[0].numpy().reshape(2)
+            arrays[f"sign{c}"] = wsign(v0[0].numpy())
+        arrays["ranks"] = np.array(ranks, np.int32)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
+        index[name] = dict(spec=spec, kwargs=kw, bytes=len(enc), psnr=psnr, ranks=[int(r) for r in ranks], enc_sha256=hashlib.sha256(enc).hexdigest()[:16])
+        print(name, index[name], flush=True)
+    with open(os.path.join(OUT, "index_qmfkw.json"), "w") as f:
+        json.dump(index, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "qmfkw":
+    gen_qmfkw()
