@@ -557,6 +557,10 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
 #define LRF_W32_ATTR(NP) HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_w32<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, LRF_BCDW32_LDS(NP)))
         LRF_W32_ATTR(9); LRF_W32_ATTR(10); LRF_W32_ATTR(11); LRF_W32_ATTR(12); LRF_W32_ATTR(13); LRF_W32_ATTR(14); LRF_W32_ATTR(15); LRF_W32_ATTR(16);
 #undef LRF_W32_ATTR
+#define LRF_W32F_ATTR(R) HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_w32f<R>, hipFuncAttributeMaxDynamicSharedMemorySize, LRF_BCDW32F_LDS))
+        LRF_W32F_ATTR(17); LRF_W32F_ATTR(18); LRF_W32F_ATTR(19); LRF_W32F_ATTR(20); LRF_W32F_ATTR(21); LRF_W32F_ATTR(22); LRF_W32F_ATTR(23); LRF_W32F_ATTR(24);
+        LRF_W32F_ATTR(25); LRF_W32F_ATTR(26); LRF_W32F_ATTR(27); LRF_W32F_ATTR(28); LRF_W32F_ATTR(29); LRF_W32F_ATTR(30); LRF_W32F_ATTR(31); LRF_W32F_ATTR(32);
+#undef LRF_W32F_ATTR
         c->attr_done |= 1u << 2;
     }
     // the b tables of the initial V
@@ -617,6 +621,19 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
                     default: LRF_LAUNCH_W32(16); break;
                     }
 #undef LRF_LAUNCH_W32
+                } else if (r.fam == 2 && mode == 1 && wave_variant && !w32_off && !r.any_native && r.rmin == r.rmax && r.rmin >= 17 && nbr >= w32_min) {
+                    // ranks 17..32, first iteration (old U = X W0, the reference's ordered chain): one wave per block, lane = row
+#define LRF_LAUNCH_W32F(RR)                                                                                          \
+    case RR:                                                                                                         \
+        hipLaunchKernelGGL((k_bcd_w32f<RR>), dim3(nbr), dim3(64), LRF_BCDW32F_LDS, rs, X, pl, blr, (const float*)fb.vf,  \
+                           (const float*)fb.wf, (const float*)fb.bf, U, fb.pp, fb.qp, gpr, nbr);                     \
+        break;
+                    switch (r.rmax) {
+                        LRF_LAUNCH_W32F(17) LRF_LAUNCH_W32F(18) LRF_LAUNCH_W32F(19) LRF_LAUNCH_W32F(20) LRF_LAUNCH_W32F(21) LRF_LAUNCH_W32F(22)
+                        LRF_LAUNCH_W32F(23) LRF_LAUNCH_W32F(24) LRF_LAUNCH_W32F(25) LRF_LAUNCH_W32F(26) LRF_LAUNCH_W32F(27) LRF_LAUNCH_W32F(28)
+                        LRF_LAUNCH_W32F(29) LRF_LAUNCH_W32F(30) LRF_LAUNCH_W32F(31) LRF_LAUNCH_W32F(32)
+                    }
+#undef LRF_LAUNCH_W32F
                 } else if (r.fam == 2) {
                     if (mode == 1) LRF_LAUNCH_MID(1);
                     else if (mode == 2) LRF_LAUNCH_MID(2);

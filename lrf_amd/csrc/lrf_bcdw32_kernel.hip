@@ -449,3 +449,334 @@ void k_bcd_w32(const float* __restrict__ X, const PlaneDesc* __restrict__ planes
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) Qp[(16 * i + 4 * lq + reg) * LRF_RPB + 16 * j + li] = (float)accQ[i][j][reg];
 }
+
+// =====================================================================================================================
+// k_bcd_w32f<R>: the FIRST iteration of ranks 17..32 in the same frame (one wave per block, lane = row, no workgroup barrier;
+// replaces k_bcd_mid<1>, whose Gauss-Seidel of a sub-tile runs on one wave of four while three wait).  The old U is X @ W0 —
+// floats, computed here by a second set of MFMA chains — and b = v0.mT @ v0 is not integer either, so the Gauss-Seidel is
+// the reference's ORDERED chain (lrf/factorization/qmf.py:108-119): per column r the sum `uu @ bb` in MKL's single-column
+// order (oracle/lrf_oracle.c dot_mkl_n1: fma(u1, b1, u0 b0), then the odd terms descending, the even ones ascending, the two
+// chains added), every product rounded before it is added.  The table row of a column (b[j][r], j = 0..31; symmetric) sits
+// in TWO VGPRs (one ds_read_b32 each, lane l reading entries l & 15 and 16 + (l & 15) of the wave's fp32 LDS table) and
+// reaches the products through the DPP row_newbcast modifier, so a column costs R - 1 v_mul_f32_dpp + R - 2 v_add_f32 +
+// the division chain, all 64 lanes on 64 rows.  R is a template parameter: every index of the ordered chains is a
+// compile-time constant.  Any bounds (the result rows are int8 either way); planes small enough for ATen's native order
+// ((R - 1) M < 400) stay on k_bcd_mid<1> (host check).  22.5 KB of LDS per wave (the table is fp32 here) and ~350 registers
+// (both MFMA operand sets resident, a and the old row as floats): one-wave workgroups, ONE wave per SIMD — at two (256
+// registers) the compiler spills 69..116 registers; one launch of ten, so the simple form was kept.
+// =====================================================================================================================
+#define LRF_BCDW32F_LDS (64 * 64 * 4 + 64 * 32 + 32 * 32 * 4)
+
+template <int J>
+__device__ __forceinline__ float w32f_prod(const float t0, const float t1, const float u)
+{
+    return w32_mul_bc16<J & 15>(J < 16 ? t0 : t1, u);
+}
+// column index of the n-th "other" column of column RR
+template <int RR>
+__device__ __forceinline__ constexpr int w32f_col(int n) { return n < RR ? n : n + 1; }
+
+// uu . bb of column RR in dot_mkl_n1's order, K = R - 1 >= 16 terms: each product is rounded, then added to its chain
+template <int RR, int N>
+__device__ __forceinline__ float w32f_prod_n(const float (&u)[32], const float t0, const float t1)
+{
+    constexpr int j = w32f_col<RR>(N);
+    return w32f_prod<j>(t0, t1, u[j]);
+}
+template <int RR, int N> // odd terms N, N - 2, ..., 3
+__device__ __forceinline__ void w32f_odd_chain(float& odd, const float (&u)[32], const float t0, const float t1)
+{
+    if constexpr (N >= 3) {
+        odd = odd + w32f_prod_n<RR, N>(u, t0, t1);
+        w32f_odd_chain<RR, N - 2>(odd, u, t0, t1);
+    }
+}
+template <int RR, int N, int K> // even terms N, N + 2, ... < K
+__device__ __forceinline__ void w32f_even_chain(float& even, const float (&u)[32], const float t0, const float t1)
+{
+    if constexpr (N < K) {
+        even = even + w32f_prod_n<RR, N>(u, t0, t1);
+        w32f_even_chain<RR, N + 2, K>(even, u, t0, t1);
+    }
+}
+template <int R, int RR>
+__device__ __forceinline__ float w32f_term2(const float (&u)[32], const float t0, const float t1)
+{
+    constexpr int K = R - 1;
+    float odd = w32f_prod_n<RR, 0>(u, t0, t1);
+    {
+        constexpr int j1 = w32f_col<RR>(1);
+        asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(odd) : "v"(j1 < 16 ? t0 : t1), "v"(u[j1]), "n"(j1 & 15));
+    }
+    constexpr int last_odd = ((K - 1) & 1) ? K - 1 : K - 2;
+    w32f_odd_chain<RR, last_odd>(odd, u, t0, t1);
+    float even = w32f_prod_n<RR, 2>(u, t0, t1);
+    w32f_even_chain<RR, 4, K>(even, u, t0, t1);
+    return odd + even;
+}
+
+template <int R, int RR, bool FAST>
+__device__ __forceinline__ void w32f_cols(const float (&a)[32], float (&u)[32], const float* tabl, const float rd0, const float rd1,
+                                          const float dn0, const float dn1, const GsParams& gp, const int lob, const int hib, float& emax)
+{
+    if constexpr (RR < R) {
+        const float t0 = tabl[32 * RR], t1 = tabl[32 * RR + 16];
+        const float num = (a[RR] - w32f_term2<R, RR>(u, t0, t1)) + LRF_EPS;
+        if (FAST) {
+            const float q = w32_mul_bc16<RR & 15>(RR < 16 ? rd0 : rd1, num);
+            const float t = q + 12582912.0f;
+            emax = fmaxf(emax, fabsf(q - (t - 12582912.0f)));
+            int c;
+            asm("v_med3_i32 %0, %1, %2, %3" : "=v"(c) : "v"(__float_as_int(t)), "s"(lob), "v"(hib));
+            u[RR] = __int_as_float(c) - 12582912.0f;
+        } else {
+            const float val = rintf(num / get_bc16<RR & 15>(RR < 16 ? dn0 : dn1));
+            u[RR] = __builtin_amdgcn_fmed3f(val, gp.lo, gp.hi);
+        }
+        w32f_cols<R, RR + 1, FAST>(a, u, tabl, rd0, rd1, dn0, dn1, gp, lob, hib, emax);
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_bcd_w32f(const float* __restrict__ X, const PlaneDesc* __restrict__ planes, const BlockDesc* __restrict__ blocks,
+                const float* __restrict__ Vf, const float* __restrict__ Wf, const float* __restrict__ Bf, int8_t* __restrict__ U,
+                float* __restrict__ Ppart, float* __restrict__ Qpart, GsParams gp, int nblocks)
+{
+    extern __shared__ __attribute__((aligned(16))) float bcdw32f_lds[]; // LRF_BCDW32F_LDS bytes: X tile, int8 u, fp32 table
+    const int blk = blockIdx.x;
+    if (blk >= nblocks) return;
+    float* Xs = bcdw32f_lds;
+    int8_t* us8 = reinterpret_cast<int8_t*>(Xs + 64 * 64);
+    float* tab = reinterpret_cast<float*>(us8 + 64 * 32);
+    const BlockDesc bd = blocks[blk];
+    const PlaneDesc pd = planes[bd.plane]; // pd.R == R (host)
+    const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
+    const float* Xp = X + pd.x_off + (long)bd.row0 * 64;
+    const float* Vp = Vf + (long)bd.plane * 64 * LRF_RPB;
+    const float* Wp = Wf + (long)bd.plane * 64 * LRF_RPB;
+    const float* gt = Bf + (long)bd.plane * LRF_GTB_STRIDE;
+    int8_t* Ub = U + pd.u_off + (long)bd.row0 * R;
+    int nrows = pd.M - bd.row0;
+    if (nrows > LRF_KC) nrows = LRF_KC;
+    const int nsub = (nrows + 63) >> 6;
+
+    // A operands of a^T = V^T X^T and of (old u)^T = W0^T X^T, resident
+    float va[2][16], wa[2][16];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int s = 0; s < 16; s++) {
+            va[t][s] = Vp[(4 * s + lq) * LRF_RPB + 16 * t + li];
+            wa[t][s] = Wp[(4 * s + lq) * LRF_RPB + 16 * t + li];
+        }
+    // the symmetric fp32 table tab[r][j] = b[j][r] (diagonal and everything past R: zero); lane l fills entries l, l + 64, ...
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const int idx = e * 64 + lane, r = idx >> 5, j = idx & 31;
+        tab[idx] = (r < R && j < R && j != r) ? gt[r * LRF_GTB_LD + (j < r ? j : j - 1)] : 0.f;
+    }
+    const float dn0 = (li < R) ? gt[li * LRF_GTB_LD + LRF_GTB_DEN] : 1.f;
+    const float dn1 = (16 + li < R) ? gt[(16 + li) * LRF_GTB_LD + LRF_GTB_DEN] : 1.f;
+    const float rd0 = 1.0f / dn0, rd1 = 1.0f / dn1;
+    const float* tabl = tab + li;
+    const int lob = 0x4B400000 + (int)gp.lo, hib = 0x4B400000 + (int)gp.hi;
+
+    f32x4 xq[4][4];
+    auto issue_x = [&](int t, int T0, int T1, bool live) {
+        const int r0 = t * 64;
+#pragma unroll
+        for (int T = T0; T < T1; T++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                int row = r0 + 16 * T + 4 * q + lq;
+                row = row < nrows ? row : nrows - 1;
+                if (live) xq[T][q] = *reinterpret_cast<const f32x4*>(Xp + (long)row * 64 + 4 * li);
+                else xq[T][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    const char* xrow_b = reinterpret_cast<const char*>(Xs) + li * 256 + 4 * lq;
+    const int g16 = 16 * li;
+    const float* xp[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) xp[e] = &Xs[lq * 64 + 4 * (li ^ (4 * e + lq))];
+    const int8_t* ub8 = us8 + lq * 32 + li;
+
+    f32x4 accP[4][2];
+    i32x4 accQ[2][2];
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int t = 0; t < 2; t++) accP[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) accQ[i][j] = (i32x4){0, 0, 0, 0};
+
+    issue_x(0, 0, 4, true);
+    for (int t = 0; t < nsub; t++) {
+        const int r0 = t * 64;
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- 1. sub-tile -> LDS, next sub-tile's loads
+#pragma unroll
+        for (int T = 0; T < 4; T++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int m = 16 * T + 4 * q + lq;
+                *reinterpret_cast<f32x4*>(&Xs[m * 64 + 4 * (li ^ (4 * q + lq))]) = xq[T][q];
+            }
+        const int tn = t + 1;
+        const bool more = tn < nsub;
+        issue_x(tn, 0, 1, more);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- 2. a^T = V^T X^T and (old u)^T = W0^T X^T: sixteen chains of 16 MFMAs, then lane = row
+        float a[32], u[32];
+        auto old_u = [&](float (&dst)[32]) { // (also the rare repeat with the IEEE division starts from it)
+            f32x4 acc[4][2];
+#pragma unroll
+            for (int T = 0; T < 4; T++)
+#pragma unroll
+                for (int tt = 0; tt < 2; tt++) acc[T][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int h = 0; h < 4; h++) {
+                float bx[4][4];
+#pragma unroll
+                for (int s = 0; s < 4; s++)
+#pragma unroll
+                    for (int T = 0; T < 4; T++)
+                        bx[s][T] = *reinterpret_cast<const float*>(xrow_b + T * 16 * 256 + ((16 * (4 * h + s)) ^ g16));
+#pragma unroll
+                for (int s = 0; s < 4; s++)
+#pragma unroll
+                    for (int T = 0; T < 4; T++)
+#pragma unroll
+                        for (int tt = 0; tt < 2; tt++)
+                            acc[T][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[tt][4 * h + s], bx[s][T], acc[T][tt], 0, 0, 0);
+            }
+            w32_tiles_to_rows(acc[0][0], acc[1][0], acc[2][0], acc[3][0], dst);
+            w32_tiles_to_rows(acc[0][1], acc[1][1], acc[2][1], acc[3][1], dst + 16);
+        };
+        {
+            f32x4 acc[4][2];
+#pragma unroll
+            for (int T = 0; T < 4; T++)
+#pragma unroll
+                for (int tt = 0; tt < 2; tt++) acc[T][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int h = 0; h < 4; h++) {
+                float bx[4][4];
+#pragma unroll
+                for (int s = 0; s < 4; s++)
+#pragma unroll
+                    for (int T = 0; T < 4; T++)
+                        bx[s][T] = *reinterpret_cast<const float*>(xrow_b + T * 16 * 256 + ((16 * (4 * h + s)) ^ g16));
+#pragma unroll
+                for (int s = 0; s < 4; s++)
+#pragma unroll
+                    for (int T = 0; T < 4; T++)
+#pragma unroll
+                        for (int tt = 0; tt < 2; tt++)
+                            acc[T][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[tt][4 * h + s], bx[s][T], acc[T][tt], 0, 0, 0);
+            }
+            w32_tiles_to_rows(acc[0][0], acc[1][0], acc[2][0], acc[3][0], a);
+            w32_tiles_to_rows(acc[0][1], acc[1][1], acc[2][1], acc[3][1], a + 16);
+        }
+        old_u(u);
+        issue_x(tn, 1, 2, more);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- 3. the ordered Gauss-Seidel, lane = row
+        {
+            float emax = 0.f;
+            w32f_cols<R, 0, true>(a, u, tabl, rd0, rd1, dn0, dn1, gp, lob, hib, emax);
+            if (__any(!(emax <= gp.fthr))) { // rare: repeat with the reference's IEEE division
+                old_u(u);
+                w32f_cols<R, 0, false>(a, u, tabl, rd0, rd1, dn0, dn1, gp, lob, hib, emax);
+            }
+        }
+        const int row = r0 + lane;
+        unsigned o[8];
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
+            unsigned w = 0u;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (4 * d + k < R) w |= ((unsigned)(int)u[4 * d + k] & 0xffu) << (8 * k);
+            o[d] = row < nrows ? w : 0u;
+        }
+        issue_x(tn, 2, 4, more);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- 4. the int8 row to LDS and to global memory (R bytes)
+        *reinterpret_cast<uint4*>(us8 + lane * 32) = make_uint4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<uint4*>(us8 + lane * 32 + 16) = make_uint4(o[4], o[5], o[6], o[7]);
+        if (row < nrows) {
+            int8_t* uo = Ub + (long)row * R;
+#pragma unroll
+            for (int d = 0; d < 8; d++)
+                if (4 * d + 4 <= R) *reinterpret_cast<u32_unaligned*>(uo + 4 * d) = o[d];
+            if constexpr ((R & 3) != 0) // bytes R-4 .. R-1: the tail of the last full dword and the head of the partial one
+                *reinterpret_cast<u32_unaligned*>(uo + R - 4) = __builtin_amdgcn_alignbyte(o[R >> 2], o[(R >> 2) - 1], (unsigned)(R & 3));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- 5. a' += X^T u, b' += u^T u (as k_bcd_w32)
+        {
+            int ui[2][16];
+#pragma unroll
+            for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+                for (int s = 0; s < 16; s++) ui[tt][s] = (int)ub8[128 * s + 16 * tt];
+            i32x4 qa[2];
+#pragma unroll
+            for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    const unsigned p01 = __builtin_amdgcn_perm((unsigned)ui[tt][4 * d + 1], (unsigned)ui[tt][4 * d], 0x0C0C0400u);
+                    const unsigned p23 = __builtin_amdgcn_perm((unsigned)ui[tt][4 * d + 3], (unsigned)ui[tt][4 * d + 2], 0x04000C0Cu);
+                    qa[tt][d] = (int)(p01 | p23);
+                }
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) accQ[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(qa[i], qa[j], accQ[i][j], 0, 0, 0);
+#pragma unroll
+            for (int h = 0; h < 4; h++) {
+                f32x4 px[4];
+#pragma unroll
+                for (int s = 0; s < 4; s++) px[s] = *reinterpret_cast<const f32x4*>(xp[s & 3] + 256 * (4 * h + s));
+#pragma unroll
+                for (int s = 0; s < 4; s++)
+#pragma unroll
+                    for (int tt = 0; tt < 2; tt++) {
+                        const float pu = (float)ui[tt][4 * h + s];
+#pragma unroll
+                        for (int c = 0; c < 4; c++) accP[c][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(px[s][c], pu, accP[c][tt], 0, 0, 0);
+                    }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    const long slot = (long)pd.blk0 + bd.blk;
+    float* Pp = Ppart + slot * 64 * LRF_RPB;
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) Pp[(4 * (4 * lq + reg) + c) * LRF_RPB + 16 * tt + li] = accP[c][tt][reg];
+    float* Qp = Qpart + slot * LRF_RPB * LRF_RPB;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) Qp[(16 * i + 4 * lq + reg) * LRF_RPB + 16 * j + li] = (float)accQ[i][j][reg];
+}

@@ -188,7 +188,8 @@ def test_wave_kernel_for_ranks_9_to_16_equals_workgroup_kernel_and_oracle(oracle
 @pytest.mark.parametrize("hw_b", [(173, 264, 272), (512, 768, 48)])
 def test_wave_kernel_for_ranks_17_to_32_equals_workgroup_kernel_and_oracle(oracle, hw_b):
     """k_bcd_w32 (one wave per 384-row block, lane = row Gauss-Seidel on int16 pairs; lrf_bcdw32_kernel.hip) takes the
-    iterations >= 2 of a run whose planes all have ranks 17..32 once the run has 1024 blocks, k_bcd_mid below that: 272
+    iterations >= 2 of a run whose planes all have ranks 17..32 once the run has 512 blocks — and k_bcd_w32f<R> the first
+    iteration when they all have the SAME rank —, k_bcd_mid below that: 272
     ragged 173x264 images (4 blocks each, the last sub-tile of a block 22 rows) and 48 images of 512x768 (24 blocks each)
     against chunks of 8 of the same images, bit for bit, and against the oracle on one image; every rank 17..32 appears in
     some plane (odd ranks solve a padding column; ranks that are not multiples of four load and store a partial dword),
@@ -201,7 +202,9 @@ def test_wave_kernel_for_ranks_17_to_32_equals_workgroup_kernel_and_oracle(oracl
     imgs = (torch.nn.functional.interpolate(base, size=(H, W), mode="bilinear", align_corners=False)
             + torch.randn(B, 3, H, W, generator=g) * 6).clamp(0, 255).to(torch.uint8).cuda()
     for ranks, bounds in (((17, 18, 19), (-16, 15)), ((20, 21, 22), (-3, 5)), ((23, 24, 25), (-16, 15)), ((26, 27, 28), (-16, 15)),
-                          ((29, 30, 31), (-16, 15)), ((32, 17, 32), (-3, 5)), ((32, 32, 32), (-16, 15)), ((21, 21, 21), (-22, 22))):
+                          ((29, 30, 31), (-16, 15)), ((32, 17, 32), (-3, 5)), ((32, 32, 32), (-16, 15)), ((21, 21, 21), (-22, 22)),
+                          # one rank in every plane: the first iteration runs on k_bcd_w32f<R> too (any bounds)
+                          ((17, 17, 17), (-16, 15)), ((22, 22, 22), (-128, 127)), ((27, 27, 27), (-3, 5)), ((30, 30, 30), (-16, 15))):
         U, V = lrf_amd.qmf_factorize_batch(imgs, ranks, num_iters=4, bounds=bounds)
         for b0 in (0, B - 8):
             Us, Vs = lrf_amd.qmf_factorize_batch(imgs[b0:b0 + 8].clone(), ranks, num_iters=4, bounds=bounds)
