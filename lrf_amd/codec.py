@@ -86,6 +86,7 @@ def qmf_factorize_host(images: torch.Tensor, ranks: Sequence[int], num_iters: in
     (page-locked — torch's pin_memory — for link-speed copies), the int8 factors come back as CPU tensors.  The batch
     streams through the pipelined encoder (include/lrf_hip.h, lrf_pipe): uploads, kernels and downloads of different
     sub-batches overlap.  Same values as qmf_factorize_batch, bit for bit."""
+    release_plane_lanes()  # idle contexts / streams of small any-shape calls would cost the pipe's schedule
     pipe = _lib.pipe(device, slots, sub_batch)
     return pipe.encode_rgb_host(images, list(ranks), num_iters, math.ceil(bounds[0]), math.floor(bounds[1]), init_sign, out)
 
@@ -251,6 +252,7 @@ def qmf_encode_batch(images: torch.Tensor, rank=None, quality=None, bounds=(-16,
             pass
         else:
             ranks = qmf_ranks((H, W), rank, quality)
+            release_plane_lanes()  # idle contexts / streams of small any-shape calls would cost the pipe's schedule
             pipe = _lib.pipe(None)
             streams = []
             for first, n, U, V in pipe.encode_rgb_host_iter(images, ranks, num_iters, math.ceil(bounds[0]), math.floor(bounds[1]),
@@ -473,12 +475,32 @@ _PLANE_LANES = {}
 
 
 def _plane_lanes(device):
-    """three contexts and three streams per (host thread, device) for the plane-parallel small calls of _qmf_encode_anyshape"""
+    """three contexts and three streams per (host thread, device) for the plane-parallel small calls of _qmf_encode_anyshape.
+    They are released again (release_plane_lanes) before this thread's pipelined batch encoder runs: every extra context /
+    stream alive in the process costs the pipe's schedule (one unused context and two streams moved
+    256 x 512x768 host -> host from 6.1 to 7-9 ms), and a lane's workspace is a few hundred MB after a large patch=False call."""
     import threading
     key = (threading.get_ident(), torch.device(device).index or 0)
     if key not in _PLANE_LANES:
         _PLANE_LANES[key] = ([_lib.Context(key[1]) for _ in range(3)], [torch.cuda.Stream(device=key[1]) for _ in range(3)])
     return _PLANE_LANES[key]
+
+
+def release_plane_lanes(all_threads: bool = False) -> int:
+    """Destroys the plane lanes of the calling thread (or of every thread): their contexts (workspaces, streams) and torch
+    streams.  Called by qmf_encode_batch's host path; safe to call any time (the lanes are re-created on demand).
+    Returns the number of lane sets released."""
+    import threading
+    me = threading.get_ident()
+    n = 0
+    for key in [k for k in _PLANE_LANES if all_threads or k[0] == me]:
+        ctxs, lanes = _PLANE_LANES.pop(key)
+        for st in lanes:
+            st.synchronize()
+        for c in ctxs:
+            c.close()
+        n += 1
+    return n
 
 
 def pack_anyshape(factors, image_hw, ranks, bounds, patch_size, dtype_name="uint8", chroma=None) -> bytes:

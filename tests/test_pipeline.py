@@ -170,3 +170,36 @@ def test_pipelined_mixed_rank_families(ranks):
             assert torch.equal(U, U0.cpu()) and torch.equal(V, V0.cpu())
     finally:
         pipe.close()
+
+
+def test_small_anyshape_call_does_not_slow_the_pipe_down():
+    """a one-image any-shape qmf_encode runs its three planes on three extra contexts / streams ("plane
+    lanes"); left alive they cost every later pipelined batch encode of the process 15-45 % (one idle context and two streams:
+    6.1 -> 7-9 ms per 256 x 512x768).  The host path of qmf_encode_batch / qmf_factorize_host releases them first: the
+    host -> host time after such a call stays that of before (median of nine runs each, 5 % for the noise of a shared box)."""
+    import time
+    import lrf_amd
+    from lrf_amd import codec
+    g = torch.Generator().manual_seed(3)
+    host = torch.randint(0, 256, (128, 3, 512, 768), dtype=torch.uint8, generator=g).pin_memory()
+    small = torch.randint(0, 256, (3, 64, 96), dtype=torch.uint8, generator=g)
+
+    def median_ms():
+        ts = []
+        for _ in range(9):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            lrf_amd.qmf_factorize_host(host, (7, 3, 3))
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts)[4] * 1e3
+
+    for _ in range(3):
+        lrf_amd.qmf_factorize_host(host, (7, 3, 3))
+    before = median_ms()
+    lrf_amd.qmf_encode(small, quality=20, patch_size=(16, 16))  # three plane lanes are created ...
+    assert len(codec._PLANE_LANES) >= 1
+    after = median_ms()  # ... and released by the first host-path call
+    assert len(codec._PLANE_LANES) == 0
+    assert after <= before * 1.05, (before, after)
+    again = lrf_amd.qmf_encode(small, quality=20, patch_size=(16, 16))  # re-created on demand, same bytes
+    assert again == lrf_amd.qmf_encode(small, quality=20, patch_size=(16, 16))
