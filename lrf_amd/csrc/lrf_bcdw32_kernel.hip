@@ -164,12 +164,21 @@ void k_bcd_w32(const float* __restrict__ X, const PlaneDesc* __restrict__ planes
     if (nrows > LRF_KC) nrows = LRF_KC;
     const int nsub = (nrows + 63) >> 6;
 
-    // A operand of a^T = V^T X^T, resident: va[t][s] = V[4s + lq][16 t + li] (columns >= R of the table are zero)
-    float va[2][16];
+    // A operand of a^T = V^T X^T, resident: va[t][s] = V[4s + lq][16 t + li] (columns >= R of the table are zero).
+    // T1V (ranks up to 24): the second rank tile holds at most eight columns — its a = x V runs on the VALU with lane = row
+    // (k_bcd_w's device: 64 k-steps x NC v_fmac_f32_dpp per row, the same k-ordered fma chain as the MFMA; V[k][16 + c]
+    // broadcast out of vb[c][k >> 4] by DPP row_newbcast) instead of 64 MFMAs of which a quarter to a half would be used.
+    constexpr bool T1V = NP <= 12;
+    constexpr int NC = T1V ? 2 * NP - 16 : 1; // columns 16 .. 2 NP - 1
+    float va[T1V ? 1 : 2][16], vb[NC][4];
 #pragma unroll
-    for (int t = 0; t < 2; t++)
+    for (int t = 0; t < (T1V ? 1 : 2); t++)
 #pragma unroll
         for (int s = 0; s < 16; s++) va[t][s] = Vp[(4 * s + lq) * LRF_RPB + 16 * t + li];
+#pragma unroll
+    for (int c = 0; c < NC; c++)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) vb[c][g4] = T1V ? Vp[(16 * g4 + li) * LRF_RPB + 16 + c] : 0.f;
     // the symmetric int16 table, diagonal zero: dword (r, p) = (b[r][2p], b[r][2p+1]); lane l builds dwords l, l + 64, ...
 #pragma unroll
     for (int e = 0; e < 8; e++) {
@@ -291,11 +300,15 @@ void k_bcd_w32(const float* __restrict__ X, const PlaneDesc* __restrict__ planes
         unsigned long long s3 = 0;
 #endif
         {
-            f32x4 acc[4][2];
+            constexpr int NT = T1V ? 1 : 2;
+            f32x4 acc[4][NT];
 #pragma unroll
             for (int T = 0; T < 4; T++)
 #pragma unroll
-                for (int tt = 0; tt < 2; tt++) acc[T][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int tt = 0; tt < NT; tt++) acc[T][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            float a1[NC];
+#pragma unroll
+            for (int c = 0; c < NC; c++) a1[c] = 0.f;
 #pragma unroll
             for (int h = 0; h < 4; h++) { // the operand reads in four quarters of 16 registers
                 float bx[4][4];
@@ -304,21 +317,46 @@ void k_bcd_w32(const float* __restrict__ X, const PlaneDesc* __restrict__ planes
 #pragma unroll
                     for (int T = 0; T < 4; T++)
                         bx[s][T] = *reinterpret_cast<const float*>(xrow_b + T * 16 * 256 + ((16 * (4 * h + s)) ^ g16));
+                // T1V: the lane's own row, k = 16 h .. 16 h + 15 (chunks 4 h .. 4 h + 3 of the swizzled tile)
+                f32x4 xr[T1V ? 4 : 1];
+                if constexpr (T1V) {
+#pragma unroll
+                    for (int cch = 0; cch < 4; cch++)
+                        xr[cch] = *reinterpret_cast<const f32x4*>(&Xs[lane * 64 + 4 * ((4 * h + cch) ^ (lane & 15))]);
+                }
 #pragma unroll
                 for (int s = 0; s < 4; s++)
 #pragma unroll
                     for (int T = 0; T < 4; T++)
 #pragma unroll
-                        for (int tt = 0; tt < 2; tt++)
+                        for (int tt = 0; tt < NT; tt++)
                             acc[T][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[tt][4 * h + s], bx[s][T], acc[T][tt], 0, 0, 0);
+                if constexpr (T1V) {
+                    [&]<int... Ks>(std::integer_sequence<int, Ks...>) {
+                        (([&] {
+                             constexpr int k = Ks; // k-step 16 h + k: V[16 h + k][16 + c] = lane k of vb[c][h]
+#pragma unroll
+                             for (int c = 0; c < NC; c++) {
+                                 const float tabv = h == 0 ? vb[c][0] : (h == 1 ? vb[c][1] : (h == 2 ? vb[c][2] : vb[c][3]));
+                                 fmac_bc16<k>(a1[c], tabv, xr[k >> 2][k & 3]);
+                             }
+                         }()),
+                         ...);
+                    }(std::make_integer_sequence<int, 16>{});
+                }
             }
 #ifdef LRF_W32_STAMPS
-            asm volatile("" ::"v"(acc[3][1][3]), "v"(acc[0][0][0]));
+            asm volatile("" ::"v"(acc[3][NT - 1][3]), "v"(acc[0][0][0]));
             s3 = stamp_now();
             W32STAMP_ADD(c_w3, s2, s3); // operand reads + 128 MFMAs
 #endif
             w32_tiles_to_rows(acc[0][0], acc[1][0], acc[2][0], acc[3][0], a);
-            w32_tiles_to_rows(acc[0][1], acc[1][1], acc[2][1], acc[3][1], a + 16);
+            if constexpr (T1V) {
+#pragma unroll
+                for (int c = 0; c < 16; c++) a[16 + c] = c < NC ? a1[c < NC ? c : 0] : 0.f;
+            } else {
+                w32_tiles_to_rows(acc[0][NT - 1], acc[1][NT - 1], acc[2][NT - 1], acc[3][NT - 1], a + 16);
+            }
         }
         issue_x(tn, 1, 2, more);
         __builtin_amdgcn_sched_barrier(0);
