@@ -35,7 +35,7 @@
 #define LRF_BCDW_MIN_BLOCKS 1024 // smaller rank <= 8 runs iterate on the workgroup kernel k_bcd (run_bcd)
 #define LRF_BCDW16_MIN_BLOCKS 1024 // likewise for rank <= 16 runs and k_bcd_w16
 #define LRF_SHARE_MIN_BLOCKS 3072   // LRF_SHARES=2|3: a rank <= 8 call of this many blocks runs as two image shares (run_two_shares)
-#define LRF_BCDW32_MIN_BLOCKS 512  // likewise for rank 17..32 runs and k_bcd_w32 (32 images: 1.32 -> 1.11 ms at (20,10,10))
+#define LRF_BCDW32_MIN_BLOCKS 128  // likewise for rank 17..32 runs and k_bcd_w32 / k_bcd_w32f (12 images: 1.06 -> 0.99 ms at (20,10,10))
 
 static thread_local char g_err[512] = "";
 
@@ -120,7 +120,7 @@ struct lrf_ctx {
     // Kernel families of one call on streams of their own (run_init / run_bcd): the runs of plan_runs touch disjoint planes, so
     // the whole chain of a run — initialisation, b table, K x (U update, V update) — is independent of the other runs'; the
     // first run stays on `stream`, the others fork behind the Gram pass and are joined at the end of run_bcd.  Created on
-    // first use (a call with 1024 blocks or more — 768 with a rank above 16 — that mixes rank families); never while kernel profiling is on.
+    // first use (a call with 1024 blocks or more — 256 with a rank above 16 — that mixes rank families); never while kernel profiling is on.
     hipStream_t fam_stream[2] = {nullptr, nullptr};
     hipEvent_t fam_fork = nullptr, fam_join[2] = {nullptr, nullptr};
     bool fam_parallel = false;   // set by the fused entry points whose run_init is followed by run_bcd at once
@@ -305,7 +305,7 @@ static int table_rp(const Tables& t) { return table_rmax(t) <= 16 ? 16 : LRF_RPB
 // A run: consecutive planes (and their blocks) that iterate on one kernel family — 0: rank <= 8 (k_bcd_w), 1: rank <= 16
 // (k_bcd<., 16>), 2: rank <= 32 (k_bcd_mid) — with that family's table pitch (16 or LRF_RPB).  A small call takes ONE family,
 // the one its largest rank needs: its launches are latency chains per block and a second launch per iteration costs more than
-// a faster kernel saves.  From 1024 blocks on (768 with a rank above 16: plan_runs) every plane
+// a faster kernel saves.  From 1024 blocks on (256 with a rank above 16: plan_runs) every plane
 // goes to its own family (256 images: (16,8,8) 4.05 -> 3.78 ms, (20,10,10) 7.07 -> see DESIGN.md); the planes of the fused
 // encode are ordered by channel, so that is at most three runs.  Pitch-16 runs of a call whose table pitch is LRF_RPB use
 // the second table set (vf16 ...): the regions of the two pitches would overlap in one buffer.
@@ -326,9 +326,9 @@ static std::vector<FamRun> plan_runs(const Tables& t)
     const int rmax_t = table_rmax(t);
     // since the families of a call run side by side on streams of their own (round 3) the split pays from 1024 blocks on
     // (64 x 512x768: (16,8,8) 0.93 -> 0.89 ms, (20,10,10) 2.04 -> 1.36 with k_bcd_w32 on the luma run); calls with a rank above
-    // 16 split from 768 blocks (32 images: (20,10,10) 1.32 -> 1.11 ms).  It was 3072 while the runs shared one stream.
+    // 16 split from 256 blocks (24 images: (20,10,10) 1.27 -> 1.04 ms, 12 images 1.06 -> 0.99).  It was 3072 while the runs shared one stream.
     static const long env_blocks = getenv("LRF_FAMILY_SPLIT_BLOCKS") ? atol(getenv("LRF_FAMILY_SPLIT_BLOCKS")) : -1; // developer aid
-    const long min_blocks = env_blocks >= 0 ? env_blocks : (rmax_t > 16 ? 768 : 1024);
+    const long min_blocks = env_blocks >= 0 ? env_blocks : (rmax_t > 16 ? 256 : 1024);
     const bool split = !no_split && bcd_wave_variant() && rmax_t <= LRF_BIG_TO_ANY_RANK && (long)t.blocks.size() >= min_blocks;
     std::vector<FamRun> runs;
     for (int p = 0; p < (int)t.planes.size(); p++) {
