@@ -504,6 +504,9 @@ void k_bcd_w32(const float* __restrict__ X, const PlaneDesc* __restrict__ planes
 // registers) the compiler spills 69..116 registers; one launch of ten, so the simple form was kept.
 // =====================================================================================================================
 #define LRF_BCDW32F_LDS (64 * 64 * 4 + 64 * 32 + 32 * 32 * 4)
+#ifndef W32F_WAVES_PER_EU
+#define W32F_WAVES_PER_EU 1
+#endif
 
 template <int J>
 __device__ __forceinline__ float w32f_prod(const float t0, const float t1, const float u)
@@ -553,12 +556,16 @@ __device__ __forceinline__ float w32f_term2(const float (&u)[32], const float t0
     return odd + even;
 }
 
+// t0 / t1: the table row of column RR (prefetched by the caller's caller: two columns ahead, as in w32_solve — left to itself
+// the compiler hoists the reads of ALL columns above the first one, 40-64 registers)
 template <int R, int RR, bool FAST>
-__device__ __forceinline__ void w32f_cols(const float (&a)[32], float (&u)[32], const float* tabl, const float rd0, const float rd1,
-                                          const float dn0, const float dn1, const GsParams& gp, const int lob, const int hib, float& emax)
+__device__ __forceinline__ void w32f_cols(const float (&a)[32], float (&u)[32], const float* tabl, float t0, float t1, float n0, float n1,
+                                          const float rd0, const float rd1, const float dn0, const float dn1, const GsParams& gp,
+                                          const int lob, const int hib, float& emax)
 {
     if constexpr (RR < R) {
-        const float t0 = tabl[32 * RR], t1 = tabl[32 * RR + 16];
+        constexpr int RN = RR + 2 < R ? RR + 2 : R - 1;
+        const float m0 = tabl[32 * RN], m1 = tabl[32 * RN + 16]; // the row two columns ahead
         const float num = (a[RR] - w32f_term2<R, RR>(u, t0, t1)) + LRF_EPS;
         if (FAST) {
             const float q = w32_mul_bc16<RR & 15>(RR < 16 ? rd0 : rd1, num);
@@ -571,12 +578,15 @@ __device__ __forceinline__ void w32f_cols(const float (&a)[32], float (&u)[32], 
             const float val = rintf(num / get_bc16<RR & 15>(RR < 16 ? dn0 : dn1));
             u[RR] = __builtin_amdgcn_fmed3f(val, gp.lo, gp.hi);
         }
-        w32f_cols<R, RR + 1, FAST>(a, u, tabl, rd0, rd1, dn0, dn1, gp, lob, hib, emax);
+#ifdef W32F_COLUMN_FENCE
+        __builtin_amdgcn_sched_barrier(0); // the products of later columns stay behind this column (register pressure)
+#endif
+        w32f_cols<R, RR + 1, FAST>(a, u, tabl, n0, n1, m0, m1, rd0, rd1, dn0, dn1, gp, lob, hib, emax);
     }
 }
 
 template <int R>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W32F_WAVES_PER_EU, W32F_WAVES_PER_EU)))
 void k_bcd_w32f(const float* __restrict__ X, const PlaneDesc* __restrict__ planes, const BlockDesc* __restrict__ blocks,
                 const float* __restrict__ Vf, const float* __restrict__ Wf, const float* __restrict__ Bf, int8_t* __restrict__ U,
                 float* __restrict__ Ppart, float* __restrict__ Qpart, GsParams gp, int nblocks)
@@ -729,10 +739,10 @@ void k_bcd_w32f(const float* __restrict__ X, const PlaneDesc* __restrict__ plane
         // ---- 3. the ordered Gauss-Seidel, lane = row
         {
             float emax = 0.f;
-            w32f_cols<R, 0, true>(a, u, tabl, rd0, rd1, dn0, dn1, gp, lob, hib, emax);
+            w32f_cols<R, 0, true>(a, u, tabl, tabl[0], tabl[16], tabl[32], tabl[48], rd0, rd1, dn0, dn1, gp, lob, hib, emax);
             if (__any(!(emax <= gp.fthr))) { // rare: repeat with the reference's IEEE division
                 old_u(u);
-                w32f_cols<R, 0, false>(a, u, tabl, rd0, rd1, dn0, dn1, gp, lob, hib, emax);
+                w32f_cols<R, 0, false>(a, u, tabl, tabl[0], tabl[16], tabl[32], tabl[48], rd0, rd1, dn0, dn1, gp, lob, hib, emax);
             }
         }
         const int row = r0 + lane;

@@ -21,3 +21,13 @@ pytestmark = pytest.mark.gpu
 def test_fuzz_tool_is_clean(tool, args):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool)] + args, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+
+
+def test_fuzz_wave_kernels_for_ranks_17_to_32():
+    """tools/dev_fuzz_w32.py with the thresholds at one block, so that runs of any size iterate on k_bcd_w32 / k_bcd_w32f:
+    random shapes and batches, ranks 17..32 per plane, K, bounds inside and outside the int16-table range — bit for bit."""
+    env = dict(os.environ, LRF_FAMILY_SPLIT_BLOCKS="1", LRF_BCDW32_MIN_BLOCKS="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dev_fuzz_w32.py"), "7", "24"], capture_output=True, text=True,
+                       timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert r.stdout.count(": ok") == 24
