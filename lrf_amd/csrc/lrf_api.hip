@@ -22,6 +22,7 @@
 #include "lrf_bigrank_kernels.hip"
 #include "lrf_midrank_kernels.hip"
 #include "lrf_bcdw_kernel.hip"
+#include "lrf_bcdp_kernel.hip"
 #include "lrf_bcdw16_kernel.hip"
 #include "lrf_bcdw32_kernel.hip"
 #include "lrf_anyshape_kernels.hip"
@@ -34,6 +35,7 @@
 #define LRF_TABLE_SETS 6 // descriptor-table sets a context keeps resident (upload_tables)
 #define LRF_BCDW_MIN_BLOCKS 1024 // smaller rank <= 8 runs iterate on the workgroup kernel k_bcd (run_bcd)
 #define LRF_BCDW16_MIN_BLOCKS 1024 // likewise for rank <= 16 runs and k_bcd_w16
+#define LRF_PERSIST_MIN_BLOCKS 4096 // a rank <= 8 call of this many blocks runs its iterations 2..K in one launch (k_bcd_p)
 #define LRF_SHARE_MIN_BLOCKS 3072   // LRF_SHARES=2|3: a rank <= 8 call of this many blocks runs as two image shares (run_two_shares)
 #define LRF_BCDW32_MIN_BLOCKS 128  // likewise for rank 17..32 runs and k_bcd_w32 / k_bcd_w32f (12 images: 1.06 -> 0.99 ms at (20,10,10))
 
@@ -128,6 +130,10 @@ struct lrf_ctx {
     hipEvent_t planes_done = nullptr; // set by a pipe: recorded after the planes kernel of lrf_qmf_encode_rgb_u8 (input buffer free)
     // two image shares of one large call on two streams (run_two_shares; an experiment, off unless LRF_SHARES=2 or 3): per
     // share the events Gram done / initial tables done / U update done / V update done
+    // the persistent iteration kernel (k_bcd_p; experiment, LRF_PERSIST=1): its queue head, tickets and flags; its error word
+    // comes back into page-locked host memory behind every launch and is looked at by the next call / lrf_ctx_synchronize
+    DevBuf psync;
+    int* h_perr = nullptr;
     hipEvent_t share_ev[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
 };
 
@@ -582,7 +588,63 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
     static const bool w32_off = getenv("LRF_NO_BCDW32") && getenv("LRF_NO_BCDW32")[0] == '1'; // developer comparison aid: k_bcd_mid<0> instead
     static const long w32_min = getenv("LRF_BCDW32_MIN_BLOCKS") ? atol(getenv("LRF_BCDW32_MIN_BLOCKS")) : LRF_BCDW32_MIN_BLOCKS; // developer aid
     static const long w16_min = getenv("LRF_BCDW16_MIN_BLOCKS") ? atol(getenv("LRF_BCDW16_MIN_BLOCKS")) : LRF_BCDW16_MIN_BLOCKS; // developer aid
+    // Iterations 2..K of a large single-run rank <= 8 call in ONE launch (k_bcd_p, lrf_bcdp_kernel.hip; round 4): the U updates of
+    // all iterations pulled from a queue, each matrix's V update done by the last of its blocks to finish.  From 4096 blocks
+    // on (256 x 512x768: 2.05 -> 1.93 ms per step; 64 x 1365x2048: 3.47 -> 3.27 ms); calls of many small matrices lose (300 x
+    // 173x264: 0.73 -> 0.79 ms) and stay on the launch-per-iteration path.  LRF_PERSIST=0 turns it off, =1 forces it from
+    // LRF_BCDW_MIN_BLOCKS blocks on (tests).
+    static const int persist_env = getenv("LRF_PERSIST") ? atoi(getenv("LRF_PERSIST")) : -1;
+    const bool persist_ok = runs.size() == 1 && runs[0].fam == 0 && wave_variant && K >= 2 && !c->fam_forked &&
+                            !(c->profile && (c->profile_mask & ~((1u << LRF_K_BCD) | (1u << LRF_K_BCD_PERSIST))) != 0);
+    const bool use_persist = persist_ok && persist_env != 0 &&
+                             runs[0].nblocks >= (persist_env == 1 ? LRF_BCDW_MIN_BLOCKS : LRF_PERSIST_MIN_BLOCKS);
+    if (use_persist) {
+        if (!(c->attr_done & (1u << 3))) {
+            HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_p, hipFuncAttributeMaxDynamicSharedMemorySize, LRF_BCDW_LDS));
+            c->attr_done |= 1u << 3;
+        }
+        if (!c->h_perr) {
+            HIP_TRY(hipHostMalloc((void**)&c->h_perr, sizeof(int), hipHostMallocDefault));
+            *c->h_perr = 0;
+        }
+        if (*c->h_perr) {
+            *c->h_perr = 0;
+            return set_err(LRF_EHIP, "k_bcd_p: a wave's poll for a V update expired in an earlier call on this context");
+        }
+    }
     for (int it = 0; it < K; it++) {
+        if (use_persist && it == 1) {
+            const FamRun& r = runs[0];
+            const size_t sbytes = sizeof(BcdpSync) + (2 * (size_t)r.nplanes + (size_t)r.nblocks) * sizeof(int); // (+ a debug count per block)
+            int rcp = ensure(c, c->psync, sbytes);
+            if (rcp) return rcp;
+            hipLaunchKernelGGL(k_bcdp_clear, dim3((unsigned)((sbytes / 4 + 255) / 256)), dim3(256), 0, c->stream, (int*)c->psync.p, (int)(sbytes / 4));
+            LAUNCH_CHECK();
+            const int total_waves = (K - 1) * r.nblocks;
+            int wgs = (total_waves + LRF_BCDW_WAVES - 1) / LRF_BCDW_WAVES;
+            if (wgs > 512) wgs = 512; // two workgroups per CU resident; later ones would only find the queue empty
+            {
+                Prof p(c, LRF_K_BCD_PERSIST);
+                hipLaunchKernelGGL(k_bcd_p, dim3((unsigned)wgs), dim3(64 * LRF_BCDW_WAVES), LRF_BCDW_LDS, c->stream, X, pl, bl + r.block0,
+                                   (float*)c->vf.p, (float*)c->bf.p, U, (float*)c->ppart.p, (float*)c->qpart.p, V, gp, r.nblocks, K - 1,
+                                   r.nplanes, r.plane0, (BcdpSync*)c->psync.p);
+                LAUNCH_CHECK();
+            }
+            HIP_TRY(hipMemcpyAsync(c->h_perr, &((BcdpSync*)c->psync.p)->err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+#ifdef LRF_BCDP_DEBUG
+            {
+                std::vector<int> cnt(r.nblocks);
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                HIP_TRY(hipMemcpy(cnt.data(), ((BcdpSync*)c->psync.p)->cell + 2 * r.nplanes, r.nblocks * sizeof(int), hipMemcpyDeviceToHost));
+                int want = 0, bad = 0;
+                for (int i = 0; i < K - 1; i++) want += 64 * (1 + 1000 * i);
+                for (int b = 0; b < r.nblocks; b++)
+                    if (cnt[b] != want && bad++ < 8) fprintf(stderr, "[k_bcd_p debug] block %d processed-count code %d (want %d)\n", b, cnt[b], want);
+                fprintf(stderr, "[k_bcd_p debug] %d blocks, %d with a wrong count, err %d\n", r.nblocks, bad, *c->h_perr);
+            }
+#endif
+            break;
+        }
         {
             Prof p(c, LRF_K_BCD);
             const int mode = (it == 0) ? first_mode : 0;
@@ -875,6 +937,8 @@ void lrf_ctx_destroy(lrf_ctx* c)
             if (b->p) (void)hipFree(b->p);
     }
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->h_perr) (void)hipHostFree(c->h_perr);
+    if (c->psync.p) (void)hipFree(c->psync.p);
     for (int i = 0; i < 2; i++) {
         if (c->fam_stream[i]) {
             (void)hipStreamSynchronize(c->fam_stream[i]);
@@ -914,6 +978,10 @@ int lrf_ctx_synchronize(lrf_ctx* c)
     if (!c) return set_err(LRF_EINVAL, "ctx is NULL");
     LRF_ON_DEVICE(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->h_perr && *c->h_perr) {
+        *c->h_perr = 0;
+        return set_err(LRF_EHIP, "k_bcd_p: a wave's poll for a V update expired (the results of that call are invalid)");
+    }
     return LRF_OK;
 }
 

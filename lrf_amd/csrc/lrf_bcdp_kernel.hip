@@ -1,0 +1,402 @@
+// lrf_bcdp_kernel.hip — k_bcd_p: EXPERIMENT (off unless LRF_PERSIST=1): iterations 2..K of a rank <= 8
+// call in ONE launch.  Included by lrf_api.hip after lrf_bcdw_kernel.hip, whose per-block arithmetic (k_bcd_w<0>) it repeats
+// operation for operation — the outputs are bit-identical.
+//
+// What it removes: per iteration two kernel boundaries, the k_vupdate launch (a latency chain per matrix that leaves the chip
+// idle) and the drain / refill of the U-update launch.  How:
+//   * items (iteration, block) are pulled in iteration-major order from one device-scope counter by whatever waves are
+//     resident (a plain grid; a wave that finds the queue empty leaves);
+//   * a block stores its partials of X^T u / u^T u, drains its stores, and takes a ticket of its matrix; the LAST arriver of
+//     (matrix, iteration) performs that matrix's V update on its own (k_vupdate on one wave: partial sums in block order,
+//     the 64-row Gauss-Seidel lane = row, the b table of the new V) and publishes flag[matrix] = iteration + 1;
+//   * a block of iteration i + 1 polls its matrix's flag before it loads V.  Queue order makes this deadlock-free without
+//     any assumption on dispatch: an item of iteration i + 1 is pulled only after every item of iteration i has been pulled
+//     by a running wave, and running waves of iteration i never wait for later items.  In steady state nobody spins: the
+//     same matrix's next item comes a full round of the queue later.  Every poll loop is BOUNDED (LRF_BCDP_MAX_POLLS): on
+//     expiry the wave sets the error word and returns, so the grid always drains; the host refuses the result.
+//   * visibility across CUs / XCDs (MI355X_MICROARCH.md, inter-workgroup visibility): everything one wave writes and another
+//     reads inside the launch — int8 U rows, partials, V table, b table — is stored `sc1` (write-through) and loaded `sc1`
+//     (L1 bypass), every storing wave drains (`s_waitcnt vmcnt(0)`) before its ticket / flag, tickets and flags are
+//     agent-scope atomics.  X is read-only and loaded plainly.
+// Summation orders, tables and outputs are those of k_bcd_w<0> + k_vupdate<8>.
+
+#ifndef LRF_BCDP_MAX_POLLS
+#define LRF_BCDP_MAX_POLLS (1 << 20) // x ~1 us per poll: a second, then the wave gives up (error word)
+#endif
+
+struct BcdpSync {
+    int head;        // next item
+    int err;         // set by a wave whose poll expired
+    int pad[30];     // (head on a line of its own)
+    int cell[1];     // [nplanes] tickets, then [nplanes] flags
+};
+
+// the queue head, tickets and flags start at zero: cleared by a kernel of the same stream (kernel -> kernel order is certain)
+__global__ void k_bcdp_clear(int* p, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) __hip_atomic_store(p + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // write-through: the line does not stay in this XCD's L2
+}
+
+__device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1(float* p, float v)
+{
+#ifdef LRF_BCDP_PLAIN_PSTORE // timing experiment only
+    *p = v;
+#else
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ void st_sc1_u32_unaligned(void* p, unsigned v)
+{
+#ifdef LRF_BCDP_PLAIN_USTORE // timing experiment only
+    *reinterpret_cast<u32_unaligned*>(p) = v;
+#else
+    asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#endif
+}
+__device__ __forceinline__ unsigned ld_sc1_u32_unaligned(const void* p) // the caller waits (s_waitcnt vmcnt(0)) before the use
+{
+    unsigned v;
+    asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+// k_vupdate<8> on one wave (lane = row of V): lds = the wave's own 18 KB (a_s [64][16], v_s [64][16], gt_s)
+__device__ __forceinline__ void bcdp_vupdate(const PlaneDesc& pd, int pli, const float* __restrict__ Ppart, const float* __restrict__ Qpart,
+                                             float* __restrict__ Vf, float* __restrict__ Bf, int8_t* __restrict__ V8, const GsParams gp,
+                                             int write_i8, float* lds, int lane)
+{
+    float* a_s = lds;
+    float* v_s = lds + 64 * LRF_RP;
+    float* gt_s = lds + 2 * 64 * LRF_RP;
+    const int R = pd.R;
+    // a' = ((P0 + P1) + P2) + ... per element, b' likewise: element e of the [64][16] table = lane + 64 j (j < 16), of the
+    // [16][16] table = lane + 64 j (j < 4); eight blocks' loads in flight at a time
+    float acc[16], q[4];
+#pragma unroll
+    for (int j = 0; j < 16; j++) acc[j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; j++) q[j] = 0.f;
+    const float* Pp = Ppart + (long)pd.blk0 * 64 * LRF_RP + lane;
+    const float* Qp = Qpart + (long)pd.blk0 * LRF_RP * LRF_RP + lane;
+    constexpr int NB = 4; // blocks in flight: 80 registers (the kernel must stay inside 256 for two waves per SIMD)
+    for (int b0 = 0; b0 < pd.nblk; b0 += NB) {
+        float pv[NB][16], qv[NB][4];
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const long blk = b0 + k < pd.nblk ? b0 + k : b0;
+#pragma unroll
+            for (int j = 0; j < 16; j++) pv[k][j] = ld_sc1(Pp + blk * 64 * LRF_RP + 64 * j);
+#pragma unroll
+            for (int j = 0; j < 4; j++) qv[k][j] = ld_sc1(Qp + blk * LRF_RP * LRF_RP + 64 * j);
+        }
+#pragma unroll
+        for (int k = 0; k < NB; k++)
+            if (b0 + k < pd.nblk) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) acc[j] = (b0 + k == 0) ? pv[k][j] : acc[j] + pv[k][j];
+#pragma unroll
+                for (int j = 0; j < 4; j++) q[j] = (b0 + k == 0) ? qv[k][j] : q[j] + qv[k][j];
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        a_s[lane + 64 * j] = acc[j];
+        v_s[lane + 64 * j] = ld_sc1(Vf + (long)pli * 64 * LRF_RP + lane + 64 * j);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int idx = lane + 64 * j, jj = idx >> 4, r = idx & 15; // b' entry (jj, r)
+        if (jj < R && r < R) {
+            if (jj == r) {
+                const float den = (q[j] + 0.f) + LRF_EPS;
+                gt_s[r * LRF_GT_LD + LRF_GT_DEN] = den;
+                gt_s[r * LRF_GT_LD + LRF_GT_RDEN] = 1.0f / den;
+            } else {
+                gt_s[r * LRF_GT_LD + (jj < r ? jj : jj - 1)] = q[j];
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
+        const bool native = (long)(R - 1) * 64 < 400;
+        const float no_tab[17] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        gs_dispatch<8, false>(R, &a_s[lane * LRF_RP], &v_s[lane * LRF_RP], nullptr, 0, gt_s, native, gp, no_tab);
+        float* Vp = Vf + (long)pli * 64 * LRF_RP + lane * LRF_RP;
+        for (int r = 0; r < R; r++) st_sc1(Vp + r, v_s[lane * LRF_RP + r]);
+        if (write_i8) {
+            int8_t* vo = V8 + pd.v_off + (long)lane * R;
+            for (int r = 0; r < R; r++) vo[r] = (int8_t)v_s[lane * LRF_RP + r];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (!write_i8) {
+        // the b table of the new V: into LDS (make_gtable's stores), then out with write-through stores
+        float* gt_n = a_s; // a_s is free now
+        make_gtable(v_s, 64, R, gt_n, lane, 64);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float* gt_g = Bf + (long)pli * LRF_GT_STRIDE;
+        for (int i = lane; i < R * LRF_GT_LD; i += 64) st_sc1(gt_g + i, gt_n[i]);
+    }
+}
+
+__global__ __launch_bounds__(64 * LRF_BCDW_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_bcd_p(const float* __restrict__ X, const PlaneDesc* __restrict__ planes,
+                                                               const BlockDesc* __restrict__ blocks, float* __restrict__ Vf,
+                                                               float* __restrict__ Bf, int8_t* __restrict__ U, float* __restrict__ Ppart,
+                                                               float* __restrict__ Qpart, int8_t* __restrict__ V8, GsParams gp, int nblocks,
+                                                               int niter, int nplanes, int plane0, BcdpSync* sync)
+{
+    constexpr int RMAX = 8;
+    extern __shared__ __attribute__((aligned(16))) float bcdp_lds[]; // LRF_BCDW_LDS bytes, per wave: X tile, then u
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
+    float* Xs = bcdp_lds + wave * (64 * 64 + 64 * RMAX);
+    float* us = Xs + 64 * 64;
+    int* ticket = sync->cell;
+    int* flag = sync->cell + nplanes;
+    const float* xp[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) xp[e] = &Xs[lq * 64 + 4 * (li ^ (4 * e + lq))];
+    const float* ub = &us[lq * RMAX + (li & 7)];
+    const float* uq = &us[(lq + 4 * (li >> 3)) * RMAX + (li & 7)];
+    const float* xrow = &Xs[lane * 64];
+    const int g16 = 16 * xsw(lane);
+    const int total = niter * nblocks;
+
+    for (;;) {
+        // lane 0 pulls, EVERY lane then holds lane 0's value (an explicit lane-0 broadcast: with `readfirstlane` of a variable
+        // that is 0 in the other lanes the compiler's control flow let lanes 1..63 go on with item 0 after lane 0 had left)
+        int idx_l = 0;
+        if (lane == 0) idx_l = __hip_atomic_fetch_add(&sync->head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int idx = __builtin_amdgcn_readfirstlane(__shfl(idx_l, 0, 64));
+        if (idx >= total) return;
+#ifdef LRF_BCDP_ROT
+        const int it = idx / nblocks, blk = (idx - it * nblocks + 100) % nblocks; // debug: which item is pulled first
+#else
+        const int it = idx / nblocks, blk = idx - it * nblocks;
+#endif
+#ifdef LRF_BCDP_DEBUG
+        atomicAdd(&sync->cell[2 * nplanes + blk], 1 + 1000 * it); // every active lane
+#endif
+        const BlockDesc bd = blocks[blk];
+        const PlaneDesc pd = planes[bd.plane];
+        const int pl = bd.plane - plane0; // index into the tickets / flags
+        const int R = pd.R;
+        if (it > 0) { // the V update of (matrix, it - 1) must have been published
+            int polls = 0;
+            while (__hip_atomic_load(&flag[pl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < it) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++polls > LRF_BCDP_MAX_POLLS) {
+                    if (lane == 0) __hip_atomic_store(&sync->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return;
+                }
+            }
+        }
+#ifdef LRF_BCDP_FENCES
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        const float* Xp = X + pd.x_off + (long)bd.row0 * 64;
+        const float* Vp = Vf + (long)bd.plane * 64 * LRF_RP;
+        const float* gt = Bf + (long)bd.plane * LRF_GT_STRIDE;
+        int8_t* Ub = U + pd.u_off + (long)bd.row0 * R;
+        int nrows = pd.M - bd.row0;
+        if (nrows > LRF_KC) nrows = LRF_KC;
+        const int nsub = (nrows + 63) >> 6;
+        const bool native = pd.native_t2_u != 0;
+
+        float vreg[8][4];
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+#pragma unroll
+            for (int kb = 0; kb < 4; kb++) vreg[r][kb] = ld_sc1(Vp + (16 * kb + li) * LRF_RP + r);
+        float tab[5];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int ci = 16 * j + li, tr = ci >> 3, tn = ci & 7;
+            tab[j] = ld_sc1(gt + tr * LRF_GT_LD + (tn < 7 ? tn : LRF_GT_RDEN));
+        }
+        tab[4] = ld_sc1(gt + (li & 7) * LRF_GT_LD + LRF_GT_DEN);
+
+        f32x4 xq[4][4];
+        auto issue_x = [&](int t, int T0, int T1, bool live) {
+            const int r0 = t * 64;
+#pragma unroll
+            for (int T = T0; T < T1; T++) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    int row = r0 + 16 * T + 4 * q + lq;
+                    row = row < nrows ? row : nrows - 1;
+                    if (live) xq[T][q] = *reinterpret_cast<const f32x4*>(Xp + (long)row * 64 + 4 * li);
+                    else xq[T][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        };
+        // The old int8 row with compiler-tracked sc1 loads: three ALIGNED dwords that cover the row's R <= 8 bytes (a hand-issued
+        // asm load would leave its result register open to compiler copies before the data has landed); row_bytes() shifts
+        // them into place.  The last dword is clamped to the one that holds the row's last byte (never past the allocation).
+        unsigned uraw[3];
+        int ush = 0;
+        auto issue_u = [&](int t) {
+            int row = t * 64 + lane;
+            row = row < nrows ? row : nrows - 1;
+            const uintptr_t a0 = reinterpret_cast<uintptr_t>(Ub + (long)row * R);
+            const uintptr_t base = a0 & ~(uintptr_t)3, last = (a0 + R - 1) & ~(uintptr_t)3;
+            ush = (int)(a0 & 3);
+            const unsigned* p0 = reinterpret_cast<const unsigned*>(base);
+            const unsigned* p1 = reinterpret_cast<const unsigned*>(base + 4 <= last ? base + 4 : last);
+            const unsigned* p2 = reinterpret_cast<const unsigned*>(base + 8 <= last ? base + 8 : last);
+#ifdef LRF_BCDP_PLAIN_U
+            uraw[0] = *p0; uraw[1] = *p1; uraw[2] = *p2;
+#else
+            uraw[0] = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uraw[1] = __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uraw[2] = __hip_atomic_load(p2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+        };
+        auto row_bytes = [&](unsigned& lo, unsigned& hi) { // bytes 0..3 and 4..7 of the row (bytes at or past R: unspecified)
+            lo = __builtin_amdgcn_alignbyte(uraw[1], uraw[0], (unsigned)ush);
+            hi = __builtin_amdgcn_alignbyte(uraw[2], uraw[1], (unsigned)ush);
+        };
+
+        f32x4 accP[4], accQ = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; c++) accP[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        issue_u(0);
+        issue_x(0, 0, 4, true);
+        for (int t = 0; t < nsub; t++) {
+            const int r0 = t * 64;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int T = 0; T < 4; T++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int m = 16 * T + 4 * q + lq;
+                    *reinterpret_cast<f32x4*>(&Xs[m * 64 + 4 * (li ^ (4 * q + lq))]) = xq[T][q];
+                }
+            float u[RMAX];
+            const int row = r0 + lane;
+            {
+                unsigned lo, hi;
+                row_bytes(lo, hi);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    u[r] = (float)(int)(int8_t)(lo >> (8 * r));
+                    u[4 + r] = (float)(int)(int8_t)(hi >> (8 * r));
+                }
+            }
+            const int tn = t + 1;
+            const bool more = tn < nsub;
+            if (more) issue_u(tn);
+            issue_x(tn, 0, 2, more);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_sched_barrier(0);
+            float a[RMAX];
+#pragma unroll
+            for (int r = 0; r < RMAX; r++) a[r] = 0.f;
+            row_times_v_dispatch(R, xrow, g16, vreg, a);
+            issue_x(tn, 2, 3, more);
+            __builtin_amdgcn_sched_barrier(0);
+            gs_regs_dispatch<RMAX>(R, a, u, tab, native, gp);
+            if (row >= nrows) {
+#pragma unroll
+                for (int r = 0; r < RMAX; r++) u[r] = 0.f;
+            }
+            issue_x(tn, 3, 4, more);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < RMAX; r += 4) *reinterpret_cast<f32x4*>(&us[lane * RMAX + r]) = (f32x4){u[r], u[r + 1], u[r + 2], u[r + 3]};
+            if (row < nrows) {
+                int8_t* uo = Ub + (long)row * R;
+                unsigned lo = 0, hi = 0;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    lo |= ((unsigned)(int)u[r] & 0xffu) << (8 * r);
+                    hi |= ((unsigned)(int)u[4 + r] & 0xffu) << (8 * r);
+                }
+                if (R >= 4) {
+                    st_sc1_u32_unaligned(uo, lo);
+                    const unsigned long long w = ((unsigned long long)hi << 32) | lo;
+                    st_sc1_u32_unaligned(uo + R - 4, (unsigned)(w >> (8 * (R - 4))));
+                } else {
+                    __hip_atomic_store(uo, (int8_t)lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (R > 1) __hip_atomic_store(uo + 1, (int8_t)(lo >> 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (R > 2) __hip_atomic_store(uo + 2, (int8_t)(lo >> 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_sched_barrier(0);
+            float pu[16], qu[8];
+#pragma unroll
+            for (int s = 0; s < 16; s++) {
+                float v = ub[4 * s * RMAX];
+                pu[s] = (li < RMAX) ? v : 0.f;
+            }
+#pragma unroll
+            for (int h = 0; h < 8; h++) qu[h] = uq[8 * h * RMAX];
+            f32x4 px[16];
+#pragma unroll
+            for (int s = 0; s < 16; s++) px[s] = *reinterpret_cast<const f32x4*>(xp[s & 3] + 256 * s);
+#pragma unroll
+            for (int s = 0; s < 16; s++) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) accP[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(px[s][c], pu[s], accP[c], 0, 0, 0);
+                if (s & 1) accQ = __builtin_amdgcn_mfma_f32_16x16x4f32(qu[s >> 1], qu[s >> 1], accQ, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        const long slot = (long)pd.blk0 + bd.blk;
+        float* Pp = Ppart + slot * 64 * LRF_RP;
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) st_sc1(Pp + (4 * (4 * lq + reg) + c) * LRF_RP + li, accP[c][reg]);
+        float* Qp = Qpart + slot * LRF_RP * LRF_RP;
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int i = 4 * lq + reg;
+            const float mine = accQ[reg];
+            const float other = __shfl(mine, ((lq + 2) & 3) * 16 + ((li + 8) & 15), 64);
+            st_sc1(Qp + i * LRF_RP + li, (i < 8 && li < 8) ? mine + other : 0.f);
+        }
+        // every store of this wave has left (write-through) before it is counted
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef LRF_BCDP_FENCES
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        int arrived_l = 0;
+        if (lane == 0) arrived_l = __hip_atomic_fetch_add(&ticket[pl], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int arrived = __builtin_amdgcn_readfirstlane(__shfl(arrived_l, 0, 64));
+        if (arrived == (it + 1) * pd.nblk - 1) { // the last block of (matrix, iteration): its V update
+#ifdef LRF_BCDP_FENCES
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            bcdp_vupdate(pd, bd.plane, Ppart, Qpart, Vf, Bf, V8, gp, it == niter - 1 ? 1 : 0, Xs, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef LRF_BCDP_FENCES
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            // every lane stores the same word (no `if (lane == 0)` here: followed by the loop head's `if (lane == 0)` pull it let
+            // the compiler thread lane 0 through both and retire it from the loop alone — lanes 1..63 then went on with item 0)
+            __hip_atomic_store(&flag[pl], it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}

@@ -214,3 +214,29 @@ def test_wave_kernel_for_ranks_17_to_32_equals_workgroup_kernel_and_oracle(oracl
         for c in range(3):
             u, v = oracle.qmf_decompose(X[c], ranks[c], 4, bounds)
             assert np.array_equal(got[2 * c], u.astype(np.int8)) and np.array_equal(got[2 * c + 1], v.astype(np.int8)), (ranks, bounds, c)
+
+
+def test_persistent_iteration_kernel_equals_launch_per_iteration():
+    """k_bcd_p (iterations 2..K of a large rank <= 8 call in one launch: items pulled from a queue, each matrix's V update by
+    the last of its blocks, sc1 hand-offs; lrf_bcdp_kernel.hip) against the launch-per-iteration path: tools/dev_persist.py in
+    two child processes (the switch is read once per process) — the factors' hashes of five workloads (256 and 128 Kodak-sized
+    images at three rank triples, 300 ragged 173x264 images, 64 of 1365x2048), each after one and after 26 runs, must agree;
+    then 60 more runs next to other GPU work, every one equal to the first."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    outs = {}
+    for mode in ("0", "1"):
+        env = dict(os.environ, LRF_PERSIST=mode, LRF_SOAK="60" if mode == "1" else "0")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dev_persist.py")], capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+        outs[mode] = [ln for ln in r.stdout.splitlines() if ln.startswith("persist=")]
+        if mode == "1":
+            assert "soak: 60 runs, 0 differ from the first" in r.stdout, r.stdout[-500:]
+    assert len(outs["0"]) == len(outs["1"]) == 5
+    for a, b in zip(outs["0"], outs["1"]):
+        sha_a = a.split("sha ")[1].split(")")[0]
+        sha_b = b.split("sha ")[1].split(")")[0]
+        assert sha_a == sha_b, (a, b)
+        first, after = sha_a.split(" (after 26 runs ")
+        assert first == after, a
