@@ -711,8 +711,7 @@ __global__ __launch_bounds__(256) void k_any_gram_mfma(const float* __restrict__
 // [M,192] Gram matrices of svd_encode and of the RGB colour-space branch, 16 x 8 / 8 x 16 patches.  k_any_eig<1> walks its
 // matrix in global memory three times per step (8.3 ms per 256 matrices of 192 x 192, ~95 % of svd_encode's initialisation);
 // here 256 NC threads hold it the way k_init does for n = 64 — thread (lane i, column chunk cc, row group rg) keeps
-// A[16 NC rg + j][64 cc + i], j < 16 NC, as NC 16-double vectors, so row k is read with a register index — and a step costs
-// two barriers.  Arithmetic: k_init's step (one reduction for sigma, t = 1 / (sigma + |x0| nrm),
+// A[16 (rg + 4 s) + j][64 cc + i], s < NC, j < 16, as NC 16-double vectors, so row k is read with a register index.  Arithmetic: k_init's step (one reduction for sigma, t = 1 / (sigma + |x0| nrm),
 // p = t A v from chains over the row groups, commutative rank-2 update).  Output: row k of A keeps the reflector v_k (i > k),
 // td = d[n], e[n], tau[n] for k_any_eig<1>, which then starts at its eigenvalue stage.
 // lane `src_lane` of a double register, as a wave-uniform value (two v_readlane_b32: the result lives in SGPRs)
@@ -721,46 +720,77 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane)
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src_lane), __builtin_amdgcn_readlane(__double2loint(v), src_lane));
 }
 
+// lane j of the quad (CTRL = j * 0x55: quad_perm [j, j, j, j]) of a double register
+template <int CTRL>
+__device__ __forceinline__ double quad_bcast_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
 template <int NC>
 __global__ __launch_bounds__(256 * NC) void k_any_tridiag_reg(double* __restrict__ G, int n, double* __restrict__ TD)
 {
-    constexpr int RPT = 16 * NC, NP = 64 * NC; // rows per thread, padded side
-    __shared__ __attribute__((aligned(16))) double xrow2[2 * NP], cpart[4 * NP];
+    constexpr int NP = 64 * NC; // padded side
+    constexpr int CP = NP + 2; // pitch of cpart: the four lanes of a quad read four sub-block rows of one column (distinct banks)
+    __shared__ __attribute__((aligned(16))) double xrow2[2 * NP], cpart[4 * NC * CP], pbuf[NP]; // cpart: one chain sum per 16-row sub-block and column
     double* A = G + (long)blockIdx.x * n * n;
     double* td = TD + (long)blockIdx.x * 3 * n;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cc = wave % NC, rg = wave / NC; // column chunk, row group (wave-uniform)
-    const int col = 64 * cc + lane, row0 = rg * RPT;
+    // Column chunk cc, row group rg (wave-uniform).  The thread's NC 16-row vectors are the sub-blocks rg, rg + 4, rg + 8 of
+    // its column (rows 16 (rg + 4 s) ..): dealt out cyclically, because the trailing matrix shrinks from the top — with
+    // consecutive sub-blocks per group the last group worked on 48 rows in every step while the first idled after step 47
+    // (stamps: its waves spent 4.4 k of 11.3 k cycles per step in the first barrier); now every group holds ceil(active / 4)
+    // sub-blocks, two thirds of the critical wave's products.  Which thread forms a sub-block's chain does not change a bit:
+    // the chains (sixteen consecutive rows from zero) and the order their sums are added in are the oracle's.
+    const int cc = wave % NC, rg = wave / NC;
+    const int col = 64 * cc + lane;
+    // the waves of a SIMD get different priorities (by row group): their scalar chains then run one after the other, each
+    // under the products of the others, instead of all three crawling together (9.8 k cycles per step against 10.2 k)
+#ifndef LRF_REG_NO_PRIO
+    if (rg == 3) __builtin_amdgcn_s_setprio(3);
+    else if (rg == 2) __builtin_amdgcn_s_setprio(2);
+    else if (rg == 1) __builtin_amdgcn_s_setprio(1);
+#endif
     d16 Ar[NC];
 #pragma unroll
     for (int s = 0; s < NC; s++)
 #pragma unroll
         for (int jj = 0; jj < 16; jj++) {
-            const int r = row0 + 16 * s + jj;
+            const int r = 16 * (rg + 4 * s) + jj;
             Ar[s][jj] = (r < n && col < n) ? A[(long)r * n + col] : 0.0;
         }
     // Every wave holds v and w on ALL columns (NC values per lane: the scalars of a step are computed redundantly, same bits),
     // so the values a thread needs at its ROWS come out of the wave's own registers by v_readlane (wave-uniform, in SGPRs)
     // instead of broadcast LDS reads — twelve waves reading 144 doubles each per step had made the LDS the bottleneck
-    // (1.26 -> 0.5 ms per 256 matrices of 192 x 192) — and w needs neither LDS nor a third barrier.
-    // A 16-row sub-block lies inside one 64-column chunk: chunk and first lane of sub-block s of this wave's rows.
+    // (1.26 -> 0.5 ms per 256 matrices of 192 x 192).
+    // Sub-block s of this wave's rows lies in column chunk s of v / w, lanes 16 rg .. 16 rg + 15.
     auto pick = [&](const double (&q)[NC], int chunk) __attribute__((always_inline)) {
         double r = q[0];
         if (NC > 1 && chunk == 1) r = q[1];
         if (NC > 2 && chunk == 2) r = q[NC - 1];
         return r;
     };
+#ifdef LRF_REG_STAMPS
+    unsigned long long st[7] = {0, 0, 0, 0, 0, 0, 0}, tq = __builtin_amdgcn_s_memtime(), tq0 = tq;
+#define REG_STAMP(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); st[i] += tn_ - tq; tq = tn_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define REG_STAMP(i)
+#endif
     for (int k = 0; k < n - 2; k++) {
         double* xrow = xrow2 + NP * (k & 1); // double-buffered: a slower wave may still be reading the other one
-        if (rg == k / RPT) { // the row group that holds row k publishes it (entries up to column k as zeros)
-            const int kl = k - row0, jj = kl & 15;
+        const bool holds_k = rg == ((k >> 4) & 3); // the row group that holds row k (sub-block k / 16 = rg + 4 s)
+        if (holds_k) { // publishes it (entries up to column k as zeros)
+            const int sk = k >> 6, jj = k & 15;
             double xk = Ar[0][jj];
-            if (NC > 1 && (kl >> 4) == 1) xk = Ar[1][jj];
-            if (NC > 2 && (kl >> 4) == 2) xk = Ar[NC - 1][jj];
+            if (NC > 1 && sk == 1) xk = Ar[1][jj];
+            if (NC > 2 && sk == 2) xk = Ar[NC - 1][jj];
             xrow[col] = (col > k) ? xk : 0.0;
         }
         __syncthreads();
+        REG_STAMP(1);
         // every wave: the reflector's scalars (same bits in all of them)
         double xs[NC], sq = 0.0;
 #pragma unroll
@@ -782,32 +812,49 @@ __global__ __launch_bounds__(256 * NC) void k_any_tridiag_reg(double* __restrict
 #pragma unroll
         for (int c2 = 0; c2 < NC; c2++) vk[c2] = (64 * c2 + lane == k + 1) ? vfix : xs[c2];
         const double vc = pick(vk, cc);
-        if (rg == k / RPT && col > k && col < n) A[(long)k * n + col] = vc; // v_k for the back-transformation
+        REG_STAMP(2);
+        if (holds_k && col > k && col < n) A[(long)k * n + col] = vc; // v_k for the back-transformation
         const bool cols_live = 64 * cc + 63 > k; // wave-uniform: some column of this wave is still in the trailing matrix
-        { // matvec partial over this thread's rows: one chain per 16-row sub-block; finished sub-blocks (v = 0 there) are skipped
-            double cs = 0.0;
+        { // matvec partials over this thread's rows: one chain per 16-row sub-block; finished sub-blocks (v = 0 there) are skipped
 #pragma unroll
             for (int s = 0; s < NC; s++) {
-                const int r0 = row0 + 16 * s;
+                const int r0 = 16 * (rg + 4 * s);
                 double c = 0.0;
                 if (cols_live && r0 + 15 > k) { // wave-uniform
-                    const double src = pick(vk, r0 >> 6);
+                    const double src = vk[s];
 #pragma unroll
-                    for (int jj = 0; jj < 16; jj++) c = fma(Ar[s][jj], readlane_f64(src, (r0 & 63) + jj), c);
+                    for (int jj = 0; jj < 16; jj++) c = fma(Ar[s][jj], readlane_f64(src, 16 * rg + jj), c);
                 }
-                cs = s ? cs + c : c;
+                cpart[(rg + 4 * s) * CP + col] = (col > k) ? c : 0.0;
             }
-            cpart[rg * NP + col] = (col > k) ? cs : 0.0;
+        }
+        REG_STAMP(3);
+        __syncthreads();
+        // p = t A v, ONCE per column: wave w combines the sub-block sums of the columns 16 w .. 16 w + 15 — lane (column
+        // 16 w + (lane >> 2), row group g = lane & 3) adds its group's NC sums in order, the four groups meet inside the quad
+        // (DPP), in the oracle's order ((g0 + g1) + g2) + g3 — and publishes them; a third barrier.  (With every wave reading
+        // all 4 NC sums of all its columns, as round 3's kernel did with four sums per column, the LDS sets the pace of the
+        // step: 221 KB per step at n = 192, 9.8 k cycles per step against 8.9 k.  One wave doing all scalar work of a step —
+        // the reflector, then p, K, w — with v and w handed out through LDS was measured too: four barriers, 9.2 k: the
+        // redundant form lets the waves of a SIMD drift apart, so that one's scalar chain runs under another's products.)
+        {
+            const int g = lane & 3, ci = 16 * wave + (lane >> 2);
+            double cgv = cpart[(NC * g) * CP + ci];
+#pragma unroll
+            for (int s2i = 1; s2i < NC; s2i++) cgv = cgv + cpart[(NC * g + s2i) * CP + ci];
+            const double c0 = quad_bcast_f64<0x00>(cgv), c1 = quad_bcast_f64<0x55>(cgv), c2q = quad_bcast_f64<0xaa>(cgv), c3 = quad_bcast_f64<0xff>(cgv);
+            const double pv = t * (((c0 + c1) + c2q) + c3);
+            if (g == 0) pbuf[ci] = pv;
         }
         __syncthreads();
-        // every wave: p, K, w on all columns
+        REG_STAMP(4);
+        // every wave: K, w on all columns
         double wk[NC];
         {
             double pk[NC], s2 = 0.0;
 #pragma unroll
             for (int c2 = 0; c2 < NC; c2++) {
-                const int i = 64 * c2 + lane;
-                pk[c2] = t * (((cpart[i] + cpart[NP + i]) + cpart[2 * NP + i]) + cpart[3 * NP + i]);
+                pk[c2] = pbuf[64 * c2 + lane];
                 s2 = fma(pk[c2], vk[c2], s2);
             }
             const double K = (0.5 * t) * wave_tree64(s2);
@@ -816,27 +863,38 @@ __global__ __launch_bounds__(256 * NC) void k_any_tridiag_reg(double* __restrict
             if (tid == 0) { td[n + k] = alpha; td[2 * n + k] = t; }
         }
         const double wc = pick(wk, cc);
-        // rank-2 update as two fmas per element (fp64 vector instructions cost 8 cycles per wave here: the four-instruction
-        // commutative form of k_init doubled the kernel's dominant term).  Element (r, c) and its mirror image may now differ
-        // in the last bit; nothing here needs exact symmetry (parity of this path is by tolerance).  v, w are zero up to k.
+        REG_STAMP(5);
+        // rank-2 update as two fmas per element (the four-instruction commutative form of k_init doubled the kernel's dominant
+        // term).  Element (r, c) and its mirror image may differ in the last bit; the full matrix is carried.  v, w are zero up to k.
 #pragma unroll
         for (int s = 0; s < NC; s++) {
-            const int r0 = row0 + 16 * s;
+            const int r0 = 16 * (rg + 4 * s);
             if (!(cols_live && r0 + 15 > k)) continue; // wave-uniform: rows and columns up to k are finished
-            const double sv = pick(vk, r0 >> 6), sw = pick(wk, r0 >> 6);
+            const double sv = vk[s], sw = wk[s];
 #pragma unroll
             for (int jj = 0; jj < 16; jj++) {
-                const double vj = readlane_f64(sv, (r0 & 63) + jj), wj = readlane_f64(sw, (r0 & 63) + jj);
+                const double vj = readlane_f64(sv, 16 * rg + jj), wj = readlane_f64(sw, 16 * rg + jj);
                 Ar[s][jj] = fma(-vj, wc, fma(-wj, vc, Ar[s][jj]));
             }
         }
+#ifdef LRF_REG_STAMPS
+        asm volatile("" ::"v"(Ar[0][0]), "v"(Ar[NC - 1][15]));
+#endif
+        REG_STAMP(6);
     }
+#ifdef LRF_REG_STAMPS
+    if (lane == 0 && blockIdx.x < 1024) { // every wave's lane 0: [matrix][wave][8]
+        unsigned long long* o = g_stamps + 8 * (16 * blockIdx.x + wave);
+        o[0] = __builtin_amdgcn_s_memtime() - tq0;
+        for (int q = 1; q < 7; q++) o[q] = st[q];
+    }
+#endif
     // d = diagonal, e[n-2] = A[n-1][n-2]
 #pragma unroll
     for (int s = 0; s < NC; s++)
 #pragma unroll
         for (int jj = 0; jj < 16; jj++) {
-            const int r = row0 + 16 * s + jj;
+            const int r = 16 * (rg + 4 * s) + jj;
             if (r == col && r < n) td[r] = Ar[s][jj];
             if (r == n - 1 && col == n - 2) td[n + n - 2] = Ar[s][jj];
         }

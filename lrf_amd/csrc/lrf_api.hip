@@ -133,7 +133,8 @@ struct lrf_ctx {
     // the persistent iteration kernel (k_bcd_p; experiment, LRF_PERSIST=1): its queue head, tickets and flags; its error word
     // comes back into page-locked host memory behind every launch and is looked at by the next call / lrf_ctx_synchronize
     DevBuf psync;
-    int* h_perr = nullptr;
+    int* h_perr = nullptr;     // page-locked: k_bcd_p writes it directly when a poll expires
+    bool psync_dirty = false;  // the queue state of k_bcd_p is not all-zero (a failed launch)
     hipEvent_t share_ev[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
 };
 
@@ -609,6 +610,7 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
         }
         if (*c->h_perr) {
             *c->h_perr = 0;
+            c->psync_dirty = true;
             return set_err(LRF_EHIP, "k_bcd_p: a wave's poll for a V update expired in an earlier call on this context");
         }
     }
@@ -616,10 +618,13 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
         if (use_persist && it == 1) {
             const FamRun& r = runs[0];
             const size_t sbytes = sizeof(BcdpSync) + (2 * (size_t)r.nplanes + (size_t)r.nblocks) * sizeof(int); // (+ a debug count per block)
+            const void* before = c->psync.p;
             int rcp = ensure(c, c->psync, sbytes);
             if (rcp) return rcp;
-            hipLaunchKernelGGL(k_bcdp_clear, dim3((unsigned)((sbytes / 4 + 255) / 256)), dim3(256), 0, c->stream, (int*)c->psync.p, (int)(sbytes / 4));
-            LAUNCH_CHECK();
+            if (c->psync.p != before || c->psync_dirty) { // a launch leaves the state zeroed (its last wave); a new buffer or a failed launch does not
+                HIP_TRY(hipMemsetAsync(c->psync.p, 0, c->psync.cap, c->stream));
+                c->psync_dirty = false;
+            }
             const int total_waves = (K - 1) * r.nblocks;
             int wgs = (total_waves + LRF_BCDW_WAVES - 1) / LRF_BCDW_WAVES;
             if (wgs > 512) wgs = 512; // two workgroups per CU resident; later ones would only find the queue empty
@@ -627,10 +632,9 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
                 Prof p(c, LRF_K_BCD_PERSIST);
                 hipLaunchKernelGGL(k_bcd_p, dim3((unsigned)wgs), dim3(64 * LRF_BCDW_WAVES), LRF_BCDW_LDS, c->stream, X, pl, bl + r.block0,
                                    (float*)c->vf.p, (float*)c->bf.p, U, (float*)c->ppart.p, (float*)c->qpart.p, V, gp, r.nblocks, K - 1,
-                                   r.nplanes, r.plane0, (BcdpSync*)c->psync.p);
+                                   r.nplanes, r.plane0, (BcdpSync*)c->psync.p, c->h_perr, 2 * r.nplanes);
                 LAUNCH_CHECK();
             }
-            HIP_TRY(hipMemcpyAsync(c->h_perr, &((BcdpSync*)c->psync.p)->err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
 #ifdef LRF_BCDP_DEBUG
             {
                 std::vector<int> cnt(r.nblocks);
@@ -641,6 +645,7 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
                 for (int b = 0; b < r.nblocks; b++)
                     if (cnt[b] != want && bad++ < 8) fprintf(stderr, "[k_bcd_p debug] block %d processed-count code %d (want %d)\n", b, cnt[b], want);
                 fprintf(stderr, "[k_bcd_p debug] %d blocks, %d with a wrong count, err %d\n", r.nblocks, bad, *c->h_perr);
+                c->psync_dirty = true; // the per-block counts are not cleared by the kernel
             }
 #endif
             break;
@@ -980,6 +985,7 @@ int lrf_ctx_synchronize(lrf_ctx* c)
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->h_perr && *c->h_perr) {
         *c->h_perr = 0;
+        c->psync_dirty = true;
         return set_err(LRF_EHIP, "k_bcd_p: a wave's poll for a V update expired (the results of that call are invalid)");
     }
     return LRF_OK;
@@ -1853,7 +1859,7 @@ int lrf_host_unregister(void* p)
     return LRF_OK;
 }
 
-#if defined(LRF_STAMPS) || defined(LRF_INIT_STAMPS) || defined(LRF_BLK_STAMPS)
+#if defined(LRF_STAMPS) || defined(LRF_INIT_STAMPS) || defined(LRF_BLK_STAMPS) || defined(LRF_REG_STAMPS)
 int lrf_debug_read_stamps(lrf_ctx* c, unsigned long long* out_host, int n)
 {
     HIP_TRY(hipStreamSynchronize(c->stream));

@@ -1,5 +1,5 @@
-// lrf_bcdp_kernel.hip — k_bcd_p: EXPERIMENT (off unless LRF_PERSIST=1): iterations 2..K of a rank <= 8
-// call in ONE launch.  Included by lrf_api.hip after lrf_bcdw_kernel.hip, whose per-block arithmetic (k_bcd_w<0>) it repeats
+// lrf_bcdp_kernel.hip — k_bcd_p (round 4): iterations 2..K of a large rank <= 8 call in ONE launch
+// (default from LRF_PERSIST_MIN_BLOCKS blocks on, lrf_api.hip; LRF_PERSIST=0 turns it off).  Included by lrf_api.hip after lrf_bcdw_kernel.hip, whose per-block arithmetic (k_bcd_w<0>) it repeats
 // operation for operation — the outputs are bit-identical.
 //
 // What it removes: per iteration two kernel boundaries, the k_vupdate launch (a latency chain per matrix that leaves the chip
@@ -13,7 +13,7 @@
 //     any assumption on dispatch: an item of iteration i + 1 is pulled only after every item of iteration i has been pulled
 //     by a running wave, and running waves of iteration i never wait for later items.  In steady state nobody spins: the
 //     same matrix's next item comes a full round of the queue later.  Every poll loop is BOUNDED (LRF_BCDP_MAX_POLLS): on
-//     expiry the wave sets the error word and returns, so the grid always drains; the host refuses the result.
+//     expiry the wave sets the error word (host memory) and returns, so the grid always drains; the host refuses the result.
 //   * visibility across CUs / XCDs (MI355X_MICROARCH.md, inter-workgroup visibility): everything one wave writes and another
 //     reads inside the launch — int8 U rows, partials, V table, b table — is stored `sc1` (write-through) and loaded `sc1`
 //     (L1 bypass), every storing wave drains (`s_waitcnt vmcnt(0)`) before its ticket / flag, tickets and flags are
@@ -26,17 +26,13 @@
 
 struct BcdpSync {
     int head;        // next item
-    int err;         // set by a wave whose poll expired
+    int done;        // waves that have left
     int pad[30];     // (head on a line of its own)
     int cell[1];     // [nplanes] tickets, then [nplanes] flags
 };
-
-// the queue head, tickets and flags start at zero: cleared by a kernel of the same stream (kernel -> kernel order is certain)
-__global__ void k_bcdp_clear(int* p, int n)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) __hip_atomic_store(p + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // write-through: the line does not stay in this XCD's L2
-}
+// The queue head, tickets and flags start at zero.  The buffer is zeroed when it is allocated (and after a failed launch);
+// after that every launch leaves it zeroed: the last wave to leave (`done`) clears what the launch used — no clearing kernel
+// and no copy of an error word per call (the error word lives in page-locked host memory the kernel writes to directly).
 
 __device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_sc1(float* p, float v)
@@ -151,7 +147,7 @@ __global__ __launch_bounds__(64 * LRF_BCDW_WAVES) __attribute__((amdgpu_waves_pe
                                                                const BlockDesc* __restrict__ blocks, float* __restrict__ Vf,
                                                                float* __restrict__ Bf, int8_t* __restrict__ U, float* __restrict__ Ppart,
                                                                float* __restrict__ Qpart, int8_t* __restrict__ V8, GsParams gp, int nblocks,
-                                                               int niter, int nplanes, int plane0, BcdpSync* sync)
+                                                               int niter, int nplanes, int plane0, BcdpSync* sync, int* err_host, int ncells)
 {
     constexpr int RMAX = 8;
     extern __shared__ __attribute__((aligned(16))) float bcdp_lds[]; // LRF_BCDW_LDS bytes, per wave: X tile, then u
@@ -169,6 +165,18 @@ __global__ __launch_bounds__(64 * LRF_BCDW_WAVES) __attribute__((amdgpu_waves_pe
     const float* xrow = &Xs[lane * 64];
     const int g16 = 16 * xsw(lane);
     const int total = niter * nblocks;
+    // leaving: the wave's own stores to the flags have landed before it is counted; the last one out zeroes the state
+    auto leave = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int l = 0;
+        if (lane == 0) l = __hip_atomic_fetch_add(&sync->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int d = __builtin_amdgcn_readfirstlane(__shfl(l, 0, 64));
+        if (d == (int)(gridDim.x * LRF_BCDW_WAVES) - 1) {
+            for (int i = lane; i < ncells; i += 64) __hip_atomic_store(&sync->cell[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sync->head, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sync->done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
 
     for (;;) {
         // lane 0 pulls, EVERY lane then holds lane 0's value (an explicit lane-0 broadcast: with `readfirstlane` of a variable
@@ -176,7 +184,10 @@ __global__ __launch_bounds__(64 * LRF_BCDW_WAVES) __attribute__((amdgpu_waves_pe
         int idx_l = 0;
         if (lane == 0) idx_l = __hip_atomic_fetch_add(&sync->head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int idx = __builtin_amdgcn_readfirstlane(__shfl(idx_l, 0, 64));
-        if (idx >= total) return;
+        if (idx >= total) {
+            leave();
+            return;
+        }
 #ifdef LRF_BCDP_ROT
         const int it = idx / nblocks, blk = (idx - it * nblocks + 100) % nblocks; // debug: which item is pulled first
 #else
@@ -193,8 +204,8 @@ __global__ __launch_bounds__(64 * LRF_BCDW_WAVES) __attribute__((amdgpu_waves_pe
             int polls = 0;
             while (__hip_atomic_load(&flag[pl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < it) {
                 __builtin_amdgcn_s_sleep(8);
-                if (++polls > LRF_BCDP_MAX_POLLS) {
-                    if (lane == 0) __hip_atomic_store(&sync->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (++polls > LRF_BCDP_MAX_POLLS) { // (the state stays dirty: the host sees the error word and zeroes it)
+                    __hip_atomic_store(err_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     return;
                 }
             }

@@ -28,7 +28,7 @@ typedef double d16 __attribute__((ext_vector_type(16)));
 #define LRF_SIGMA_TINY 1e-280
 
 // Diagnostic build only (-DLRF_STAMPS, never shipped): per-phase cycle sums of k_bcd, wave 0 of each workgroup.
-#if defined(LRF_STAMPS) || defined(LRF_INIT_STAMPS) || defined(LRF_BLK_STAMPS)
+#if defined(LRF_STAMPS) || defined(LRF_INIT_STAMPS) || defined(LRF_BLK_STAMPS) || defined(LRF_REG_STAMPS)
 __device__ unsigned long long g_stamps[8 * 16384];
 __device__ __forceinline__ unsigned long long stamp_now()
 {
