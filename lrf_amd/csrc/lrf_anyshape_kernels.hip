@@ -1522,6 +1522,16 @@ __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, 
                                                  const double* __restrict__ td_in /* d, e, tau of k_any_tridiag_reg, or NULL */)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef LRF_REG_STAMPS // (tools/dev_stamps_eig.py: stage boundaries of every wave's lane 0, [matrix][wave][8])
+    unsigned long long est[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int esi = 0;
+#define EIG_STAMP() { __builtin_amdgcn_sched_barrier(0); est[esi++] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#define EIG_STAMPS_OUT() { if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) { unsigned long long* o_ = g_stamps + 8 * (16 * blockIdx.x + (threadIdx.x >> 6)); for (int q_ = 0; q_ < 8; q_++) o_[q_] = est[q_]; } }
+    EIG_STAMP();
+#else
+#define EIG_STAMP()
+#define EIG_STAMPS_OUT()
+#endif
     double* Lv = reinterpret_cast<double*>(smem);
     double* Lw = Lv + n;
     double* Ld = Lw + n;
@@ -1878,6 +1888,7 @@ __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, 
     }
     __syncthreads();
 
+    EIG_STAMP();
     if (stop_after == 1) return;
     // ---- Gershgorin hull, pivmin
     {
@@ -1929,69 +1940,96 @@ __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, 
         }
         __syncthreads();
         const int n8 = n & ~7;
-        for (int r = wave; r < Rc; r += 4) {
-            const int kk = n - 1 - r;
-            double a = Lscal[2], b = Lscal[3];
-            for (int pass = 0; pass < 10; pass++) {
-                const double h = (b - a) / 65.0;
-                const double x = a + h * (double)(lane + 1);
-                double p = 1.0, pp = 0.0;
-                unsigned sg = 0u;
-                int cnt = 0;
-                bool zero = false;
-#pragma unroll 1
-                for (int j0 = 0; j0 < n8; j0 += 8) { // not unrolled further: the table reads must stay inside the pass loop
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        const double2 q = de[j0 + u];
-                        const double pn = fma(q.x - x, p, -(q.y * pp));
-                        zero |= (pn == 0.0);
-                        sg = __builtin_amdgcn_alignbit(sg, (unsigned)__double2hiint(pn), 31);
-                        pp = p;
-                        p = pn;
-                    }
-                    cnt += __popc((sg ^ (sg >> 1)) & 0xffu);
+        // A wave runs TWO searches at once (eigenvalues r and r + 4, as k_init does): the two dependent chains and their table
+        // reads interleave, and a call with 5..8 eigenvalues needs one round instead of two (the stage issues ~7.5 vector
+        // instructions per Sturm step and wave, so two interleaved searches cost what two rounds did: 70 us at R = 5, n = 192).
+        // A wave with one eigenvalue left runs it twice (same bits, result stored once).
+        auto sturm_slow = [&](double x) {
+            double p = 1.0, pp = 0.0;
+            int cnt = 0;
+            for (int j = 0; j < n; j++) {
+                const double2 q = de[j];
+                double pn = fma(q.x - x, p, -(q.y * pp));
+                if (pn == 0.0) pn = (__double2hiint(p) < 0) ? 0x1p-200 : -0x1p-200;
+                cnt += ((__double2hiint(pn) ^ __double2hiint(p)) < 0);
+                pp = p;
+                p = pn;
+                if ((j & 7) == 7) {
                     const int ea = __builtin_amdgcn_frexp_exp(p), eb = __builtin_amdgcn_frexp_exp(pp);
                     const int m = ea > eb ? ea : eb;
                     p = ldexp(p, -m);
                     pp = ldexp(pp, -m);
                 }
-                for (int j = n8; j < n; j++) {
-                    const double2 q = de[j];
-                    const double pn = fma(q.x - x, p, -(q.y * pp));
-                    zero |= (pn == 0.0);
-                    cnt += ((__double2hiint(pn) ^ __double2hiint(p)) < 0);
-                    pp = p;
-                    p = pn;
+            }
+            return cnt;
+        };
+        for (int r0 = wave; r0 < Rc; r0 += 8) {
+            const int r1 = r0 + 4 < Rc ? r0 + 4 : r0;
+            const int kk[2] = {n - 1 - r0, n - 1 - r1};
+            double a[2] = {Lscal[2], Lscal[2]}, b[2] = {Lscal[3], Lscal[3]};
+            for (int pass = 0; pass < 10; pass++) {
+                double x[2], p[2] = {1.0, 1.0}, pp[2] = {0.0, 0.0};
+                unsigned sg[2] = {0u, 0u};
+                int cnt[2] = {0, 0};
+                bool zero[2] = {false, false};
+#pragma unroll
+                for (int s2 = 0; s2 < 2; s2++) {
+                    const double h = (b[s2] - a[s2]) / 65.0;
+                    x[s2] = a[s2] + h * (double)(lane + 1);
                 }
-                if (__any(zero)) { // wave-uniform
-                    p = 1.0, pp = 0.0, cnt = 0;
-                    for (int j = 0; j < n; j++) {
-                        const double2 q = de[j];
-                        double pn = fma(q.x - x, p, -(q.y * pp));
-                        if (pn == 0.0) pn = (__double2hiint(p) < 0) ? 0x1p-200 : -0x1p-200;
-                        cnt += ((__double2hiint(pn) ^ __double2hiint(p)) < 0);
-                        pp = p;
-                        p = pn;
-                        if ((j & 7) == 7) {
-                            const int ea = __builtin_amdgcn_frexp_exp(p), eb = __builtin_amdgcn_frexp_exp(pp);
-                            const int m = ea > eb ? ea : eb;
-                            p = ldexp(p, -m);
-                            pp = ldexp(pp, -m);
+#pragma unroll 1
+                for (int j0 = 0; j0 < n8; j0 += 8) { // not unrolled further: the table reads must stay inside the pass loop
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const double2 q = de[j0 + u];
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; s2++) {
+                            const double pn = fma(q.x - x[s2], p[s2], -(q.y * pp[s2]));
+                            zero[s2] |= (pn == 0.0);
+                            sg[s2] = __builtin_amdgcn_alignbit(sg[s2], (unsigned)__double2hiint(pn), 31);
+                            pp[s2] = p[s2];
+                            p[s2] = pn;
                         }
                     }
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; s2++) {
+                        cnt[s2] += __popc((sg[s2] ^ (sg[s2] >> 1)) & 0xffu);
+                        const int ea = __builtin_amdgcn_frexp_exp(p[s2]), eb = __builtin_amdgcn_frexp_exp(pp[s2]);
+                        const int m = ea > eb ? ea : eb;
+                        p[s2] = ldexp(p[s2], -m);
+                        pp[s2] = ldexp(pp[s2], -m);
+                    }
                 }
-                const unsigned long long mask = __ballot(cnt > kk);
-                const int jj = mask ? (int)__builtin_ctzll(mask) : 64;
-                const double xm = __shfl(x, jj > 0 ? jj - 1 : 0, 64), xj = __shfl(x, jj < 64 ? jj : 63, 64);
-                const double na = (jj == 0) ? a : xm, nb = (jj == 64) ? b : xj;
-                a = na;
-                b = nb;
+                for (int j = n8; j < n; j++) {
+                    const double2 q = de[j];
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; s2++) {
+                        const double pn = fma(q.x - x[s2], p[s2], -(q.y * pp[s2]));
+                        zero[s2] |= (pn == 0.0);
+                        cnt[s2] += ((__double2hiint(pn) ^ __double2hiint(p[s2])) < 0);
+                        pp[s2] = p[s2];
+                        p[s2] = pn;
+                    }
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; s2++) {
+                    if (__any(zero[s2])) cnt[s2] = sturm_slow(x[s2]); // wave-uniform
+                    const unsigned long long mask = __ballot(cnt[s2] > kk[s2]);
+                    const int jj = mask ? (int)__builtin_ctzll(mask) : 64;
+                    const double xm = __shfl(x[s2], jj > 0 ? jj - 1 : 0, 64), xj = __shfl(x[s2], jj < 64 ? jj : 63, 64);
+                    const double na = (jj == 0) ? a[s2] : xm, nb = (jj == 64) ? b[s2] : xj;
+                    a[s2] = na;
+                    b[s2] = nb;
+                }
             }
-            if (lane == 0) Llam[r] = ldexp(0.5 * (a + b), sc);
+            if (lane == 0) {
+                Llam[r0] = ldexp(0.5 * (a[0] + b[0]), sc);
+                if (r1 != r0) Llam[r1] = ldexp(0.5 * (a[1] + b[1]), sc);
+            }
         }
     }
     __syncthreads();
+    EIG_STAMP();
     if (stop_after == 2) return;
     if (stop_after == 9) { // developer aid (tools/dev_any_init_bits.py): d, e, lambda as raw doubles in the E1 output
         double* dbg = reinterpret_cast<double*>(E1 + (long)blockIdx.x * n * R);
@@ -2001,47 +2039,61 @@ __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, 
         }
         return;
     }
-    // ---- twisted factorisation, thread per eigenvalue
-    for (int r = tid; r < Rc; r += 256) {
+    // ---- twisted factorisation, TWO threads per eigenvalue (t = 2 r + dir): the two pivot sequences are independent chains
+    // of one division per step, and so are the two halves of the vector on either side of the twist index — one lane each
+    // instead of one after the other.  The two lanes of a pair sit in one wave, so the loops are written ONCE with the
+    // direction as data (a branch per direction would run the two one after the other); the arithmetic per element is
+    // unchanged.  The twist index is searched by both lanes, half of the range each.
+    for (int t = tid; t < 2 * Rc; t += 256) { // (t and t ^ 1 are lanes of one wave: 256 is even)
+        const int r = t >> 1, dir = t & 1;
         const double lam = Llam[r];
-        double q = Ld[0] - lam;
-        Dp[r] = q;
-        for (int j = 1; j < n; j++) {
-            if (fabs(q) < pivmin) q = -pivmin;
-            q = (Ld[j] - lam) - Le2[j - 1] / q;
-            Dp[(long)j * Rc + r] = q;
+        double* Dsel = dir ? Dm : Dp; // D+ runs forward from row 0, D- backward from row n - 1
+        {
+            const int j0 = dir ? n - 1 : 0;
+            double q = Ld[j0] - lam;
+            Dsel[(long)j0 * Rc + r] = q;
+            for (int i = 1; i < n; i++) {
+                const int j = dir ? n - 1 - i : i;
+                const double e2 = Le2[dir ? j : j - 1];
+                if (fabs(q) < pivmin) q = -pivmin;
+                q = (Ld[j] - lam) - e2 / q;
+                Dsel[(long)j * Rc + r] = q;
+            }
         }
-        q = Ld[n - 1] - lam;
-        Dm[(long)(n - 1) * Rc + r] = q;
-        for (int j = n - 2; j >= 0; j--) {
-            if (fabs(q) < pivmin) q = -pivmin;
-            q = (Ld[j] - lam) - Le2[j] / q;
-            Dm[(long)j * Rc + r] = q;
-        }
-        int kt = 0;
-        double best = 0.0;
-        for (int j = 0; j < n; j++) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the other lane of the pair reads this lane's sequence below
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // the first index of the smallest |(D+ + D-) - (d - lambda)|: the sequential scan's rule (j == 0 || g < best), the
+        // second half scanned by the other lane from best = +inf and merged with the same strict comparison
+        const int half = n >> 1;
+        int kt = dir ? -1 : 0;
+        double best = dir ? __builtin_inf() : 0.0;
+        const int jb = dir ? half : 0, je = dir ? n : half;
+        for (int j = jb; j < je; j++) {
             const double g = fabs((Dp[(long)j * Rc + r] + Dm[(long)j * Rc + r]) - (Ld[j] - lam));
-            if (j == 0 || g < best) { best = g; kt = j; }
+            if ((!dir && j == 0) || g < best) { best = g; kt = j; }
+        }
+        {
+            const double ob = __shfl_xor(best, 1, 64);
+            const int ok = __shfl_xor(kt, 1, 64);
+            const double b0 = dir ? ob : best, b1 = dir ? best : ob; // (first half, second half)
+            const int k0 = dir ? ok : kt, k1 = dir ? kt : ok;
+            kt = (half > 0 && b1 < b0) ? k1 : k0;
         }
         double* x = Z + (long)r * n;
         double xv = 1.0;
-        x[kt] = 1.0;
-        for (int j = kt - 1; j >= 0; j--) {
-            double qq = Dp[(long)j * Rc + r];
+        if (dir == 0) x[kt] = 1.0;
+        const int cnt = dir ? n - 1 - kt : kt; // below the twist: j = kt - 1 .. 0 with D+; above: j = kt .. n - 2 with D-[j + 1]
+        for (int i = 0; i < cnt; i++) {
+            const int j = dir ? kt + i : kt - 1 - i;
+            double qq = Dsel[(long)(dir ? j + 1 : j) * Rc + r];
             if (fabs(qq) < pivmin) qq = -pivmin;
             xv = -(Le[j] / qq) * xv;
-            x[j] = xv;
-        }
-        xv = 1.0;
-        for (int j = kt; j < n - 1; j++) {
-            double qq = Dm[(long)(j + 1) * Rc + r];
-            if (fabs(qq) < pivmin) qq = -pivmin;
-            xv = -(Le[j] / qq) * xv;
-            x[j + 1] = xv;
+            x[dir ? j + 1 : j] = xv;
         }
     }
     __syncthreads();
+    EIG_STAMP();
     if (stop_after == 3) return;
     if (stop_after >= 1300 && stop_after < 1400) { // developer aid: vectors r0.. of Z as raw doubles in the E1 output
         double* dbg = reinterpret_cast<double*>(E1 + (long)blockIdx.x * n * R);
@@ -2163,23 +2215,29 @@ __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, 
         }
         return;
     }
+    EIG_STAMP();
     if (stop_after == 4) return;
-    // ---- back-transformation x <- H_0 H_1 ... H_{n-3} x, CW vectors per wave at a time, lane owns i = lane + 64 e
+    // ---- back-transformation x <- H_0 H_1 ... H_{n-3} x, up to CW vectors per wave at a time, lane owns i = lane + 64 e.  The
+    // vectors are dealt out over the four waves (slot w of wave g: vector base + g + 4 w): with consecutive vectors per wave
+    // a call of rank <= CW ran on one wave (svd_encode, R = 5: 173 us of the kernel's 370)
     constexpr int NE = 4 * NCT, CW = 32 / NE;
     float* E1b = E1 + (long)blockIdx.x * n * R;
     float* E2b = E2 + (long)blockIdx.x * n * R;
-    for (int g0 = wave * CW; g0 < Rc; g0 += 4 * CW) {
+    for (int g0 = wave; g0 < Rc; g0 += 4 * CW) { // vector of slot w: g0 + 4 w
         double x[CW][NE];
 #pragma unroll
         for (int w = 0; w < CW; w++)
 #pragma unroll
             for (int e = 0; e < NE; e++) {
                 const int i = lane + 64 * e;
-                x[w][e] = (g0 + w < Rc && i < n) ? Z[(long)(g0 + w) * n + i] : 0.0;
+                x[w][e] = (g0 + 4 * w < Rc && i < n) ? Z[(long)(g0 + 4 * w) * n + i] : 0.0;
             }
-        // the reflector of step k - 1 is requested (global memory, L2) before step k is computed; the dot products reduce
-        // through the DPP / permlane tree of k_init (wave_tree64), not the LDS crossbar
-        double vn[NE];
+        // the reflectors of the next PF steps are in flight (global memory) while step k is computed; the dot products reduce
+        // through the DPP / permlane tree of k_init (wave_tree64), not the LDS crossbar.  What a step costs is that tree: ~50
+        // dependent instructions per vector and step, ~1000 cycles (ablations, 256 matrices of 192 x 192: synthetic reflectors
+        // instead of the loads change nothing, a plain sum instead of the tree takes a third off)
+        constexpr int PF = 4;
+        double vq[PF][NE];
         auto load_v = [&](int k, double (&v)[NE]) __attribute__((always_inline)) {
             const double* Ak = A + (long)(k > 0 ? k : 0) * n;
 #pragma unroll
@@ -2188,28 +2246,37 @@ __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, 
                 v[e] = (k >= 0 && i < n && i > k) ? Ak[i] : 0.0;
             }
         };
-        load_v(n - 3, vn);
-        for (int k = n - 3; k >= 0; k--) {
-            double v[NE];
 #pragma unroll
-            for (int e = 0; e < NE; e++) v[e] = vn[e];
-            load_v(k - 1, vn);
-            const double tk = Ltau[k];
-            if (tk == 0.0) continue;
+        for (int pf = 0; pf < PF; pf++) load_v(n - 3 - pf, vq[pf]);
+        for (int k0 = n - 3; k0 >= 0; k0 -= PF) {
 #pragma unroll
-            for (int w = 0; w < CW; w++) {
-                if (g0 + w >= Rc) continue; // wave-uniform
-                double dsum = 0.0;
+            for (int pf = 0; pf < PF; pf++) {
+                const int k = k0 - pf;
+                double v[NE];
 #pragma unroll
-                for (int e = 0; e < NE; e++) dsum = fma(v[e], x[w][e], dsum);
-                const double sc = tk * wave_tree64(dsum);
+                for (int e = 0; e < NE; e++) v[e] = vq[pf][e];
+                load_v(k - PF, vq[pf]);
+                const double tk = k >= 0 ? Ltau[k] : 0.0;
+                if (tk != 0.0) {
 #pragma unroll
-                for (int e = 0; e < NE; e++) x[w][e] = fma(-sc, v[e], x[w][e]);
+                    for (int w = 0; w < CW; w++) {
+                        if (g0 + 4 * w >= Rc) continue; // wave-uniform
+                        double dsum = 0.0;
+#pragma unroll
+                        for (int e = 0; e < NE; e++) dsum = fma(v[e], x[w][e], dsum);
+                        const double sc = tk * wave_tree64(dsum);
+#pragma unroll
+                        for (int e = 0; e < NE; e++) x[w][e] = fma(-sc, v[e], x[w][e]);
+                    }
+                }
             }
         }
+#ifdef LRF_REG_STAMPS
+        if (esi == 5) EIG_STAMP();
+#endif
 #pragma unroll
         for (int w = 0; w < CW; w++) {
-            const int r = g0 + w;
+            const int r = g0 + 4 * w;
             if (r >= Rc) continue;
             double dsum = 0.0;
 #pragma unroll
@@ -2231,6 +2298,10 @@ __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, 
             }
         }
     }
+#ifdef LRF_REG_STAMPS
+    while (esi < 7) EIG_STAMP();
+    EIG_STAMPS_OUT();
+#endif
     // columns r >= min(M, N): zero (qmf.py:50-52)
     for (long e = tid; e < (long)n * (R - Rc); e += 256) {
         const long i = e / (R - Rc), r = Rc + (e - i * (R - Rc));
