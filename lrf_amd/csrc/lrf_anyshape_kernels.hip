@@ -710,8 +710,8 @@ __global__ __launch_bounds__(256) void k_any_gram_mfma(const float* __restrict__
 // Householder tridiagonalisation of a symmetric n x n matrix, 64 < n <= 64 NC (NC = 2, 3), with the matrix in REGISTERS: the
 // [M,192] Gram matrices of svd_encode and of the RGB colour-space branch, 16 x 8 / 8 x 16 patches.  k_any_eig<1> walks its
 // matrix in global memory three times per step (8.3 ms per 256 matrices of 192 x 192, ~95 % of svd_encode's initialisation);
-// here 256 NC threads hold it the way k_init does for n = 64 — thread (lane i, column chunk cc, row group rg) keeps
-// A[16 (rg + 4 s) + j][64 cc + i], s < NC, j < 16, as NC 16-double vectors, so row k is read with a register index.  Arithmetic: k_init's step (one reduction for sigma, t = 1 / (sigma + |x0| nrm),
+// here 256 NC threads hold it in registers — thread (lane i, wave b) keeps A[16 b + j][64 c + i], c < NC, j < 16, as NC
+// 16-double vectors, so row k is read with a register index.  Arithmetic: k_init's step (one reduction for sigma, t = 1 / (sigma + |x0| nrm),
 // p = t A v from chains over the row groups, commutative rank-2 update).  Output: row k of A keeps the reflector v_k (i > k),
 // td = d[n], e[n], tau[n] for k_any_eig<1>, which then starts at its eigenvalue stage.
 // lane `src_lane` of a double register, as a wave-uniform value (two v_readlane_b32: the result lives in SGPRs)
@@ -738,41 +738,41 @@ __global__ __launch_bounds__(256 * NC) void k_any_tridiag_reg(double* __restrict
     double* A = G + (long)blockIdx.x * n * n;
     double* td = TD + (long)blockIdx.x * 3 * n;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // Column chunk cc, row group rg (wave-uniform).  The thread's NC 16-row vectors are the sub-blocks rg, rg + 4, rg + 8 of
-    // its column (rows 16 (rg + 4 s) ..): dealt out cyclically, because the trailing matrix shrinks from the top — with
-    // consecutive sub-blocks per group the last group worked on 48 rows in every step while the first idled after step 47
-    // (stamps: its waves spent 4.4 k of 11.3 k cycles per step in the first barrier); now every group holds ceil(active / 4)
-    // sub-blocks, two thirds of the critical wave's products.  Which thread forms a sub-block's chain does not change a bit:
-    // the chains (sixteen consecutive rows from zero) and the order their sums are added in are the oracle's.
-    const int cc = wave % NC, rg = wave / NC;
-    const int col = 64 * cc + lane;
-    // the waves of a SIMD get different priorities (by row group): their scalar chains then run one after the other, each
-    // under the products of the others, instead of all three crawling together (9.8 k cycles per step against 10.2 k)
+    // Wave b holds the 16-row sub-block b (rows 16 b .. 16 b + 15) on ALL columns: a thread keeps NC 16-double vectors, one per
+    // column chunk (columns lane, 64 + lane, ...).  Round 3's layout gave a wave one column chunk and 16 NC consecutive rows:
+    // every wave-uniform operand (v and w at a ROW: two v_readlane_b32 per double) then served one product, and the
+    // instruction count per element was 3 in the product A v and 6 in the update; with all chunks in one thread it serves NC
+    // of them: (2 + NC) / NC and (4 + 2 NC) / NC.  The trailing matrix shrinks from the top, so the last wave is the
+    // critical one: 16 rows x the live chunks (240 / 176 / 112 instructions per step as the chunks finish, against 432 in
+    // every step for round 3's last row group).  Which thread forms a sub-block's chain does not change a bit: the chains
+    // (sixteen consecutive rows from zero) and the order their sums are added in are the oracle's.
+    const int b = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // the waves of a SIMD get different priorities, the later sub-blocks first: their scalar chains then run one after the
+    // other, each under the products of the others, instead of all three crawling together
 #ifndef LRF_REG_NO_PRIO
-    if (rg == 3) __builtin_amdgcn_s_setprio(3);
-    else if (rg == 2) __builtin_amdgcn_s_setprio(2);
-    else if (rg == 1) __builtin_amdgcn_s_setprio(1);
+    if (b >= 3 * NC) __builtin_amdgcn_s_setprio(3);
+    else if (b >= 2 * NC) __builtin_amdgcn_s_setprio(2);
+    else if (b >= NC) __builtin_amdgcn_s_setprio(1);
 #endif
     d16 Ar[NC];
 #pragma unroll
-    for (int s = 0; s < NC; s++)
+    for (int c = 0; c < NC; c++)
 #pragma unroll
         for (int jj = 0; jj < 16; jj++) {
-            const int r = 16 * (rg + 4 * s) + jj;
-            Ar[s][jj] = (r < n && col < n) ? A[(long)r * n + col] : 0.0;
+            const int r = 16 * b + jj, col = 64 * c + lane;
+            Ar[c][jj] = (r < n && col < n) ? A[(long)r * n + col] : 0.0;
         }
     // Every wave holds v and w on ALL columns (NC values per lane: the scalars of a step are computed redundantly, same bits),
     // so the values a thread needs at its ROWS come out of the wave's own registers by v_readlane (wave-uniform, in SGPRs)
     // instead of broadcast LDS reads — twelve waves reading 144 doubles each per step had made the LDS the bottleneck
-    // (1.26 -> 0.5 ms per 256 matrices of 192 x 192).
-    // Sub-block s of this wave's rows lies in column chunk s of v / w, lanes 16 rg .. 16 rg + 15.
+    // (1.26 -> 0.5 ms per 256 matrices of 192 x 192).  The rows of sub-block b are the lanes 16 (b & 3) .. + 15 of chunk b >> 2.
     auto pick = [&](const double (&q)[NC], int chunk) __attribute__((always_inline)) {
         double r = q[0];
         if (NC > 1 && chunk == 1) r = q[1];
         if (NC > 2 && chunk == 2) r = q[NC - 1];
         return r;
     };
+    const int rl0 = 16 * (b & 3), rch = b >> 2; // first lane and chunk of this wave's rows in v / w
 #ifdef LRF_REG_STAMPS
     unsigned long long st[7] = {0, 0, 0, 0, 0, 0, 0}, tq = __builtin_amdgcn_s_memtime(), tq0 = tq;
 #define REG_STAMP(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); st[i] += tn_ - tq; tq = tn_; __builtin_amdgcn_sched_barrier(0); }
@@ -781,13 +781,11 @@ __global__ __launch_bounds__(256 * NC) void k_any_tridiag_reg(double* __restrict
 #endif
     for (int k = 0; k < n - 2; k++) {
         double* xrow = xrow2 + NP * (k & 1); // double-buffered: a slower wave may still be reading the other one
-        const bool holds_k = rg == ((k >> 4) & 3); // the row group that holds row k (sub-block k / 16 = rg + 4 s)
-        if (holds_k) { // publishes it (entries up to column k as zeros)
-            const int sk = k >> 6, jj = k & 15;
-            double xk = Ar[0][jj];
-            if (NC > 1 && sk == 1) xk = Ar[1][jj];
-            if (NC > 2 && sk == 2) xk = Ar[NC - 1][jj];
-            xrow[col] = (col > k) ? xk : 0.0;
+        const bool holds_k = b == (k >> 4); // the wave that holds row k publishes it (entries up to column k as zeros)
+        if (holds_k) {
+            const int jj = k & 15;
+#pragma unroll
+            for (int c = 0; c < NC; c++) xrow[64 * c + lane] = (64 * c + lane > k) ? Ar[c][jj] : 0.0;
         }
         __syncthreads();
         REG_STAMP(1);
@@ -811,34 +809,42 @@ __global__ __launch_bounds__(256 * NC) void k_any_tridiag_reg(double* __restrict
         double vk[NC]; // v on the columns lane, 64 + lane, ...
 #pragma unroll
         for (int c2 = 0; c2 < NC; c2++) vk[c2] = (64 * c2 + lane == k + 1) ? vfix : xs[c2];
-        const double vc = pick(vk, cc);
         REG_STAMP(2);
-        if (holds_k && col > k && col < n) A[(long)k * n + col] = vc; // v_k for the back-transformation
-        const bool cols_live = 64 * cc + 63 > k; // wave-uniform: some column of this wave is still in the trailing matrix
-        { // matvec partials over this thread's rows: one chain per 16-row sub-block; finished sub-blocks (v = 0 there) are skipped
+        if (holds_k) { // v_k for the back-transformation
 #pragma unroll
-            for (int s = 0; s < NC; s++) {
-                const int r0 = 16 * (rg + 4 * s);
-                double c = 0.0;
-                if (cols_live && r0 + 15 > k) { // wave-uniform
-                    const double src = vk[s];
-#pragma unroll
-                    for (int jj = 0; jj < 16; jj++) c = fma(Ar[s][jj], readlane_f64(src, 16 * rg + jj), c);
-                }
-                cpart[(rg + 4 * s) * CP + col] = (col > k) ? c : 0.0;
+            for (int c = 0; c < NC; c++) {
+                const int col = 64 * c + lane;
+                if (col > k && col < n) A[(long)k * n + col] = vk[c];
             }
+        }
+        const bool rows_live = 16 * b + 15 > k; // wave-uniform: some row of this wave is still in the trailing matrix
+        { // matvec partials of this thread's sub-block: one chain per column; finished rows (v = 0 there) and chunks are skipped
+            double cs[NC];
+#pragma unroll
+            for (int c = 0; c < NC; c++) cs[c] = 0.0;
+            if (rows_live) {
+                const double src = pick(vk, rch);
+#pragma unroll
+                for (int jj = 0; jj < 16; jj++) { // (finished chunks are not skipped: v = 0 there, and their sums are masked below)
+                    const double vj = readlane_f64(src, rl0 + jj);
+#pragma unroll
+                    for (int c = 0; c < NC; c++) cs[c] = fma(Ar[c][jj], vj, cs[c]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NC; c++) cpart[b * CP + 64 * c + lane] = (64 * c + lane > k) ? cs[c] : 0.0;
         }
         REG_STAMP(3);
         __syncthreads();
         // p = t A v, ONCE per column: wave w combines the sub-block sums of the columns 16 w .. 16 w + 15 — lane (column
         // 16 w + (lane >> 2), row group g = lane & 3) adds its group's NC sums in order, the four groups meet inside the quad
         // (DPP), in the oracle's order ((g0 + g1) + g2) + g3 — and publishes them; a third barrier.  (With every wave reading
-        // all 4 NC sums of all its columns, as round 3's kernel did with four sums per column, the LDS sets the pace of the
-        // step: 221 KB per step at n = 192, 9.8 k cycles per step against 8.9 k.  One wave doing all scalar work of a step —
-        // the reflector, then p, K, w — with v and w handed out through LDS was measured too: four barriers, 9.2 k: the
-        // redundant form lets the waves of a SIMD drift apart, so that one's scalar chain runs under another's products.)
+        // all 4 NC sums of all its columns the LDS sets the pace of the step: 221 KB per step at n = 192.  One wave doing all
+        // scalar work of a step — the reflector, then p, K, w — with v and w handed out through LDS was measured too: four
+        // barriers, slower: the redundant form lets the waves of a SIMD drift apart, so that one's scalar chain runs under
+        // another's products.)
         {
-            const int g = lane & 3, ci = 16 * wave + (lane >> 2);
+            const int g = lane & 3, ci = 16 * b + (lane >> 2);
             double cgv = cpart[(NC * g) * CP + ci];
 #pragma unroll
             for (int s2i = 1; s2i < NC; s2i++) cgv = cgv + cpart[(NC * g + s2i) * CP + ci];
@@ -862,19 +868,17 @@ __global__ __launch_bounds__(256 * NC) void k_any_tridiag_reg(double* __restrict
             for (int c2 = 0; c2 < NC; c2++) wk[c2] = fma(-K, vk[c2], pk[c2]);
             if (tid == 0) { td[n + k] = alpha; td[2 * n + k] = t; }
         }
-        const double wc = pick(wk, cc);
         REG_STAMP(5);
         // rank-2 update as two fmas per element (the four-instruction commutative form of k_init doubled the kernel's dominant
-        // term).  Element (r, c) and its mirror image may differ in the last bit; the full matrix is carried.  v, w are zero up to k.
+        // term).  Element (r, c) and its mirror image may differ in the last bit: the FULL matrix is carried.  v, w are zero up
+        // to k: finished rows and chunks are skipped.
+        if (rows_live) {
+            const double sv = pick(vk, rch), sw = pick(wk, rch);
 #pragma unroll
-        for (int s = 0; s < NC; s++) {
-            const int r0 = 16 * (rg + 4 * s);
-            if (!(cols_live && r0 + 15 > k)) continue; // wave-uniform: rows and columns up to k are finished
-            const double sv = vk[s], sw = wk[s];
+            for (int jj = 0; jj < 16; jj++) { // (finished chunks are not skipped: v = w = 0 there leaves the element as it is)
+                const double vj = readlane_f64(sv, rl0 + jj), wj = readlane_f64(sw, rl0 + jj);
 #pragma unroll
-            for (int jj = 0; jj < 16; jj++) {
-                const double vj = readlane_f64(sv, 16 * rg + jj), wj = readlane_f64(sw, 16 * rg + jj);
-                Ar[s][jj] = fma(-vj, wc, fma(-wj, vc, Ar[s][jj]));
+                for (int c = 0; c < NC; c++) Ar[c][jj] = fma(-vj, wk[c], fma(-wj, vk[c], Ar[c][jj]));
             }
         }
 #ifdef LRF_REG_STAMPS
@@ -884,19 +888,19 @@ __global__ __launch_bounds__(256 * NC) void k_any_tridiag_reg(double* __restrict
     }
 #ifdef LRF_REG_STAMPS
     if (lane == 0 && blockIdx.x < 1024) { // every wave's lane 0: [matrix][wave][8]
-        unsigned long long* o = g_stamps + 8 * (16 * blockIdx.x + wave);
+        unsigned long long* o = g_stamps + 8 * (16 * blockIdx.x + b);
         o[0] = __builtin_amdgcn_s_memtime() - tq0;
         for (int q = 1; q < 7; q++) o[q] = st[q];
     }
 #endif
     // d = diagonal, e[n-2] = A[n-1][n-2]
 #pragma unroll
-    for (int s = 0; s < NC; s++)
+    for (int c = 0; c < NC; c++)
 #pragma unroll
         for (int jj = 0; jj < 16; jj++) {
-            const int r = 16 * (rg + 4 * s) + jj;
-            if (r == col && r < n) td[r] = Ar[s][jj];
-            if (r == n - 1 && col == n - 2) td[n + n - 2] = Ar[s][jj];
+            const int r = 16 * b + jj, col = 64 * c + lane;
+            if (r == col && r < n) td[r] = Ar[c][jj];
+            if (r == n - 1 && col == n - 2) td[n + n - 2] = Ar[c][jj];
         }
     if (tid == 0) { td[n + n - 1] = 0.0; td[2 * n + n - 2] = 0.0; td[2 * n + n - 1] = 0.0; }
 }
@@ -1522,11 +1526,11 @@ __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, 
                                                  const double* __restrict__ td_in /* d, e, tau of k_any_tridiag_reg, or NULL */)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-#ifdef LRF_REG_STAMPS // (tools/dev_stamps_eig.py: stage boundaries of every wave's lane 0, [matrix][wave][8])
+#ifdef LRF_REG_STAMPS // (tools/dev_stamps_eig.py: stage boundaries of every wave's lane 0, [matrix][12 + wave][8]: k_any_tridiag_reg has 0..11)
     unsigned long long est[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int esi = 0;
 #define EIG_STAMP() { __builtin_amdgcn_sched_barrier(0); est[esi++] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
-#define EIG_STAMPS_OUT() { if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) { unsigned long long* o_ = g_stamps + 8 * (16 * blockIdx.x + (threadIdx.x >> 6)); for (int q_ = 0; q_ < 8; q_++) o_[q_] = est[q_]; } }
+#define EIG_STAMPS_OUT() { if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) { unsigned long long* o_ = g_stamps + 8 * (16 * blockIdx.x + 12 + (threadIdx.x >> 6)); for (int q_ = 0; q_ < 8; q_++) o_[q_] = est[q_]; } }
     EIG_STAMP();
 #else
 #define EIG_STAMP()
