@@ -1948,11 +1948,14 @@ int lrf_svd_encode_rgb_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_t H, 
         LAUNCH_CHECK();
         if ((rc = gram192_u8(c, (const uint8_t*)X8, xs, (int)B, M, G))) return rc;
         if ((rc = any_eig_from_gram(c, G, (int)B, M, N, R, sign, Vn, Wn))) return rc;
-        const dim3 pg((unsigned)((M + 255) / 256), (unsigned)B);
-        if (R <= 4)
-            hipLaunchKernelGGL((k_prod192_u8<4>), pg, dim3(256), 0, c->stream, (const uint8_t*)X8, xs, M, (const float*)Wn, R, Uf);
-        else
-            hipLaunchKernelGGL((k_prod192_u8<8>), pg, dim3(256), 0, c->stream, (const uint8_t*)X8, xs, M, (const float*)Wn, R, Uf);
+        const dim3 pg((unsigned)((M + 256 * LRF_PROD192_GROUPS - 1) / (256 * LRF_PROD192_GROUPS)), (unsigned)B);
+#define LRF_LAUNCH_P192(RR) \
+    case RR: hipLaunchKernelGGL((k_prod192_u8<RR>), pg, dim3(256), 0, c->stream, (const uint8_t*)X8, xs, M, (const float*)Wn, Uf); break;
+        switch (R) {
+            LRF_LAUNCH_P192(1) LRF_LAUNCH_P192(2) LRF_LAUNCH_P192(3) LRF_LAUNCH_P192(4) LRF_LAUNCH_P192(5) LRF_LAUNCH_P192(6)
+            LRF_LAUNCH_P192(7) LRF_LAUNCH_P192(8)
+        }
+#undef LRF_LAUNCH_P192
         LAUNCH_CHECK();
     } else {
         hipLaunchKernelGGL((k_patchify_rgb<float>), dim3(hp / 8, (unsigned)B), dim3(256), 0, c->stream, rgb, (int)H, (int)W, top, left, nw, xs, X);

@@ -246,53 +246,58 @@ __global__ __launch_bounds__(256) void k_gram192_fold(const int* __restrict__ P,
     G[(long)blockIdx.y * 192 * 192 + e] = (double)(S + 128 * (si + sj) + 16384ll * M);
 }
 
-// ---- u = X w for the byte matrix [M,192] and R <= RP columns (svd_encode, round 3): U[m][r] = the k-ordered fp32 fma chain
-// over k = 0..191 of x[m][k] w[k][r] — one block of the reference's K-blocking, the chain k_any_prod's MFMA tiles compute —
-// with lane = row: a thread loads its row's 192 bytes (twelve 16-byte loads; the 64 rows of a wave are 12 KB contiguous) and
-// reads w[k][0..RP) from an LDS table by broadcast ds_read_b128s.  k_any_prod took 0.67 ms for 256 x [6144,192] x [192,5]
-// (a 32-wide rank tile with 5 columns in use, 1.2 GB of fp32 X at 1.8 TB/s).  grid (ceil(M/256), B)
-template <int RP>
-__global__ __launch_bounds__(256) void k_prod192_u8(const uint8_t* __restrict__ X, long x_stride, int M, const float* __restrict__ Wn, int R,
+// ---- u = X w for the byte matrix [M,192] and R <= 8 columns (svd_encode): U[m][r] = the k-ordered fp32 fma chain over
+// k = 0..191 of x[m][k] w[k][r] — one block of the reference's K-blocking, the chain k_any_prod's MFMA tiles compute — with
+// lane = row.  Round 4: the table w lives in VGPRs (register t of column r holds w[16 t + (lane & 15)][r], 12 R registers)
+// and reaches the VALU through the DPP row_newbcast operand of v_fmac_f32 (k_bcd_w's device): one instruction per product
+// and no LDS at all.  Round 3's form read w[k][0..RP) from an LDS table by broadcast ds_read_b128s, RP = 4 or 8: 384 KB of
+// LDS reads per 12 KB of rows and 8 products per k where 5 are wanted — 0.268 ms for 256 x [6144,192] x [192,5], five times
+// the bytes' time.  A wave walks LRF_PROD192_GROUPS groups of 64 rows (the table is loaded once per wave); a thread loads its
+// row's 192 bytes as twelve 16-byte loads, the next row group's first piece requested under the arithmetic.
+// grid (ceil(M / (256 LRF_PROD192_GROUPS)), B), 256 threads.
+#define LRF_PROD192_GROUPS 4
+template <int J, int R>
+__device__ __forceinline__ void prod192_step(float (&acc)[R], const float (&wt)[R], float x)
+{
+#pragma unroll
+    for (int r = 0; r < R; r++) fmac_bc16<J>(acc[r], wt[r], x);
+}
+template <int R>
+__global__ __launch_bounds__(256) void k_prod192_u8(const uint8_t* __restrict__ X, long x_stride, int M, const float* __restrict__ Wn,
                                                     float* __restrict__ Uf)
 {
-    __shared__ __attribute__((aligned(16))) float Ws[192 * RP];
+    const int lane = threadIdx.x & 63, li = lane & 15, wave = threadIdx.x >> 6;
     const float* Wb = Wn + (long)blockIdx.y * 192 * R;
-    for (int e = threadIdx.x; e < 192 * RP; e += 256) {
-        const int k = e / RP, r = e - k * RP;
-        Ws[e] = (r < R) ? Wb[k * R + r] : 0.f;
-    }
-    const int m = blockIdx.x * 256 + threadIdx.x;
-    const uint8_t* xr = X + (long)blockIdx.y * x_stride + (long)(m < M ? m : M - 1) * 192;
-    uint4 xn = *reinterpret_cast<const uint4*>(xr);
-    __syncthreads();
-    float acc[RP];
+    float wt[12][R];
 #pragma unroll
-    for (int r = 0; r < RP; r++) acc[r] = 0.f;
-    // sixteen columns per trip, the next sixteen bytes of the row requested before this trip's arithmetic; the loop is NOT
-    // unrolled: with all 192 steps in one block the compiler hoists the 384 table reads and spills 1600 registers
-#pragma unroll 1
-    for (int i = 0; i < 12; i++) {
-        const unsigned w4[4] = {xn.x, xn.y, xn.z, xn.w};
-        xn = *reinterpret_cast<const uint4*>(xr + 16 * (i < 11 ? i + 1 : 11));
-        const float* wi = &Ws[16 * i * RP];
+    for (int t = 0; t < 12; t++)
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const float x = (float)((w4[j >> 2] >> (8 * (j & 3))) & 255u);
+        for (int r = 0; r < R; r++) wt[t][r] = Wb[(16 * t + li) * R + r];
+    const uint8_t* Xb = X + (long)blockIdx.y * x_stride;
+    const int g0 = (blockIdx.x * 4 + wave) * LRF_PROD192_GROUPS; // first 64-row group of this wave
+    for (int g = 0; g < LRF_PROD192_GROUPS; g++) {
+        const int m = (g0 + g) * 64 + lane;
+        if ((g0 + g) * 64 >= M) break; // wave-uniform
+        const uint8_t* xr = Xb + (long)(m < M ? m : M - 1) * 192;
+        uint4 xq[12];
 #pragma unroll
-            for (int r = 0; r < RP; r += 4) {
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(wi + j * RP + r);
-                acc[r] = fmaf(x, wv[0], acc[r]);
-                acc[r + 1] = fmaf(x, wv[1], acc[r + 1]);
-                acc[r + 2] = fmaf(x, wv[2], acc[r + 2]);
-                acc[r + 3] = fmaf(x, wv[3], acc[r + 3]);
-            }
+        for (int t = 0; t < 12; t++) xq[t] = *reinterpret_cast<const uint4*>(xr + 16 * t);
+        float acc[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 12; t++) {
+            const unsigned w4[4] = {xq[t].x, xq[t].y, xq[t].z, xq[t].w};
+#define LRF_P192(J) prod192_step<J, R>(acc, wt[t], (float)((w4[(J) >> 2] >> (8 * ((J) & 3))) & 255u))
+            LRF_P192(0); LRF_P192(1); LRF_P192(2); LRF_P192(3); LRF_P192(4); LRF_P192(5); LRF_P192(6); LRF_P192(7);
+            LRF_P192(8); LRF_P192(9); LRF_P192(10); LRF_P192(11); LRF_P192(12); LRF_P192(13); LRF_P192(14); LRF_P192(15);
+#undef LRF_P192
         }
-    }
-    if (m < M) {
-        float* uo = Uf + ((long)blockIdx.y * M + m) * R;
+        if (m < M) {
+            float* uo = Uf + ((long)blockIdx.y * M + m) * R;
 #pragma unroll
-        for (int r = 0; r < RP; r++)
-            if (r < R) uo[r] = acc[r];
+            for (int r = 0; r < R; r++) uo[r] = acc[r];
+        }
     }
 }
 
