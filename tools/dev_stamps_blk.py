@@ -5,6 +5,8 @@ import ctypes, os, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
 import numpy as np, torch
+from lrf_amd import _lib as _l0
+if os.environ.get("LRF_LIB"): _l0.LIB_PATH = os.path.join(os.path.dirname(_l0.LIB_PATH), os.environ["LRF_LIB"])
 from lrf_amd import _lib
 B, M, N, R = (int(a) for a in sys.argv[1:5])
 X = torch.rand(B, M, N, device="cuda") * 255
