@@ -269,11 +269,14 @@ def test_hip_bcd_equals_oracle_on_any_shape(M, N, R, K, bounds, oracle):
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,N,R", [(384, 16, 5), (35, 256, 6), (100, 300, 40), (300, 100, 100), (64, 64, 3), (513, 300, 7),
                                   (20, 1024, 20), (700, 600, 30), (230, 500, 12), (256, 256, 9), (257, 400, 5), (600, 511, 11),
-                                  (1100, 1030, 6)])
+                                  (1100, 1030, 6), (150, 65, 4), (200, 128, 5), (400, 130, 9), (250, 191, 17), (300, 192, 8),
+                                  (192, 700, 13)])
 def test_hip_init_matches_oracle_init(M, N, R, oracle):
     """SVD initialisation on any shape: bit for bit the oracle's restatement (lrf_oracle_any.c: every tridiagonalisation
-    variant is in the list — sides 16 / 35 / 64 plain, 100 in registers, and the blocked one with panels of 16 (230, 256,
-    257, 300, 511), 8 (600) and 4 steps (1030)); against LAPACK (numpy) and the independent Jacobi solver
+    variant is in the list — sides 16 / 35 / 64 plain; in registers (round 4's layout: a wave per 16-row sub-block) 65, 100
+    and 128 with two column chunks, 130, 191 and 192 with three, ranks that give the eigen-solver one, two and three rounds
+    of paired searches and one to five vectors per wave in the back-transformation; and the blocked one with panels of 16
+    (230, 256, 257, 300, 511), 8 (600) and 4 steps (1030)); against LAPACK (numpy) and the independent Jacobi solver
     the rank-R product u0 v0^T agrees to fp32 accuracy, the column norms are the singular values, the default sign holds"""
     from lrf_amd import _lib
     rng = np.random.default_rng(M + N + R)
