@@ -2245,9 +2245,10 @@ __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, 
         auto load_v = [&](int k, double (&v)[NE]) __attribute__((always_inline)) {
             const double* Ak = A + (long)(k > 0 ? k : 0) * n;
 #pragma unroll
-            for (int e = 0; e < NE; e++) {
-                const int i = lane + 64 * e;
-                v[e] = (k >= 0 && i < n && i > k) ? Ak[i] : 0.0;
+            for (int e = 0; e < NE; e++) { // unconditional loads from clamped addresses, then a select: a load under a condition
+                const int i = lane + 64 * e; // becomes a branch around it, sixteen of them per step
+                const double a = Ak[i < n ? i : n - 1];
+                v[e] = (k >= 0 && i < n && i > k) ? a : 0.0;
             }
         };
 #pragma unroll
