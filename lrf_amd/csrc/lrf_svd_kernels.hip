@@ -237,8 +237,19 @@ __global__ __launch_bounds__(256) void k_gram192_fold(const int* __restrict__ P,
     if (e >= 192 * 192) return;
     const int i = e / 192, j = e - 192 * i;
     long long S = 0, si = 0, sj = 0;
-    for (int c = 0; c < nchunks; c++) {
-        const int* pc = Pp + (long)c * (192 * 192 + 192);
+    constexpr long PS = 192 * 192 + 192;
+    int c = 0;
+    for (; c + 4 <= nchunks; c += 4) { // (integer sums: any order) the loads of four chunks in flight
+        const int* pc = Pp + (long)c * PS;
+        const int a0 = pc[e], a1 = pc[PS + e], a2 = pc[2 * PS + e], a3 = pc[3 * PS + e];
+        const int b0 = pc[192 * 192 + i], b1 = pc[PS + 192 * 192 + i], b2 = pc[2 * PS + 192 * 192 + i], b3 = pc[3 * PS + 192 * 192 + i];
+        const int d0 = pc[192 * 192 + j], d1 = pc[PS + 192 * 192 + j], d2 = pc[2 * PS + 192 * 192 + j], d3 = pc[3 * PS + 192 * 192 + j];
+        S += ((long long)a0 + a1) + ((long long)a2 + a3);
+        si += ((long long)b0 + b1) + ((long long)b2 + b3);
+        sj += ((long long)d0 + d1) + ((long long)d2 + d3);
+    }
+    for (; c < nchunks; c++) {
+        const int* pc = Pp + (long)c * PS;
         S += pc[e];
         si += pc[192 * 192 + i];
         sj += pc[192 * 192 + j];
@@ -325,7 +336,28 @@ __global__ __launch_bounds__(256) void k_minmax(const float* __restrict__ T, lon
     __shared__ float smin[4], smax[4];
     const float* t = T + (long)blockIdx.x * stride;
     float mn = 3.4e38f, mx = -3.4e38f;
-    for (long i = threadIdx.x; i < n; i += 256) {
+    // (min / max do not depend on the order.)  16-byte loads, four of them in flight per thread, where the tensor allows: one
+    // workgroup walking 30720 floats with a 4-byte load per trip took 50 us of svd_encode's step (a chain of memory round trips)
+    long i0 = 0;
+    if (((reinterpret_cast<uintptr_t>(t) & 15) == 0)) {
+        const float4* t4 = reinterpret_cast<const float4*>(t);
+        const long n4 = n >> 2;
+        long q = threadIdx.x;
+        for (; q + 768 < n4; q += 1024) {
+            const float4 a = t4[q], b = t4[q + 256], c = t4[q + 512], d = t4[q + 768];
+            mn = fminf(fminf(fminf(mn, fminf(a.x, a.y)), fminf(fminf(a.z, a.w), fminf(b.x, b.y))), fminf(fminf(b.z, b.w), fminf(fminf(c.x, c.y), fminf(c.z, c.w))));
+            mn = fminf(mn, fminf(fminf(d.x, d.y), fminf(d.z, d.w)));
+            mx = fmaxf(fmaxf(fmaxf(mx, fmaxf(a.x, a.y)), fmaxf(fmaxf(a.z, a.w), fmaxf(b.x, b.y))), fmaxf(fmaxf(b.z, b.w), fmaxf(fmaxf(c.x, c.y), fmaxf(c.z, c.w))));
+            mx = fmaxf(mx, fmaxf(fmaxf(d.x, d.y), fmaxf(d.z, d.w)));
+        }
+        for (; q < n4; q += 256) {
+            const float4 a = t4[q];
+            mn = fminf(mn, fminf(fminf(a.x, a.y), fminf(a.z, a.w)));
+            mx = fmaxf(mx, fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)));
+        }
+        i0 = n4 << 2;
+    }
+    for (long i = i0 + threadIdx.x; i < n; i += 256) {
         float v = t[i];
         mn = fminf(mn, v);
         mx = fmaxf(mx, v);
