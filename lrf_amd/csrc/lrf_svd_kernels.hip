@@ -21,25 +21,43 @@ __global__ __launch_bounds__(256) void k_patchify_rgb(const uint8_t* __restrict_
     const int hh = blockIdx.x;
     const uint8_t* img = rgb + (long)blockIdx.y * 3 * H * W;
     T* Xp = X + (long)blockIdx.y * img_floats + (long)hh * nw * 192;
-    for (int it = threadIdx.x; it < nw * 48; it += 256) {
-        const int ww = it / 48, rem = it - ww * 48;
-        const int c = rem >> 4, a = (rem >> 1) & 7, b4 = (rem & 1) * 4;
-        const int y = reflect_idx(hh * 8 + a - top, H);
-        f32x4 out;
-        const int x0 = ww * 8 + b4 - left;
-        const uint8_t* rowp = img + (long)c * H * W + (long)y * W;
-        uint32_t w4;
-        if (x0 >= 0 && x0 + 3 < W) { // no reflection inside these four pixels: one (unaligned) word instead of four byte loads
-            typedef uint32_t __attribute__((aligned(1))) u32u;
-            w4 = *reinterpret_cast<const u32u*>(rowp + x0);
-        } else {
-            w4 = 0;
+    if constexpr (sizeof(T) == 1) {
+        // bytes: an item is one 8-pixel patch row (ww, c, a) — one 8-byte load, one 8-byte store, the 24 items of a patch
+        // 192 contiguous bytes of X (four pixels per item: 0.165 ms per 256 images, 3.7 TB/s)
+        for (int it = threadIdx.x; it < nw * 24; it += 256) {
+            const int ww = it / 24, rem = it - ww * 24;
+            const int c = rem >> 3, a = rem & 7;
+            const int y = reflect_idx(hh * 8 + a - top, H);
+            const int x0 = ww * 8 - left;
+            const uint8_t* rowp = img + (long)c * H * W + (long)y * W;
+            uint64_t w8;
+            if (x0 >= 0 && x0 + 7 < W) { // no reflection inside these eight pixels: one (unaligned) 8-byte word
+                typedef uint64_t __attribute__((aligned(1))) u64u;
+                w8 = *reinterpret_cast<const u64u*>(rowp + x0);
+            } else {
+                w8 = 0;
 #pragma unroll
-            for (int i = 0; i < 4; i++) w4 |= (uint32_t)rowp[reflect_idx(x0 + i, W)] << (8 * i);
+                for (int i = 0; i < 8; i++) w8 |= (uint64_t)rowp[reflect_idx(x0 + i, W)] << (8 * i);
+            }
+            *reinterpret_cast<uint64_t*>(Xp + ww * 192 + c * 64 + a * 8) = w8;
         }
-        if constexpr (sizeof(T) == 1) {
-            *reinterpret_cast<uint32_t*>(Xp + ww * 192 + c * 64 + a * 8 + b4) = w4;
-        } else {
+    } else {
+        for (int it = threadIdx.x; it < nw * 48; it += 256) {
+            const int ww = it / 48, rem = it - ww * 48;
+            const int c = rem >> 4, a = (rem >> 1) & 7, b4 = (rem & 1) * 4;
+            const int y = reflect_idx(hh * 8 + a - top, H);
+            f32x4 out;
+            const int x0 = ww * 8 + b4 - left;
+            const uint8_t* rowp = img + (long)c * H * W + (long)y * W;
+            uint32_t w4;
+            if (x0 >= 0 && x0 + 3 < W) { // no reflection inside these four pixels: one (unaligned) word instead of four byte loads
+                typedef uint32_t __attribute__((aligned(1))) u32u;
+                w4 = *reinterpret_cast<const u32u*>(rowp + x0);
+            } else {
+                w4 = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) w4 |= (uint32_t)rowp[reflect_idx(x0 + i, W)] << (8 * i);
+            }
 #pragma unroll
             for (int i = 0; i < 4; i++) out[i] = (float)((w4 >> (8 * i)) & 255u);
             *reinterpret_cast<f32x4*>(Xp + ww * 192 + c * 64 + a * 8 + b4) = out;
