@@ -734,7 +734,8 @@ __global__ __launch_bounds__(256 * NC) void k_any_tridiag_reg(double* __restrict
 {
     constexpr int NP = 64 * NC; // padded side
     constexpr int CP = NP + 2; // pitch of cpart: the four lanes of a quad read four sub-block rows of one column (distinct banks)
-    __shared__ __attribute__((aligned(16))) double xrow2[2 * NP], cpart[4 * NC * CP], pbuf[NP]; // cpart: one chain sum per 16-row sub-block and column
+    __shared__ __attribute__((aligned(16))) double xrow2[2 * NP], cpart[4 * NC * CP], pbuf[NP], vbuf[NP], tbuf[2]; // cpart: one chain sum per 16-row sub-block and column
+    __shared__ int sflag[2];
     double* A = G + (long)blockIdx.x * n * n;
     double* td = TD + (long)blockIdx.x * 3 * n;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -789,26 +790,50 @@ __global__ __launch_bounds__(256 * NC) void k_any_tridiag_reg(double* __restrict
         }
         __syncthreads();
         REG_STAMP(1);
-        // every wave: the reflector's scalars (same bits in all of them)
-        double xs[NC], sq = 0.0;
+        // The reflector's scalars: ONE wave per SIMD computes them (the last four waves: same bits in all of them), the others
+        // wait and take v from LDS.  With every wave computing them the three waves of a SIMD issue the same ~150 dependent
+        // fp64 instructions one after the other, and a step is bound by what a SIMD issues (stamps: ~4.2 k cycles per step,
+        // a third of them these chains).
+        double vk[NC], t = 0.0, alpha = 0.0; // v on the columns lane, 64 + lane, ...
+        bool live_step;
+        if (b >= 4 * NC - 4) {
+            double xs[NC], sq = 0.0;
 #pragma unroll
-        for (int c2 = 0; c2 < NC; c2++) {
-            xs[c2] = xrow[64 * c2 + lane];
-            sq = fma(xs[c2], xs[c2], sq);
+            for (int c2 = 0; c2 < NC; c2++) {
+                xs[c2] = xrow[64 * c2 + lane];
+                sq = fma(xs[c2], xs[c2], sq);
+            }
+            const double sigma = wave_tree64(sq); // DPP / permlane tree of k_init (lrf_kernels.hip): no LDS crossbar
+            live_step = sigma > LRF_SIGMA_TINY;
+            if (live_step) {
+                const double x0 = readlane_f64(pick(xs, (k + 1) >> 6), (k + 1) & 63);
+                const double nrm = sqrt(sigma);
+                alpha = (x0 >= 0.0) ? -nrm : nrm;
+                const double vfix = x0 - alpha;
+                t = 1.0 / fma(fabs(x0), nrm, sigma);
+#pragma unroll
+                for (int c2 = 0; c2 < NC; c2++) vk[c2] = (64 * c2 + lane == k + 1) ? vfix : xs[c2];
+            } else {
+#pragma unroll
+                for (int c2 = 0; c2 < NC; c2++) vk[c2] = 0.0;
+            }
+            if (b == 4 * NC - 1) {
+#pragma unroll
+                for (int c2 = 0; c2 < NC; c2++) vbuf[64 * c2 + lane] = vk[c2];
+                if (lane == 0) { sflag[0] = live_step ? 1 : 0; tbuf[0] = t; }
+            }
         }
-        const double sigma = wave_tree64(sq); // DPP / permlane tree of k_init (lrf_kernels.hip): no LDS crossbar
-        if (!(sigma > LRF_SIGMA_TINY)) { // wave-uniform, the same in every wave
+        __syncthreads();
+        if (b < 4 * NC - 4) {
+            live_step = sflag[0] != 0;
+            t = tbuf[0];
+#pragma unroll
+            for (int c2 = 0; c2 < NC; c2++) vk[c2] = vbuf[64 * c2 + lane];
+        }
+        if (!live_step) { // wave-uniform, the same in every wave
             if (tid == 0) { td[n + k] = 0.0; td[2 * n + k] = 0.0; }
             continue; // the next step writes the other buffer, and its barrier orders the step after
         }
-        const double x0 = readlane_f64(pick(xs, (k + 1) >> 6), (k + 1) & 63);
-        const double nrm = sqrt(sigma);
-        const double alpha = (x0 >= 0.0) ? -nrm : nrm;
-        const double vfix = x0 - alpha;
-        const double t = 1.0 / fma(fabs(x0), nrm, sigma);
-        double vk[NC]; // v on the columns lane, 64 + lane, ...
-#pragma unroll
-        for (int c2 = 0; c2 < NC; c2++) vk[c2] = (64 * c2 + lane == k + 1) ? vfix : xs[c2];
         REG_STAMP(2);
         if (holds_k) { // v_k for the back-transformation
 #pragma unroll
@@ -866,7 +891,7 @@ __global__ __launch_bounds__(256 * NC) void k_any_tridiag_reg(double* __restrict
             const double K = (0.5 * t) * wave_tree64(s2);
 #pragma unroll
             for (int c2 = 0; c2 < NC; c2++) wk[c2] = fma(-K, vk[c2], pk[c2]);
-            if (tid == 0) { td[n + k] = alpha; td[2 * n + k] = t; }
+            if (tid == 256 * NC - 1) { td[n + k] = alpha; td[2 * n + k] = t; } // (a thread of the last wave: it has alpha)
         }
         REG_STAMP(5);
         // rank-2 update as two fmas per element (the four-instruction commutative form of k_init doubled the kernel's dominant
