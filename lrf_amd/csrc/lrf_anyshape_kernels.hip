@@ -2000,7 +2000,8 @@ __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, 
                 double x[2], p[2] = {1.0, 1.0}, pp[2] = {0.0, 0.0};
                 unsigned sg[2] = {0u, 0u};
                 int cnt[2] = {0, 0};
-                bool zero[2] = {false, false};
+                double zm[2] = {1.0, 1.0}; // the smallest |minor| of the pass: a zero is looked for once, at its end (one v_min_f64 per
+                                           // step instead of a compare, a select and an OR)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; s2++) {
                     const double h = (b[s2] - a[s2]) / 65.0;
@@ -2014,7 +2015,7 @@ __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, 
 #pragma unroll
                         for (int s2 = 0; s2 < 2; s2++) {
                             const double pn = fma(q.x - x[s2], p[s2], -(q.y * pp[s2]));
-                            zero[s2] |= (pn == 0.0);
+                            zm[s2] = fmin(zm[s2], fabs(pn));
                             sg[s2] = __builtin_amdgcn_alignbit(sg[s2], (unsigned)__double2hiint(pn), 31);
                             pp[s2] = p[s2];
                             p[s2] = pn;
@@ -2034,7 +2035,7 @@ __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, 
 #pragma unroll
                     for (int s2 = 0; s2 < 2; s2++) {
                         const double pn = fma(q.x - x[s2], p[s2], -(q.y * pp[s2]));
-                        zero[s2] |= (pn == 0.0);
+                        zm[s2] = fmin(zm[s2], fabs(pn));
                         cnt[s2] += ((__double2hiint(pn) ^ __double2hiint(p[s2])) < 0);
                         pp[s2] = p[s2];
                         p[s2] = pn;
@@ -2042,7 +2043,7 @@ __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, 
                 }
 #pragma unroll
                 for (int s2 = 0; s2 < 2; s2++) {
-                    if (__any(zero[s2])) cnt[s2] = sturm_slow(x[s2]); // wave-uniform
+                    if (__any(zm[s2] == 0.0)) cnt[s2] = sturm_slow(x[s2]); // wave-uniform
                     const unsigned long long mask = __ballot(cnt[s2] > kk[s2]);
                     const int jj = mask ? (int)__builtin_ctzll(mask) : 64;
                     const double xm = __shfl(x[s2], jj > 0 ? jj - 1 : 0, 64), xj = __shfl(x[s2], jj < 64 ? jj : 63, 64);
