@@ -304,13 +304,23 @@ __global__ __launch_bounds__(256) void k_prod192_u8(const uint8_t* __restrict__ 
         for (int r = 0; r < R; r++) wt[t][r] = Wb[(16 * t + li) * R + r];
     const uint8_t* Xb = X + (long)blockIdx.y * x_stride;
     const int g0 = (blockIdx.x * 4 + wave) * LRF_PROD192_GROUPS; // first 64-row group of this wave
+    uint4 xq[12], xn[12];
+    auto load_group = [&](int g, uint4 (&q)[12]) __attribute__((always_inline)) {
+        const int m = (g0 + g) * 64 + lane;
+        const uint8_t* xr = Xb + (long)(m < M ? m : M - 1) * 192;
+#pragma unroll
+        for (int t = 0; t < 12; t++) q[t] = *reinterpret_cast<const uint4*>(xr + 16 * t);
+    };
+    if (g0 * 64 < M) load_group(0, xq);
     for (int g = 0; g < LRF_PROD192_GROUPS; g++) {
         const int m = (g0 + g) * 64 + lane;
         if ((g0 + g) * 64 >= M) break; // wave-uniform
-        const uint8_t* xr = Xb + (long)(m < M ? m : M - 1) * 192;
-        uint4 xq[12];
+        const bool more = g + 1 < LRF_PROD192_GROUPS && (g0 + g + 1) * 64 < M; // wave-uniform
+        if (more) load_group(g + 1, xn); // the next group's rows are requested before this group's arithmetic
+        else {
 #pragma unroll
-        for (int t = 0; t < 12; t++) xq[t] = *reinterpret_cast<const uint4*>(xr + 16 * t);
+            for (int t = 0; t < 12; t++) xn[t] = make_uint4(0u, 0u, 0u, 0u);
+        }
         float acc[R];
 #pragma unroll
         for (int r = 0; r < R; r++) acc[r] = 0.f;
@@ -327,6 +337,8 @@ __global__ __launch_bounds__(256) void k_prod192_u8(const uint8_t* __restrict__ 
 #pragma unroll
             for (int r = 0; r < R; r++) uo[r] = acc[r];
         }
+#pragma unroll
+        for (int t = 0; t < 12; t++) xq[t] = xn[t];
     }
 }
 
