@@ -1898,7 +1898,7 @@ static int gram192_u8(lrf_ctx* c, const T* X, long xs, int B, int M, double* G)
     int* P = (int*)c->any_td.p; // consumed by the fold before the eigen-solver reuses the buffer (same stream)
     hipLaunchKernelGGL((k_gram192_u8<T>), dim3((unsigned)nchunks, (unsigned)B), dim3(256), 0, c->stream, X, xs, M, P, nchunks);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_gram192_fold, dim3(144, (unsigned)B), dim3(256), 0, c->stream, (const int*)P, nchunks, M, G);
+    hipLaunchKernelGGL(k_gram192_fold, dim3(78, (unsigned)B), dim3(256), 0, c->stream, (const int*)P, nchunks, M, G);
     LAUNCH_CHECK();
     return LRF_OK;
 }

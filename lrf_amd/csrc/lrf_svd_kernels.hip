@@ -138,8 +138,8 @@ __global__ __launch_bounds__(256) void k_gram_blk(const float* __restrict__ X, l
 // column sums s_i on the VALU, and G_ij = S_ij + 128 (s_i + s_j) + 128^2 M — exact integers (< 2^53), so G is the exact Gram
 // matrix and does not depend on how the rows are grouped.  One workgroup per (1536-row chunk, matrix): the twelve 16-column
 // tiles of a 64-row block meet in LDS as int8 in MFMA operand layout (double-buffered, one barrier per block), and wave w
-// accumulates the 12 x 3 tile products (all tiles) x (its own three) — both triangles, the same code in every wave — plus
-// the column sums of its tiles as products with a tile of ones.  k_gram192_fold adds the chunks' int32
+// accumulates the tile products (row tiles 0 .. jt) x (its own three column tiles jt) — the upper triangle, the same code in
+// every wave — plus the column sums of its tiles as products with a tile of ones.  k_gram192_fold adds the chunks' int32
 // partials and the offset terms.  256 x [6144,192]: 2.49 ms (k_gram_blk, fp64 MFMA at 39 % of its peak) -> 0.8 ms with strided dword loads -> see DESIGN.md.
 #define LRF_G192_ROWS 1536
 template <typename T> // float: uint8-valued floats; uint8_t: the bytes themselves (k_patchify_rgb<uint8_t>)
@@ -154,13 +154,20 @@ __global__ __launch_bounds__(256) void k_gram192_u8(const T* __restrict__ X, lon
     const int li = lane & 15, kq = lane >> 4;
     const int row_lo = chunk * LRF_G192_ROWS, row_hi = min(M, row_lo + LRF_G192_ROWS);
     const int nblk = (row_hi - row_lo + 63) >> 6;
-    i32x4 acc[3][12], accs[3];
+    // The upper triangle only (round 4; k_gram192_fold mirrors it): wave w owns the column tiles jt = w, 7 - w, 8 + w and for
+    // each the row tiles 0 .. jt — as straight-line code the same in every wave: 4 + 8 + 12 products (the ones with a row
+    // tile beyond jt are computed and dropped), 24 MFMAs per 64-row block and wave instead of 36, 96 accumulator registers
+    // instead of 144 (three waves per SIMD instead of two).
+    const int jt0 = wave, jt1 = 7 - wave, jt2 = 8 + wave;
+    i32x4 acc0[4], acc1[8], acc2[12], accs[3];
 #pragma unroll
-    for (int j = 0; j < 3; j++) {
-        accs[j] = (i32x4){0, 0, 0, 0};
+    for (int j = 0; j < 3; j++) accs[j] = (i32x4){0, 0, 0, 0};
 #pragma unroll
-        for (int i = 0; i < 12; i++) acc[j][i] = (i32x4){0, 0, 0, 0};
-    }
+    for (int i = 0; i < 4; i++) acc0[i] = (i32x4){0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc1[i] = (i32x4){0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 12; i++) acc2[i] = (i32x4){0, 0, 0, 0};
     // A 64 x 192 block is loaded as float4s along the rows (768 contiguous bytes per row: the strided dword loads of the
     // operand layout ran at 1.5 TB/s): item = (row group g of 4 rows, column group c4 of 4 columns), 16 x 48 items, three
     // per thread; its 4 x 4 values become int8, are transposed in registers (v_perm_b32) and go to LDS as four dwords, each
@@ -218,47 +225,65 @@ __global__ __launch_bounds__(256) void k_gram192_u8(const T* __restrict__ X, lon
         const uint4* lb = lds[blk & 1];
         i32x4 Bv[3];
         const i32x4 ones = (i32x4){0x01010101, 0x01010101, 0x01010101, 0x01010101};
+        const int jts[3] = {jt0, jt1, jt2};
 #pragma unroll
         for (int j = 0; j < 3; j++) {
-            const uint4 x = lb[(3 * wave + j) * 64 + lane];
+            const uint4 x = lb[jts[j] * 64 + lane];
             Bv[j] = (i32x4){(int)x.x, (int)x.y, (int)x.z, (int)x.w};
-            accs[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Bv[j], ones, accs[j], 0, 0, 0); // column sums of tile 3 wave + j (every column of D)
+            accs[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Bv[j], ones, accs[j], 0, 0, 0); // column sums of tile jts[j] (every column of D)
         }
 #pragma unroll
         for (int i = 0; i < 12; i++) {
             const uint4 x = lb[i * 64 + lane];
             const i32x4 Av = (i32x4){(int)x.x, (int)x.y, (int)x.z, (int)x.w};
-#pragma unroll
-            for (int j = 0; j < 3; j++) acc[j][i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Av, Bv[j], acc[j][i], 0, 0, 0);
+            if (i < 4) acc0[i < 4 ? i : 0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Av, Bv[0], acc0[i < 4 ? i : 0], 0, 0, 0);
+            if (i < 8) acc1[i < 8 ? i : 0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Av, Bv[1], acc1[i < 8 ? i : 0], 0, 0, 0);
+            acc2[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Av, Bv[2], acc2[i], 0, 0, 0);
         }
     }
-    // D[r][c] of tile product (i, j): rows r = 4 (lane >> 4) + reg of tile i, column c = lane & 15 of tile 3 wave + j
+    // D[r][c] of tile product (i, jt): rows r = 4 (lane >> 4) + reg of tile i, column c = lane & 15 of tile jt; i <= jt only
+    auto store_tile = [&](const i32x4& a, int i, int jt) __attribute__((always_inline)) {
+        if (i <= jt) { // wave-uniform
 #pragma unroll
-    for (int j = 0; j < 3; j++)
+            for (int reg = 0; reg < 4; reg++) Pp[(16 * i + 4 * kq + reg) * 192 + 16 * jt + li] = a[reg];
+        }
+    };
 #pragma unroll
-        for (int i = 0; i < 12; i++)
+    for (int i = 0; i < 4; i++) store_tile(acc0[i], i, jt0);
 #pragma unroll
-            for (int reg = 0; reg < 4; reg++) Pp[(16 * i + 4 * kq + reg) * 192 + 48 * wave + 16 * j + li] = acc[j][i][reg];
-    // column sums: D[r][c] = sum of column r of tile 3 wave + j for every c; the lanes with c = 0 write them
+    for (int i = 0; i < 8; i++) store_tile(acc1[i], i, jt1);
+#pragma unroll
+    for (int i = 0; i < 12; i++) store_tile(acc2[i], i, jt2);
+    // column sums: D[r][c] = sum of column r of tile jt for every c; the lanes with c = 0 write them
     if (li == 0) {
+        const int jts[3] = {jt0, jt1, jt2};
 #pragma unroll
         for (int j = 0; j < 3; j++)
 #pragma unroll
-            for (int reg = 0; reg < 4; reg++) Pp[192 * 192 + 48 * wave + 16 * j + 4 * kq + reg] = accs[j][reg];
+            for (int reg = 0; reg < 4; reg++) Pp[192 * 192 + 16 * jts[j] + 4 * kq + reg] = accs[j][reg];
     }
 }
 
+// One workgroup per 16 x 16 tile on or above the diagonal (78 of them; the partials hold those tiles only) and matrix: the
+// chunks' int32 partials and the offset terms, then the tile and — through LDS — its mirror image, both with row-contiguous
+// stores.  grid (78, B).
 __global__ __launch_bounds__(256) void k_gram192_fold(const int* __restrict__ P, int nchunks, int M, double* __restrict__ G)
 {
+    __shared__ double tile[16][17];
     const int* Pp = P + (long)blockIdx.y * nchunks * (192 * 192 + 192);
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= 192 * 192) return;
-    const int i = e / 192, j = e - 192 * i;
+    int it = 0, jt = 0; // blockIdx.x -> (it <= jt): row it of the triangle starts at it * 12 - it (it - 1) / 2
+    {
+        int t = blockIdx.x;
+        while (t >= 12 - it) { t -= 12 - it; it++; }
+        jt = it + t;
+    }
+    const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
+    const int i = 16 * it + r, j = 16 * jt + c, e = i * 192 + j;
     long long S = 0, si = 0, sj = 0;
     constexpr long PS = 192 * 192 + 192;
-    int c = 0;
-    for (; c + 4 <= nchunks; c += 4) { // (integer sums: any order) the loads of four chunks in flight
-        const int* pc = Pp + (long)c * PS;
+    int ch = 0;
+    for (; ch + 4 <= nchunks; ch += 4) { // (integer sums: any order) the loads of four chunks in flight
+        const int* pc = Pp + (long)ch * PS;
         const int a0 = pc[e], a1 = pc[PS + e], a2 = pc[2 * PS + e], a3 = pc[3 * PS + e];
         const int b0 = pc[192 * 192 + i], b1 = pc[PS + 192 * 192 + i], b2 = pc[2 * PS + 192 * 192 + i], b3 = pc[3 * PS + 192 * 192 + i];
         const int d0 = pc[192 * 192 + j], d1 = pc[PS + 192 * 192 + j], d2 = pc[2 * PS + 192 * 192 + j], d3 = pc[3 * PS + 192 * 192 + j];
@@ -266,13 +291,20 @@ __global__ __launch_bounds__(256) void k_gram192_fold(const int* __restrict__ P,
         si += ((long long)b0 + b1) + ((long long)b2 + b3);
         sj += ((long long)d0 + d1) + ((long long)d2 + d3);
     }
-    for (; c < nchunks; c++) {
-        const int* pc = Pp + (long)c * PS;
+    for (; ch < nchunks; ch++) {
+        const int* pc = Pp + (long)ch * PS;
         S += pc[e];
         si += pc[192 * 192 + i];
         sj += pc[192 * 192 + j];
     }
-    G[(long)blockIdx.y * 192 * 192 + e] = (double)(S + 128 * (si + sj) + 16384ll * M);
+    const double v = (double)(S + 128 * (si + sj) + 16384ll * M);
+    double* Gb = G + (long)blockIdx.y * 192 * 192;
+    Gb[e] = v;
+    if (it != jt) { // (block-uniform)
+        tile[r][c] = v;
+        __syncthreads();
+        Gb[(16 * jt + r) * 192 + 16 * it + c] = tile[c][r];
+    }
 }
 
 // ---- u = X w for the byte matrix [M,192] and R <= 8 columns (svd_encode): U[m][r] = the k-ordered fp32 fma chain over
