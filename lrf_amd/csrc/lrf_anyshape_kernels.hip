@@ -712,7 +712,7 @@ __global__ __launch_bounds__(256) void k_any_gram_mfma(const float* __restrict__
 // matrix in global memory three times per step (8.3 ms per 256 matrices of 192 x 192, ~95 % of svd_encode's initialisation);
 // here 256 NC threads hold it in registers — thread (lane i, wave b) keeps A[16 b + j][64 c + i], c < NC, j < 16, as NC
 // 16-double vectors, so row k is read with a register index.  Arithmetic: k_init's step (one reduction for sigma, t = 1 / (sigma + |x0| nrm),
-// p = t A v from chains over the row groups, commutative rank-2 update).  Output: row k of A keeps the reflector v_k (i > k),
+// p = t A v from chains over 16-row sub-blocks), the rank-2 update as two fmas per element; four barriers per step.  Output: row k of A keeps the reflector v_k (i > k),
 // td = d[n], e[n], tau[n] for k_any_eig<1>, which then starts at its eigenvalue stage.
 // lane `src_lane` of a double register, as a wave-uniform value (two v_readlane_b32: the result lives in SGPRs)
 __device__ __forceinline__ double readlane_f64(double v, int src_lane)
@@ -748,8 +748,7 @@ __global__ __launch_bounds__(256 * NC) void k_any_tridiag_reg(double* __restrict
     // every step for round 3's last row group).  Which thread forms a sub-block's chain does not change a bit: the chains
     // (sixteen consecutive rows from zero) and the order their sums are added in are the oracle's.
     const int b = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // the waves of a SIMD get different priorities, the later sub-blocks first: their scalar chains then run one after the
-    // other, each under the products of the others, instead of all three crawling together
+    // the waves of a SIMD get different priorities, the later sub-blocks (the ones that work until the last step) first
 #ifndef LRF_REG_NO_PRIO
     if (b >= 3 * NC) __builtin_amdgcn_s_setprio(3);
     else if (b >= 2 * NC) __builtin_amdgcn_s_setprio(2);
@@ -763,10 +762,11 @@ __global__ __launch_bounds__(256 * NC) void k_any_tridiag_reg(double* __restrict
             const int r = 16 * b + jj, col = 64 * c + lane;
             Ar[c][jj] = (r < n && col < n) ? A[(long)r * n + col] : 0.0;
         }
-    // Every wave holds v and w on ALL columns (NC values per lane: the scalars of a step are computed redundantly, same bits),
-    // so the values a thread needs at its ROWS come out of the wave's own registers by v_readlane (wave-uniform, in SGPRs)
-    // instead of broadcast LDS reads — twelve waves reading 144 doubles each per step had made the LDS the bottleneck
-    // (1.26 -> 0.5 ms per 256 matrices of 192 x 192).  The rows of sub-block b are the lanes 16 (b & 3) .. + 15 of chunk b >> 2.
+    // Every wave holds v and w on ALL columns (NC values per lane: v from the reflector waves or LDS, w computed in every
+    // wave, same bits), so the values a thread needs at its ROWS come out of the wave's own registers by v_readlane
+    // (wave-uniform, in SGPRs) instead of broadcast LDS reads — twelve waves reading 144 doubles each per step had made the
+    // LDS the bottleneck (1.26 -> 0.5 ms per 256 matrices of 192 x 192).  The rows of sub-block b are the lanes
+    // 16 (b & 3) .. + 15 of chunk b >> 2.
     auto pick = [&](const double (&q)[NC], int chunk) __attribute__((always_inline)) {
         double r = q[0];
         if (NC > 1 && chunk == 1) r = q[1];
