@@ -574,6 +574,9 @@ def main():
                         "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                         "algorithmic_bytes_per_launch": passes * alg_bytes, "avg_launch_ms": round(bcd_ms, 5),
                         "launches_measured": bcdp_launches,
+                        "traffic_source": ("profiles/traffic_latest.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                           "command on the same sources (tools/run_profiles_r04.sh, tools/make_traffic.py) — a committed "
+                                           "measurement, not collected in this run") if traffic is not None else None,
                         "note": "k_bcd_p = iterations 2..%d in one launch (%d U-update passes of %d B each + the per-matrix V updates, "
                                 "which the launch-per-iteration path ran as k_vupdate); the first iteration is k_bcd_w<1>: "
                                 "%.5f ms per launch" % (NUM_ITERS, passes, alg_bytes, bcd_total_ms / max(bcd_launches, 1))}
@@ -588,7 +591,10 @@ def main():
                 roof = {"bound": "hbm", "kernel": "k_bcd_w", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                         "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(bcd_ms, 5),
-                        "launches_measured": bcd_launches}
+                        "launches_measured": bcd_launches,
+                        "traffic_source": ("profiles/traffic_latest.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                           "command on the same sources (tools/run_profiles_r04.sh, tools/make_traffic.py) — a committed "
+                                           "measurement, not collected in this run") if traffic is not None else None}
         out = {
             "metric": metric,
             "value": round(value, 2),
