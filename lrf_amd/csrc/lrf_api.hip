@@ -35,7 +35,7 @@
 #define LRF_TABLE_SETS 6 // descriptor-table sets a context keeps resident (upload_tables)
 #define LRF_BCDW_MIN_BLOCKS 1024 // smaller rank <= 8 runs iterate on the workgroup kernel k_bcd (run_bcd)
 #define LRF_BCDW16_MIN_BLOCKS 1024 // likewise for rank <= 16 runs and k_bcd_w16
-#define LRF_PERSIST_MIN_BLOCKS 4096 // a rank <= 8 call of this many blocks runs its iterations 2..K in one launch (k_bcd_p)
+#define LRF_PERSIST_MIN_BLOCKS 3584 // a rank <= 8 call of this many blocks runs its iterations 2..K in one launch (k_bcd_p)
 #define LRF_SHARE_MIN_BLOCKS 3072   // LRF_SHARES=2|3: a rank <= 8 call of this many blocks runs as two image shares (run_two_shares)
 #define LRF_BCDW32_MIN_BLOCKS 128  // likewise for rank 17..32 runs and k_bcd_w32 / k_bcd_w32f (12 images: 1.06 -> 0.99 ms at (20,10,10))
 
@@ -590,9 +590,11 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
     static const long w32_min = getenv("LRF_BCDW32_MIN_BLOCKS") ? atol(getenv("LRF_BCDW32_MIN_BLOCKS")) : LRF_BCDW32_MIN_BLOCKS; // developer aid
     static const long w16_min = getenv("LRF_BCDW16_MIN_BLOCKS") ? atol(getenv("LRF_BCDW16_MIN_BLOCKS")) : LRF_BCDW16_MIN_BLOCKS; // developer aid
     // Iterations 2..K of a large single-run rank <= 8 call in ONE launch (k_bcd_p, lrf_bcdp_kernel.hip; round 4): the U updates of
-    // all iterations pulled from a queue, each matrix's V update done by the last of its blocks to finish.  From 4096 blocks
-    // on (256 x 512x768: 2.05 -> 1.93 ms per step; 64 x 1365x2048: 3.47 -> 3.27 ms); calls of many small matrices lose (300 x
-    // 173x264: 0.73 -> 0.79 ms) and stay on the launch-per-iteration path.  LRF_PERSIST=0 turns it off, =1 forces it from
+    // all iterations pulled from a queue, each matrix's V update done by the last of its blocks to finish.  From 3584 blocks
+    // on (256 x 512x768: 2.05 -> 1.93 ms per step; 64 x 1365x2048: 3.47 -> 3.27 ms; tools/dev_persist_threshold.py, 512x768
+    // images: 48 / 64 images lose 15 %, 96 win 3 %, 128 lose 1.5 % — a round and a half of the 2048 wave slots —, 160 win 3 %,
+    // 192 win 7 %); what decides is the number of blocks, not the matrices' size (tools/dev_persist_small.py: 1200 x 173x264
+    // -3 %, 600 x 352x288 -9 %; 300 x 173x264, 1200 blocks: +8 %).  LRF_PERSIST=0 turns it off, =1 forces it from
     // LRF_BCDW_MIN_BLOCKS blocks on (tests).
     static const int persist_env = getenv("LRF_PERSIST") ? atoi(getenv("LRF_PERSIST")) : -1;
     const bool persist_ok = runs.size() == 1 && runs[0].fam == 0 && wave_variant && K >= 2 && !c->fam_forked &&
