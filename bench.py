@@ -300,6 +300,69 @@ def decode_leg(torch, _lib, ctx, U, V, H, W, ranks, steps):
                                 "frac": round(alg / (k * 1e-3) / 1e9 / 8000.0, 4), "algorithmic_bytes_per_launch": alg}}
 
 
+def smooth_batch(torch, dev, count, H, W, seed=4321):
+    """SURVEY 8(d) config 2's smooth variant: bilinear-upsampled (H/8 x W/8) uniform noise + N(0, 4) per pixel, clamped to
+    uint8 — low-rank structure, so the clamp / saturation paths, the tie fallback of the Gauss-Seidel and the exact-division
+    path see other data than on i.i.d. noise."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    base = torch.rand((count, 3, H // 8, W // 8), device=dev, generator=g) * 255.0
+    img = torch.nn.functional.interpolate(base, size=(H, W), mode="bilinear", align_corners=False)
+    img = img + torch.randn((count, 3, H, W), device=dev, generator=g) * 2.0
+    return img.clamp_(0, 255).to(torch.uint8)
+
+
+def sweep_leg(torch, lrf_amd, _lib, ctx, images, H, W, steps=10):
+    """The other workloads the reference's sweeps run (experiments/comparison/eval.py:83: luma ranks up to 26; BASELINE config 3:
+    24 images per call) next to the headline, each timed like it (inputs and factors in HBM, one region of `steps` steps between
+    synchronisations, events on the BCD launches only): quality 7 = ranks (4,2,2) and the smooth-image variant of config 2
+    (SURVEY 8(d)), the rank families 9..16 and 17..32 at 256 images, the headline ranks at 24 and 64 images."""
+    dims = _lib.plane_dims(H, W)
+    B = images.shape[0]
+    smooth = smooth_batch(torch, images.device, B, H, W)
+    cases = [("256 x 512x768 random, quality 7 = ranks (4,2,2)", images, (4, 2, 2)),
+             ("256 x 512x768 smooth (upsampled noise + N(0,4)), ranks (7,3,3)", smooth, (7, 3, 3)),
+             ("256 x 512x768 random, ranks (16,8,8)", images, (16, 8, 8)),
+             ("256 x 512x768 random, ranks (26,13,13)", images, (26, 13, 13)),
+             ("64 x 512x768 random, ranks (7,3,3)", images[:64], (7, 3, 3)),
+             ("24 x 512x768 random, ranks (7,3,3) (one quality of BASELINE config 3 in one call)", images[:24], (7, 3, 3))]
+    out = []
+    for label, imgs, ranks in cases:
+        imgs = imgs.contiguous()
+        n = imgs.shape[0]
+        U = torch.empty((n, sum(d[4] * r for d, r in zip(dims, ranks))), dtype=torch.int8, device=imgs.device)
+        V = torch.empty((n, 64 * sum(ranks)), dtype=torch.int8, device=imgs.device)
+        for _ in range(3):
+            lrf_amd.qmf_factorize_batch(imgs, ranks, NUM_ITERS, BOUNDS, out=(U, V))
+        ctx.profile_kernels([_lib.LRF_K_BCD, _lib.LRF_K_BCD_PERSIST])
+        ctx.profile_reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            lrf_amd.qmf_factorize_batch(imgs, ranks, NUM_ITERS, BOUNDS, out=(U, V))
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        ctx.synchronize()  # (raises if a persistent launch gave up)
+        bcd_ms, bcd_n = ctx.kernel_time(_lib.LRF_K_BCD)
+        p_ms, p_n = ctx.kernel_time(_lib.LRF_K_BCD_PERSIST)
+        ctx.profile(False)
+        alg = n * (sum(d[4] for d in dims) * 64 * 4 + sum(d[4] * r for d, r in zip(dims, ranks)))  # one U-update pass over all planes
+        if p_n:  # iterations 2..K in one launch
+            kname, k_ms, k_bytes = "k_bcd_p", p_ms / p_n, (NUM_ITERS - 1) * alg
+        else:  # one U-update launch per iteration (a call of several rank families: their launches of an iteration together)
+            kname, k_ms, k_bytes = "k_bcd (launch per iteration)", bcd_ms / bcd_n, alg
+        out.append({"workload": label, "ranks": list(ranks), "images": n, "ms_per_step": round(dt * 1e3, 4),
+                    "mpix_s": round(n * H * W / dt / 1e6, 1),
+                    "dominant_kernel": kname, "kernel_avg_ms": round(k_ms, 5), "algorithmic_bytes_per_launch": k_bytes,
+                    "roofline_frac": round(k_bytes / (k_ms * 1e-3) / 8e12, 4),
+                    "whole_encode_frac_of_hbm_peak": round(75.1 * n * H * W / dt / 8e12, 4)})
+        del U, V
+    return {"sweep": out,
+            "sweep_note": "each entry: HBM-resident like `value`, 3 warm-up calls then one region of %d steps; roofline_frac = "
+                          "algorithmic bytes of the dominant BCD launch (X read once per pass + int8 U written once per pass) / its "
+                          "HIP-event time / 8 TB/s; whole_encode_frac by SURVEY 8(d)'s 75.1 B/pixel (priced at ranks (7,3,3))" % steps}
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -626,14 +689,18 @@ def main():
             # 75.1 algorithmic bytes per input pixel for the whole encode at K = 10
             "whole_encode_frac_of_hbm_peak": round(75.1 * total_px / world / dt / 8e12, 4) if args.config != "svd" else None,
             "kernels": {k: {a: round(b, 5) for a, b in v.items()} for k, v in kern.items()},
-            "kernels_note": "per-kernel breakdown from a separate untimed pass with every launch bracketed by events; "
-                            "roofline.avg_launch_ms is measured inside the timed regions (events on the BCD launches only)",
+            "kernels_note": "per-kernel breakdown from a separate untimed pass with every launch bracketed by events (k_bcd = the "
+                            "first iteration's launch, k_bcd_persist = iterations 2..K in one launch where k_bcd_p runs; the V "
+                            "updates of those iterations happen inside it); roofline.avg_launch_ms is measured inside the timed "
+                            "regions (events on the BCD launches only)",
         }
         out["ranks"] = rank_stats
         out["forced_dist"] = force_dist
         out.update(extras)
         if world == 1 and not args.no_extras and args.config != "svd":
             out.update(decode_leg(torch, _lib, ctx, U, V, H, W, RANKS, args.steps))
+            if args.config == "kodak" and B == 256:
+                out.update(sweep_leg(torch, lrf_amd, _lib, ctx, images, H, W))
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(images[:min(B, 256)].cpu().numpy(), H, W, RANKS)
                 out["cpu_baseline"]["reference_torch_cpu"] = REFERENCE_TORCH_CPU.get(args.config)

@@ -58,6 +58,15 @@ void lrf_ctx_destroy(lrf_ctx* ctx);
 int lrf_ctx_set_stream(lrf_ctx* ctx, void* hip_stream);
 int lrf_ctx_use_own_stream(lrf_ctx* ctx);
 int lrf_ctx_synchronize(lrf_ctx* ctx);
+/* Asynchronous failures.  Large rank <= 8 calls run their iterations 2..K in ONE launch (k_bcd_p) whose waves wait for each
+ * other with BOUNDED polls; a poll that expires (never observed in service; the exit every wave reaches) makes the launch
+ * give up and report its number in page-locked host memory.  Because calls only enqueue, the report is read where results are
+ * handed back: lrf_ctx_synchronize (after its wait), lrf_pipe_wait_next (for the piece it returns), the next persistent
+ * call's entry, and lrf_ctx_check — which does NOT wait: call it after the stream has been waited for by other means (a
+ * device-to-host copy on the stream, an event).  A non-zero return means: the factors of the named call and of every later
+ * call on this context up to the check are invalid; the context itself stays usable (the next call clears the state).
+ * Replaces nothing in the reference (its calls are synchronous Python): this is the error half of the async boundary. */
+int lrf_ctx_check(lrf_ctx* ctx);
 /* bytes of scratch the context currently holds.  The scratch grows to the largest call seen (2.4 KB per input pixel of the
  * default branch: a 512 x 1365x2048 batch holds ~9 GB) and is kept for reuse; lrf_ctx_trim waits for the stream and gives
  * all of it back (the next call allocates again). */
@@ -167,6 +176,15 @@ int lrf_qmf_decompose_ex_f32(lrf_ctx* ctx, const float* X, int64_t B, int64_t M,
  */
 int lrf_qmf_svd_init_f32(lrf_ctx* ctx, const float* X, int64_t B, int64_t M, int64_t N, int R,
                          const int8_t* sign, float* U0, float* V0);
+
+/*
+ * QMF.loss(x, u, v, w) for a batch: the relative error ||x - (w0 + w1 u v^T)||_F / (||x||_F + 1e-16) per matrix —
+ * lrf/factorization/qmf.py:225-227, relative_error lrf/factorization/utils.py:12-15 — which QMF(verbose=True) prints before every
+ * iteration (qmf.py:208-210).  X [B,M,N], U [B,M,R], V [B,N,R] fp32; W [B,2] = (w0, w1) or NULL (= (0, 1)); loss [B] fp32.  The
+ * sums are accumulated in fp64 (the reference: torch.norm in fp32; agreement to ~1e-6 relative).
+ */
+int lrf_qmf_loss_f32(lrf_ctx* ctx, const float* X, const float* U, const float* V, const float* W, int64_t B, int64_t M, int64_t N, int R,
+                     float* loss);
 
 /*
  * Fused encode of B images (default qmf_encode branch, everything between image.float() and the

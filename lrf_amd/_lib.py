@@ -49,6 +49,7 @@ def load():
         lib.lrf_ctx_set_stream.argtypes = [c_void_p, c_void_p]
         lib.lrf_ctx_use_own_stream.argtypes = [c_void_p]
         lib.lrf_ctx_synchronize.argtypes = [c_void_p]
+        lib.lrf_ctx_check.argtypes = [c_void_p]
         lib.lrf_ctx_trim.argtypes = [c_void_p]
         lib.lrf_ctx_profile.argtypes = [c_void_p, c_int]
         lib.lrf_ctx_profile_reset.argtypes = [c_void_p]
@@ -67,6 +68,7 @@ def load():
         lib.lrf_qmf_decompose_ex_f32.argtypes = [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_int, ctypes.POINTER(QmfOpts), c_void_p,
                                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         lib.lrf_qmf_svd_init_f32.argtypes = [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p]
+        lib.lrf_qmf_loss_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_void_p]
         lib.lrf_qmf_encode_rgb_u8.argtypes = [c_void_p, c_void_p, c_i64, c_i64, c_i64, ctypes.POINTER(c_int), c_int, c_int,
                                               c_int, c_void_p, c_void_p, c_void_p]
         lib.lrf_qmf_decode_rgb_u8.argtypes = [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, ctypes.POINTER(c_int),
@@ -111,9 +113,9 @@ def load():
 
 
 EXPORTS = ["lrf_last_error", "lrf_device_count", "lrf_version", "lrf_ctx_create", "lrf_ctx_destroy", "lrf_ctx_set_stream", "lrf_ctx_use_own_stream",
-           "lrf_ctx_synchronize", "lrf_ctx_workspace_bytes", "lrf_ctx_trim", "lrf_ctx_profile", "lrf_ctx_profile_kernels", "lrf_ctx_kernel_time",
+           "lrf_ctx_synchronize", "lrf_ctx_check", "lrf_ctx_workspace_bytes", "lrf_ctx_trim", "lrf_ctx_profile", "lrf_ctx_profile_kernels", "lrf_ctx_kernel_time",
            "lrf_ctx_profile_reset", "lrf_malloc", "lrf_free", "lrf_memcpy_h2d", "lrf_memcpy_d2h", "lrf_plane_dims",
-           "lrf_qmf_planes_from_rgb_u8", "lrf_qmf_decompose_f32", "lrf_qmf_decompose_ex_f32", "lrf_qmf_bcd_f32", "lrf_qmf_svd_init_f32",
+           "lrf_qmf_planes_from_rgb_u8", "lrf_qmf_decompose_f32", "lrf_qmf_decompose_ex_f32", "lrf_qmf_bcd_f32", "lrf_qmf_svd_init_f32", "lrf_qmf_loss_f32",
            "lrf_qmf_encode_rgb_u8", "lrf_qmf_decode_rgb_u8", "lrf_svd_encode_rgb_u8", "lrf_svd_decode_rgb_u8",
            "lrf_qmf_rgbspace_encode_u8", "lrf_qmf_rgbspace_decode_u8", "lrf_rgbspace_dims_any", "lrf_qmf_rgbspace_matrix_u8",
            "lrf_qmf_rgbspace_decode_any_u8", "lrf_quantize_u8", "lrf_svd_decode_any_u8",
@@ -212,6 +214,19 @@ class Context:
     def synchronize(self):
         check(self._lib.lrf_ctx_synchronize(self._h))
 
+    def check(self):
+        """Raises LrfError if a persistent launch (k_bcd_p) on this context gave up since the last look (include/lrf_hip.h,
+        lrf_ctx_check).  Does not wait: call it once the stream has been waited for — after `.cpu()` of a result, a
+        torch.cuda.synchronize().  Every wrapper that hands results to the host calls it (`to_host`)."""
+        check(self._lib.lrf_ctx_check(self._h))
+
+    def to_host(self, *tensors):
+        """the tensors on the host (torch's copy waits for the stream the kernels ran on), then `check`: the one way results
+        of the encoder leave the device in this package, so that a failed launch raises in the call it belongs to"""
+        out = tuple(t.cpu() for t in tensors)
+        self.check()
+        return out
+
     def workspace_bytes(self):
         return int(self._lib.lrf_ctx_workspace_bytes(self._h))
 
@@ -306,6 +321,20 @@ class Context:
         self.use_torch_stream()
         check(self._lib.lrf_qmf_svd_init_f32(self._h, _dptr(X), B, M, N, R, _dptr(sign), _dptr(U0), _dptr(V0)))
         return U0, V0
+
+    def loss(self, X, U, V, W=None):
+        """QMF.loss per matrix (lrf_qmf_loss_f32): X [B,M,N], U [B,M,R], V [B,N,R] fp32 CUDA, W [B,2] or None -> fp32 [B]"""
+        import torch
+        X, U, V = X.float().contiguous(), U.float().contiguous(), V.float().contiguous()
+        B, M, N = X.shape
+        R = U.shape[-1]
+        assert tuple(U.shape) == (B, M, R) and tuple(V.shape) == (B, N, R)
+        if W is not None:
+            W = W.to(device=X.device, dtype=torch.float32).reshape(B, 2).contiguous()
+        out = torch.empty((B,), dtype=torch.float32, device=X.device)
+        self.use_torch_stream()
+        check(self._lib.lrf_qmf_loss_f32(self._h, _dptr(X), _dptr(U), _dptr(V), _dptr(W), B, M, N, int(R), _dptr(out)))
+        return out
 
     def encode_rgb(self, rgb, ranks, K, lo, hi, sign=None, out=None):
         """rgb uint8 [B,3,H,W] (CUDA) -> (U int8 [B, sum M_c R_c], V int8 [B, 64 sum R_c])"""
@@ -611,8 +640,9 @@ class Pipe:
                 yield int(first.value), int(n.value), U, V
         finally:  # never leave copies into the caller's buffers in flight (an abandoned generator, an error)
             n = c_i64(1)
-            while n.value:
-                if self._lib.lrf_pipe_wait_next(self._h, None, ctypes.byref(n)):
+            for _ in range(max(1, int(n_sub.value)) + 1):  # (a piece that reports a failed launch still counts as waited for)
+                self._lib.lrf_pipe_wait_next(self._h, None, ctypes.byref(n))
+                if not n.value:
                     break
 
 

@@ -124,6 +124,31 @@ _PACK_POOL = None
 _PACK_LIB = None
 
 
+def default_pack_threads() -> int:
+    """Host threads for the zlib-9 container packing when the caller names none: the CPUs this process may actually use —
+    the smaller of its affinity mask and its cgroup CPU quota (a GPU box here: 256 CPUs in the mask, a quota of 16; more
+    threads than the quota borrow against it and are then throttled, DESIGN.md "bytes out")."""
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: [t.strip(), None])):
+        try:
+            with open(path) as f:
+                quota, period = parse(f.read())
+            if period is None:
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = f.read().strip()
+            if quota not in ("max", "-1") and int(period) > 0:
+                n = min(n, max(1, int(quota) // int(period)))
+            break
+        except (OSError, ValueError):
+            continue
+    return max(1, min(n, 64))
+
+
 def _pack_lib():
     """liblrf_pack.so (include/lrf_pack.h): the same container built by native host threads."""
     global _PACK_LIB
@@ -238,7 +263,7 @@ def qmf_encode_batch(images: torch.Tensor, rank=None, quality=None, bounds=(-16,
                      init_sign=None, pack_workers: Optional[int] = None, patch: bool = True, patch_size=(8, 8)) -> list:
     """Batched qmf_encode (YCbCr branch) -> list of byte streams, one per image.  The factorisation of the whole batch
     runs on the GPU; for the default 8x8 patches the byte containers are packed by liblrf_pack.so on native host threads
-    (`pack_workers` = 0: one per hardware thread), or, with pack_workers="python", by the Python container code on a
+    (`pack_workers` None / 0: as many as this process may use, default_pack_threads), or, with pack_workers="python", by the Python container code on a
     thread pool.  Other patch sizes and patch=False go through the any-shape kernels (container packed in Python)."""
     assert (rank, quality) != (None, None), "Either 'rank' or 'quality' must be specified."
     H, W = images.shape[-2:]
@@ -258,7 +283,7 @@ def qmf_encode_batch(images: torch.Tensor, rank=None, quality=None, bounds=(-16,
             for first, n, U, V in pipe.encode_rgb_host_iter(images, ranks, num_iters, math.ceil(bounds[0]), math.floor(bounds[1]),
                                                             init_sign):
                 streams += pack_streams_native(U[first:first + n].numpy(), V[first:first + n].numpy(), (H, W), ranks, bounds,
-                                               (8, 8), "uint8", threads=pack_workers or 0)
+                                               (8, 8), "uint8", threads=pack_workers or default_pack_threads())
             return streams
     ctx = _lib.context(images.device.index if images.is_cuda else None)
     dev = images if images.is_cuda else images.cuda(ctx.device)
@@ -270,11 +295,11 @@ def qmf_encode_batch(images: torch.Tensor, rank=None, quality=None, bounds=(-16,
                                     init_sign, None)
     ranks = qmf_ranks((H, W), rank, quality)
     U, V = qmf_factorize_batch(dev, ranks, num_iters, bounds, init_sign)
-    Uh, Vh = U.cpu().numpy(), V.cpu().numpy()
+    Uh, Vh = (t.numpy() for t in ctx.to_host(U, V))  # waits for the stream, then raises if a launch of this call gave up
     dtype_name = str(images.dtype).split(".")[-1]
     if pack_workers != "python" and not (isinstance(pack_workers, int) and pack_workers < 0):
         try:
-            return pack_streams_native(Uh, Vh, (H, W), ranks, bounds, (8, 8), dtype_name, threads=pack_workers or 0)
+            return pack_streams_native(Uh, Vh, (H, W), ranks, bounds, (8, 8), dtype_name, threads=pack_workers or default_pack_threads())
         except OSError:  # liblrf_pack.so missing or linked against another zlib: the Python container code, same bytes
             pack_workers = "python"
     pack_workers = None if pack_workers == "python" else -pack_workers
@@ -319,9 +344,10 @@ def qmf_encode(image: torch.Tensor, rank=None, quality=None, color_space: str = 
         factors = _svd_init_factors(ctx, dev, ranks, init_sign)
     else:
         U, V = qmf_factorize_batch(dev, ranks, num_iters, (lo, hi), init_sign)
-        Uh, Vh = U.cpu().numpy(), V.cpu().numpy()
+        Uh, Vh = (t.numpy() for t in ctx.to_host(U, V))
         try:  # the container through liblrf_pack.so: the columns of the six factors are zlib-packed on host threads
-            return pack_streams_native(Uh, Vh, (H, W), ranks, bounds, patch_size, str(image.dtype).split(".")[-1], threads=16)[0]
+            return pack_streams_native(Uh, Vh, (H, W), ranks, bounds, patch_size, str(image.dtype).split(".")[-1],
+                                       threads=default_pack_threads())[0]
         except OSError:  # library not built: the same bytes from the Python container code
             factors = split_factors(Uh[0], Vh[0], (H, W), ranks)
     return pack_image(factors, (H, W), ranks, bounds, patch_size, str(image.dtype).split(".")[-1])
@@ -472,6 +498,7 @@ def _qmf_encode_general(ctx, dev, color_space, rank, quality, bounds, patch_size
 
 
 _PLANE_LANES = {}
+_PLANE_LANES_LOCK = __import__("threading").Lock()
 
 
 def _plane_lanes(device):
@@ -481,20 +508,26 @@ def _plane_lanes(device):
     256 x 512x768 host -> host from 6.1 to 7-9 ms), and a lane's workspace is a few hundred MB after a large patch=False call."""
     import threading
     key = (threading.get_ident(), torch.device(device).index or 0)
-    if key not in _PLANE_LANES:
-        _PLANE_LANES[key] = ([_lib.Context(key[1]) for _ in range(3)], [torch.cuda.Stream(device=key[1]) for _ in range(3)])
-    return _PLANE_LANES[key]
+    with _PLANE_LANES_LOCK:
+        lanes = _PLANE_LANES.get(key)
+    if lanes is None:
+        lanes = ([_lib.Context(key[1]) for _ in range(3)], [torch.cuda.Stream(device=key[1]) for _ in range(3)])
+        with _PLANE_LANES_LOCK:
+            _PLANE_LANES[key] = lanes
+    return lanes
 
 
 def release_plane_lanes(all_threads: bool = False) -> int:
-    """Destroys the plane lanes of the calling thread (or of every thread): their contexts (workspaces, streams) and torch
-    streams.  Called by qmf_encode_batch's host path; safe to call any time (the lanes are re-created on demand).
-    Returns the number of lane sets released."""
+    """Destroys the plane lanes of the calling thread: their contexts (workspaces, streams) and torch streams.  Called by
+    qmf_encode_batch's host path; safe to call any time (the lanes are re-created on demand).  all_threads=True also takes
+    the lanes of OTHER threads — only for a quiescent process (tests, shutdown): a lane another thread is encoding on would
+    be closed under it.  Returns the number of lane sets released."""
     import threading
     me = threading.get_ident()
     n = 0
-    for key in [k for k in _PLANE_LANES if all_threads or k[0] == me]:
-        ctxs, lanes = _PLANE_LANES.pop(key)
+    with _PLANE_LANES_LOCK:
+        mine = [(k, _PLANE_LANES.pop(k)) for k in list(_PLANE_LANES) if all_threads or k[0] == me]
+    for key, (ctxs, lanes) in mine:
         for st in lanes:
             st.synchronize()
         for c in ctxs:

@@ -2458,3 +2458,40 @@ __global__ __launch_bounds__(256) void k_any_decode(AnyDecodePlane d0, AnyDecode
         out[(long)ch * H * W + o] = (uint8_t)acc; // truncation (to_dtype)
     }
 }
+
+// ---- QMF.loss (lrf/factorization/qmf.py:225-227; relative_error, lrf/factorization/utils.py:12-15): per matrix the squared
+// norms of x - (w0 + w1 u v^T) and of x, in fp64 (k_any_loss, one workgroup per 64-row tile: partial sums added by atomics),
+// then sqrt(num) / (sqrt(den) + 1e-16) (k_any_loss_finish).  A diagnostic (QMF(verbose=True)), not part of the encoder.
+__global__ __launch_bounds__(256) void k_any_loss(const float* __restrict__ X, const float* __restrict__ U, const float* __restrict__ V,
+                                                  const float* __restrict__ Wp, int M, int N, int R, double* __restrict__ acc)
+{
+    const int b = blockIdx.y, row0 = blockIdx.x * 64;
+    const float* x = X + (long)b * M * N;
+    const float* u = U + (long)b * M * R;
+    const float* v = V + (long)b * N * R;
+    const float w0 = Wp ? Wp[2 * b] : 0.f, w1 = Wp ? Wp[2 * b + 1] : 1.f;
+    __shared__ double part[4];
+    double num = 0.0, den = 0.0;
+    const int rows = M - row0 < 64 ? M - row0 : 64;
+    for (long e = threadIdx.x; e < (long)rows * N; e += 256) {
+        const int m = row0 + (int)(e / N), n = (int)(e % N);
+        float y = 0.f; // u @ v.mT: a k-ordered fma chain
+        for (int r = 0; r < R; r++) y = fmaf(u[(long)m * R + r], v[(long)n * R + r], y);
+        y = Wp ? w0 + w1 * y : y;
+        const float xv = x[(long)m * N + n];
+        const double d = (double)(xv - y);
+        num += d * d;
+        den += (double)xv * (double)xv;
+    }
+    num = block_sum(num, part, threadIdx.x);
+    den = block_sum(den, part, threadIdx.x);
+    if (threadIdx.x == 0) {
+        atomicAdd(&acc[2 * b], num);
+        atomicAdd(&acc[2 * b + 1], den);
+    }
+}
+__global__ void k_any_loss_finish(const double* __restrict__ acc, int B, float* __restrict__ loss)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) loss[b] = (float)(sqrt(acc[2 * b]) / (sqrt(acc[2 * b + 1]) + 1e-16));
+}

@@ -43,64 +43,84 @@ __device__ __forceinline__ void w16_tiles_to_rows(const f32x4 (&acc)[4], float (
     }
 }
 
-// The int8 row of R bytes as ceil(R/4) dwords (bytes past R are zero), all in registers (uint4 by value: arrays of
-// dwords merged through the rank switch ended up in scratch memory).  R >= 4: dword d comes from offset min(4d, R-4)
-// (unaligned, the last one overlapping its predecessor); R < 4: byte loads (a dword would leave the row's allocation).
-template <int R>
-__device__ __forceinline__ uint4 w16_load_row(const int8_t* up)
+// The old int8 row of a lane, R bytes from `up` (any alignment), requested one sub-tile ahead and finished (w16_row_dwords) when
+// it is used: dword d of the finished row = bytes 4d .. 4d+3 (bytes at or past R: unspecified — the solve reads R of them).
+//   MemLaunch: ceil(R/4) unaligned dword loads from offsets min(4d, R-4) (the last one overlapping its predecessor; R < 4: byte
+//              loads, a dword would leave the row's allocation), the partial last dword shifted into place when finished;
+//   MemSc1   : the ALIGNED dwords that cover the row as compiler-tracked sc1 loads (k_bcd_p's scheme: a hand-issued asm load
+//              would leave its result register open to compiler copies before the data has landed), funnel-shifted
+//              (v_alignbyte) when finished; the last dword is clamped to the one that holds the row's last byte.
+struct W16RawRow {
+    unsigned d[5];
+    unsigned sh;
+};
+template <int R, class MEM>
+__device__ __forceinline__ void w16_load_row(const int8_t* up, W16RawRow& w)
 {
-    uint4 w = make_uint4(0u, 0u, 0u, 0u);
-    if constexpr (R < 4) {
+    if constexpr (MEM::kSc1) {
+        const uintptr_t a0 = reinterpret_cast<uintptr_t>(up);
+        const uintptr_t base = a0 & ~(uintptr_t)3, last = (a0 + R - 1) & ~(uintptr_t)3;
+        w.sh = (unsigned)(a0 & 3);
+        constexpr int ND = (R + 3) / 4 + 1; // aligned dwords that can hold R bytes at any offset
+#pragma unroll
+        for (int d = 0; d < 5; d++)
+            if (d < ND) {
+                const uintptr_t a = base + 4 * d <= last ? base + 4 * d : last;
+                w.d[d] = MEM::ld_u32(reinterpret_cast<const unsigned*>(a));
+            }
+    } else if constexpr (R < 4) {
         unsigned v = (uint8_t)up[0];
         if constexpr (R > 1) v |= (unsigned)(uint8_t)up[R > 1 ? 1 : 0] << 8;
         if constexpr (R > 2) v |= (unsigned)(uint8_t)up[R > 2 ? 2 : 0] << 16;
-        w.x = v;
+        w.d[0] = v;
     } else {
-        w.x = *reinterpret_cast<const u32_unaligned*>(up);
-        if constexpr (R > 4) w.y = *reinterpret_cast<const u32_unaligned*>(up + (R >= 8 ? 4 : R - 4));
-        if constexpr (R > 8) w.z = *reinterpret_cast<const u32_unaligned*>(up + (R >= 12 ? 8 : R - 4));
-        if constexpr (R > 12) w.w = *reinterpret_cast<const u32_unaligned*>(up + (R >= 16 ? 12 : R - 4));
+        w.d[0] = *reinterpret_cast<const u32_unaligned*>(up);
+        if constexpr (R > 4) w.d[1] = *reinterpret_cast<const u32_unaligned*>(up + (R >= 8 ? 4 : R - 4));
+        if constexpr (R > 8) w.d[2] = *reinterpret_cast<const u32_unaligned*>(up + (R >= 12 ? 8 : R - 4));
+        if constexpr (R > 12) w.d[3] = *reinterpret_cast<const u32_unaligned*>(up + (R >= 16 ? 12 : R - 4));
     }
-    return w;
 }
-// what w16_load_row fetched -> bytes 4d .. 4d+3 of the row in dword d, zero past the row's end: the partial last dword
-// was loaded from offset R - 4, so byte 4d of the row sits at index 4 - (R & 3) of it
-template <int R>
-__device__ __forceinline__ uint4 w16_align_row(uint4 w)
+template <int R, class MEM>
+__device__ __forceinline__ uint4 w16_row_dwords(const W16RawRow& w)
 {
-    if constexpr (R >= 4 && (R & 3) != 0) {
-        constexpr int sh = 8 * (4 - (R & 3));
-        if constexpr (R / 4 == 1) w.y >>= sh;
-        if constexpr (R / 4 == 2) w.z >>= sh;
-        if constexpr (R / 4 == 3) w.w >>= sh;
+    unsigned o[4] = {0u, 0u, 0u, 0u};
+    if constexpr (MEM::kSc1) {
+#pragma unroll
+        for (int d = 0; d < 4; d++)
+            if (4 * d < R) o[d] = __builtin_amdgcn_alignbyte(w.d[d + 1 < (R + 3) / 4 + 1 ? d + 1 : d], w.d[d], w.sh);
+    } else {
+#pragma unroll
+        for (int d = 0; d < 4; d++)
+            if (4 * d < R) o[d] = w.d[d];
+        // the partial last dword was loaded from offset R - 4, so byte 4d of the row sits at index 4 - (R & 3) of it
+        if constexpr (R >= 4 && (R & 3) != 0) o[R / 4] >>= 8 * (4 - (R & 3));
     }
-    return w;
+    return make_uint4(o[0], o[1], o[2], o[3]);
 }
-template <int R>
+template <int R, class MEM>
 __device__ __forceinline__ void w16_store_row(int8_t* uo, const uint4 w)
 {
     if constexpr (R < 4) {
-        uo[0] = (int8_t)w.x;
-        if constexpr (R > 1) uo[1] = (int8_t)(w.x >> 8);
-        if constexpr (R > 2) uo[2] = (int8_t)(w.x >> 16);
+        MEM::st_u8(uo, (int8_t)w.x);
+        if constexpr (R > 1) MEM::st_u8(uo + 1, (int8_t)(w.x >> 8));
+        if constexpr (R > 2) MEM::st_u8(uo + 2, (int8_t)(w.x >> 16));
     } else {
-        *reinterpret_cast<u32_unaligned*>(uo) = w.x;
-        if constexpr (R >= 8) *reinterpret_cast<u32_unaligned*>(uo + 4) = w.y;
-        if constexpr (R >= 12) *reinterpret_cast<u32_unaligned*>(uo + 8) = w.z;
-        if constexpr (R >= 16) *reinterpret_cast<u32_unaligned*>(uo + 12) = w.w;
+        MEM::st_u32(uo, w.x);
+        if constexpr (R >= 8) MEM::st_u32(uo + 4, w.y);
+        if constexpr (R >= 12) MEM::st_u32(uo + 8, w.z);
+        if constexpr (R >= 16) MEM::st_u32(uo + 12, w.w);
         if constexpr ((R & 3) != 0) { // bytes R-4 .. R-1: the tail of the last full dword and the head of the partial one
             const unsigned lo = R / 4 == 1 ? w.x : (R / 4 == 2 ? w.y : w.z), hi = R / 4 == 1 ? w.y : (R / 4 == 2 ? w.z : w.w);
-            *reinterpret_cast<u32_unaligned*>(uo + R - 4) = __builtin_amdgcn_alignbyte(hi, lo, R & 3);
+            MEM::st_u32(uo + R - 4, __builtin_amdgcn_alignbyte(hi, lo, R & 3));
         }
     }
 }
 
-// One row: old int8 row (as loaded) and a = x V -> new int8 row (bytes past R zero).  Every lane of the wave must be
+// One row: old int8 row (w16_row_dwords) and a = x V -> new int8 row (bytes past R zero).  Every lane of the wave must be
 // active (the table operands are DPP broadcasts out of other lanes' registers).
 template <int R>
-__device__ __forceinline__ uint4 w16_row(const float (&a16)[16], const uint4 wload, const float (&tabv)[17], const GsParams& gp)
+__device__ __forceinline__ uint4 w16_row(const float (&a16)[16], const uint4 wo, const float (&tabv)[17], const GsParams& gp)
 {
-    const uint4 wo = w16_align_row<R>(wload);
     float a[R], u0[R], u[R], T[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
@@ -203,24 +223,17 @@ __device__ __forceinline__ uint4 w16_row_first(const float (&a16)[16], const flo
     return make_uint4(o[0], o[1], o[2], o[3]);
 }
 
-template <int MODE>
-__global__ __launch_bounds__(64 * LRF_BCDW16_WAVES) void k_bcd_w16(const float* __restrict__ X, const PlaneDesc* __restrict__ planes,
-                                                                  const BlockDesc* __restrict__ blocks, const float* __restrict__ Vf,
-                                                                  const float* __restrict__ Wf, const float* __restrict__ Bf, int8_t* __restrict__ U,
-                                                                  float* __restrict__ Ppart, float* __restrict__ Qpart, GsParams gp,
-                                                                  int nblocks)
+// One (matrix, 384-row block) on one wave.  Xs: the wave's LRF_BCDW16_WAVE_LDS bytes of LDS (X tile, then the int8 u tile).
+// MEM (lrf_device.h): MemLaunch for the launch-per-iteration kernel below, MemSc1 inside the persistent kernel (lrf_bcdp_kernel.hip),
+// where the V and b tables, the old int8 rows and the partial tables are handed from wave to wave within the launch.
+template <int MODE, class MEM>
+__device__ __forceinline__ void w16_block(const float* __restrict__ X, const PlaneDesc& pd, const BlockDesc& bd, const float* __restrict__ Vf,
+                                          const float* __restrict__ Wf, const float* __restrict__ Bf, int8_t* __restrict__ U,
+                                          float* __restrict__ Ppart, float* __restrict__ Qpart, const GsParams& gp, float* Xs, const int lane)
 {
-    extern __shared__ __attribute__((aligned(16))) float bcdw16_lds[]; // LRF_BCDW16_LDS bytes, per wave: X tile, then int8 u
-
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int blk = blockIdx.x * LRF_BCDW16_WAVES + wave;
-    if (blk >= nblocks) return; // the waves of a workgroup never synchronise with each other
-    float* Xs = reinterpret_cast<float*>(reinterpret_cast<char*>(bcdw16_lds) + wave * LRF_BCDW16_WAVE_LDS);
     int8_t* us8 = reinterpret_cast<int8_t*>(Xs + 64 * 64);
-    const BlockDesc bd = blocks[blk];
-    const PlaneDesc pd = planes[bd.plane];
     const int R = pd.R;
-    const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
+    const int li = lane & 15, lq = lane >> 4;
     const float* Xp = X + pd.x_off + (long)bd.row0 * 64;
     const float* Vp = Vf + (long)bd.plane * 64 * LRF_RP;
     const float* gt = Bf + (long)bd.plane * LRF_GT_STRIDE;
@@ -233,20 +246,23 @@ __global__ __launch_bounds__(64 * LRF_BCDW16_WAVES) void k_bcd_w16(const float* 
     float va[16], wa[MODE == 1 ? 16 : 1];
 #pragma unroll
     for (int s = 0; s < 16; s++) {
-        va[s] = Vp[(4 * s + lq) * LRF_RP + li];
+        va[s] = MEM::ld(Vp + (4 * s + lq) * LRF_RP + li);
         if (MODE == 1) wa[s] = Wf[(long)bd.plane * 64 * LRF_RP + (4 * s + lq) * LRF_RP + li];
     }
     // the symmetric b table of the exact Gauss-Seidel: tabv[j], lane l = b[j][l & 15] (diagonal: den); [16]: 1 / den
     float tabv[17];
 #pragma unroll
     for (int j = 0; j < 16; j++)
-        tabv[j] = (j < R && li < R) ? ((j == li) ? gt[li * LRF_GT_LD + LRF_GT_DEN] : gt[li * LRF_GT_LD + (j < li ? j : j - 1)]) : 0.f;
-    tabv[16] = (li < R) ? gt[li * LRF_GT_LD + LRF_GT_RDEN] : 0.f;
+        tabv[j] = (j < R && li < R) ? ((j == li) ? MEM::ld(gt + li * LRF_GT_LD + LRF_GT_DEN) : MEM::ld(gt + li * LRF_GT_LD + (j < li ? j : j - 1))) : 0.f;
+    tabv[16] = (li < R) ? MEM::ld(gt + li * LRF_GT_LD + LRF_GT_RDEN) : 0.f;
 
     // prefetch registers: xq[T][q] = X[r0 + 16T + 4q + lq][4li .. +3] (each load instruction: four whole rows, 1 KB);
     // upre = the old int8 row of this lane (w16_load_row).  Rows past the end of the block are clamped to its last row.
     f32x4 xq[4][4];
-    uint4 upre = make_uint4(0u, 0u, 0u, 0u);
+    W16RawRow upre;
+#pragma unroll
+    for (int d = 0; d < 5; d++) upre.d[d] = 0u;
+    upre.sh = 0u;
     auto issue_x = [&](int t, int T0, int T1) {
         const int r0 = t * 64;
 #pragma unroll
@@ -265,14 +281,13 @@ __global__ __launch_bounds__(64 * LRF_BCDW16_WAVES) void k_bcd_w16(const float* 
         row = row < nrows ? row : nrows - 1;
         const int8_t* up = Ub + (long)row * R;
         switch (R) {
-#define LRF_CASE(r) case r: upre = w16_load_row<r>(up); break;
+#define LRF_CASE(r) case r: w16_load_row<r, MEM>(up, upre); break;
             LRF_CASE(1) LRF_CASE(2) LRF_CASE(3) LRF_CASE(4) LRF_CASE(5) LRF_CASE(6) LRF_CASE(7) LRF_CASE(8)
             LRF_CASE(9) LRF_CASE(10) LRF_CASE(11) LRF_CASE(12) LRF_CASE(13) LRF_CASE(14) LRF_CASE(15)
 #undef LRF_CASE
-        default: upre = w16_load_row<16>(up); break;
+        default: w16_load_row<16, MEM>(up, upre); break;
         }
     };
-
     // B operand of a^T: X[16T + li][4s + lq] lives at byte (16T + li) * 256 + ((16 s) ^ (16 li)) + 4 lq of the tile
     const char* xrow_b = reinterpret_cast<const char*>(Xs) + li * 256 + 4 * lq;
     const int g16 = 16 * li;
@@ -300,7 +315,8 @@ __global__ __launch_bounds__(64 * LRF_BCDW16_WAVES) void k_bcd_w16(const float* 
                 const int m = 16 * T + 4 * q + lq;
                 *reinterpret_cast<f32x4*>(&Xs[m * 64 + 4 * (li ^ (4 * q + lq))]) = xq[T][q];
             }
-        uint4 w = upre;
+        const W16RawRow wraw = upre;
+        uint4 w = make_uint4(0u, 0u, 0u, 0u);
         const int tn = t + 1;
         const bool more = tn < nsub;
         if (more) {
@@ -343,11 +359,11 @@ __global__ __launch_bounds__(64 * LRF_BCDW16_WAVES) void k_bcd_w16(const float* 
         __builtin_amdgcn_sched_barrier(0);
         // ---- 3. Gauss-Seidel in registers: w = old int8 row in (MODE 0, exact-integer form), new int8 row out
         switch (R) {
-#define LRF_CASE(r) case r: if constexpr (MODE == 1) w = w16_row_first<r>(a, uf, tabv, gp); else w = w16_row<r>(a, w, tabv, gp); break;
+#define LRF_CASE(r) case r: if constexpr (MODE == 1) w = w16_row_first<r>(a, uf, tabv, gp); else w = w16_row<r>(a, w16_row_dwords<r, MEM>(wraw), tabv, gp); break;
             LRF_CASE(1) LRF_CASE(2) LRF_CASE(3) LRF_CASE(4) LRF_CASE(5) LRF_CASE(6) LRF_CASE(7) LRF_CASE(8)
             LRF_CASE(9) LRF_CASE(10) LRF_CASE(11) LRF_CASE(12) LRF_CASE(13) LRF_CASE(14) LRF_CASE(15)
 #undef LRF_CASE
-        default: if constexpr (MODE == 1) w = w16_row_first<16>(a, uf, tabv, gp); else w = w16_row<16>(a, w, tabv, gp); break;
+        default: if constexpr (MODE == 1) w = w16_row_first<16>(a, uf, tabv, gp); else w = w16_row<16>(a, w16_row_dwords<16, MEM>(wraw), tabv, gp); break;
         }
         const int row = r0 + lane;
         if (row >= nrows) w = make_uint4(0u, 0u, 0u, 0u);
@@ -358,11 +374,11 @@ __global__ __launch_bounds__(64 * LRF_BCDW16_WAVES) void k_bcd_w16(const float* 
         if (row < nrows) {
             int8_t* uo = Ub + (long)row * R;
             switch (R) {
-#define LRF_CASE(r) case r: w16_store_row<r>(uo, w); break;
+#define LRF_CASE(r) case r: w16_store_row<r, MEM>(uo, w); break;
                 LRF_CASE(1) LRF_CASE(2) LRF_CASE(3) LRF_CASE(4) LRF_CASE(5) LRF_CASE(6) LRF_CASE(7) LRF_CASE(8)
                 LRF_CASE(9) LRF_CASE(10) LRF_CASE(11) LRF_CASE(12) LRF_CASE(13) LRF_CASE(14) LRF_CASE(15)
 #undef LRF_CASE
-            default: w16_store_row<16>(uo, w); break;
+            default: w16_store_row<16, MEM>(uo, w); break;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -396,9 +412,29 @@ __global__ __launch_bounds__(64 * LRF_BCDW16_WAVES) void k_bcd_w16(const float* 
 #pragma unroll
     for (int c = 0; c < 4; c++)
 #pragma unroll
-        for (int reg = 0; reg < 4; reg++) Pp[(4 * (4 * lq + reg) + c) * LRF_RP + li] = accP[c][reg];
+        for (int reg = 0; reg < 4; reg++) MEM::st(Pp + (4 * (4 * lq + reg) + c) * LRF_RP + li, accP[c][reg]);
     // b' partial: D[i = 4*lq + reg][j = li], exact integers
     float* Qp = Qpart + slot * LRF_RP * LRF_RP;
 #pragma unroll
-    for (int reg = 0; reg < 4; reg++) Qp[(4 * lq + reg) * LRF_RP + li] = accQ[reg];
+    for (int reg = 0; reg < 4; reg++) MEM::st(Qp + (4 * lq + reg) * LRF_RP + li, accQ[reg]);
+}
+
+#ifndef LRF_W16_WAVES_PER_EU_MODE1
+#define LRF_W16_WAVES_PER_EU_MODE1 1
+#endif
+template <int MODE>
+__global__ __launch_bounds__(64 * LRF_BCDW16_WAVES) __attribute__((amdgpu_waves_per_eu(MODE == 1 ? LRF_W16_WAVES_PER_EU_MODE1 : 2, 2))) void k_bcd_w16(const float* __restrict__ X, const PlaneDesc* __restrict__ planes,
+                                                                  const BlockDesc* __restrict__ blocks, const float* __restrict__ Vf,
+                                                                  const float* __restrict__ Wf, const float* __restrict__ Bf, int8_t* __restrict__ U,
+                                                                  float* __restrict__ Ppart, float* __restrict__ Qpart, GsParams gp,
+                                                                  int nblocks)
+{
+    extern __shared__ __attribute__((aligned(16))) float bcdw16_lds[]; // LRF_BCDW16_LDS bytes, per wave: X tile, then int8 u
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int blk = blockIdx.x * LRF_BCDW16_WAVES + wave;
+    if (blk >= nblocks) return; // the waves of a workgroup never synchronise with each other
+    float* Xs = reinterpret_cast<float*>(reinterpret_cast<char*>(bcdw16_lds) + wave * LRF_BCDW16_WAVE_LDS);
+    const BlockDesc bd = blocks[blk];
+    const PlaneDesc pd = planes[bd.plane];
+    w16_block<MODE, MemLaunch>(X, pd, bd, Vf, Wf, Bf, U, Ppart, Qpart, gp, Xs, (int)(threadIdx.x & 63));
 }

@@ -138,24 +138,18 @@ __device__ __forceinline__ void w32_tiles_to_rows(const f32x4& a0, const f32x4& 
 }
 
 // NP: pairs of rank columns in use (ceil(R / 2), 9..16); an odd R solves one padding column whose table row, a and result are zero
-template <int NP>
-__global__ __launch_bounds__(64 * LRF_BCDW32_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void k_bcd_w32(const float* __restrict__ X, const PlaneDesc* __restrict__ planes, const BlockDesc* __restrict__ blocks,
-               const float* __restrict__ Vf, const float* __restrict__ Bf, int8_t* __restrict__ U, float* __restrict__ Ppart,
-               float* __restrict__ Qpart, GsParams gp, int nblocks)
+// One (matrix, 384-row block) on one wave.  Xs: the wave's LRF_BCDW32_WAVE_LDS(NP) bytes of LDS (X tile, int8 u tile, int16 table).
+// MEM (lrf_device.h): MemLaunch for the launch-per-iteration kernel below, MemSc1 inside the persistent kernel (lrf_bcdp_kernel.hip).
+// blk_id: only the diagnostic stamps use it.
+template <int NP, class MEM>
+__device__ __forceinline__ void w32_block(const float* __restrict__ X, const PlaneDesc& pd, const BlockDesc& bd, const float* __restrict__ Vf,
+                                          const float* __restrict__ Bf, int8_t* __restrict__ U, float* __restrict__ Ppart,
+                                          float* __restrict__ Qpart, const GsParams& gp, float* Xs, const int lane, const int blk_id)
 {
-    extern __shared__ __attribute__((aligned(16))) float bcdw32_lds[]; // LRF_BCDW32_LDS bytes, per wave: X tile, int8 u, table
-
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int blk = blockIdx.x * LRF_BCDW32_WAVES + wave;
-    if (blk >= nblocks) return; // the waves of a workgroup never synchronise with each other
-    float* Xs = reinterpret_cast<float*>(reinterpret_cast<char*>(bcdw32_lds) + wave * LRF_BCDW32_WAVE_LDS(NP));
     int8_t* us8 = reinterpret_cast<int8_t*>(Xs + 64 * 64);
     int* tab16 = reinterpret_cast<int*>(us8 + 64 * 32);
-    const BlockDesc bd = blocks[blk];
-    const PlaneDesc pd = planes[bd.plane];
     const int R = pd.R; // 2 NP - 1 or 2 NP
-    const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
+    const int li = lane & 15, lq = lane >> 4;
     const float* Xp = X + pd.x_off + (long)bd.row0 * 64;
     const float* Vp = Vf + (long)bd.plane * 64 * LRF_RPB;
     const float* gt = Bf + (long)bd.plane * LRF_GTB_STRIDE;
@@ -174,30 +168,34 @@ void k_bcd_w32(const float* __restrict__ X, const PlaneDesc* __restrict__ planes
 #pragma unroll
     for (int t = 0; t < (T1V ? 1 : 2); t++)
 #pragma unroll
-        for (int s = 0; s < 16; s++) va[t][s] = Vp[(4 * s + lq) * LRF_RPB + 16 * t + li];
+        for (int s = 0; s < 16; s++) va[t][s] = MEM::ld(Vp + (4 * s + lq) * LRF_RPB + 16 * t + li);
 #pragma unroll
     for (int c = 0; c < NC; c++)
 #pragma unroll
-        for (int g4 = 0; g4 < 4; g4++) vb[c][g4] = T1V ? Vp[(16 * g4 + li) * LRF_RPB + 16 + c] : 0.f;
+        for (int g4 = 0; g4 < 4; g4++) vb[c][g4] = T1V ? MEM::ld(Vp + (16 * g4 + li) * LRF_RPB + 16 + c) : 0.f;
     // the symmetric int16 table, diagonal zero: dword (r, p) = (b[r][2p], b[r][2p+1]); lane l builds dwords l, l + 64, ...
 #pragma unroll
     for (int e = 0; e < 8; e++) {
         const int idx = e * 64 + lane, r = idx >> 4, c0 = 2 * (idx & 15), c1 = c0 + 1;
         float b0 = 0.f, b1 = 0.f;
-        if (r < R && c0 < R && c0 != r) b0 = gt[c0 * LRF_GTB_LD + (r < c0 ? r : r - 1)]; // b[r][c0]: gt row c lists b[j][c], j != c
-        if (r < R && c1 < R && c1 != r) b1 = gt[c1 * LRF_GTB_LD + (r < c1 ? r : r - 1)];
+        if (r < R && c0 < R && c0 != r) b0 = MEM::ld(gt + c0 * LRF_GTB_LD + (r < c0 ? r : r - 1)); // b[r][c0]: gt row c lists b[j][c], j != c
+        if (r < R && c1 < R && c1 != r) b1 = MEM::ld(gt + c1 * LRF_GTB_LD + (r < c1 ? r : r - 1));
         if (r < 2 * NP) tab16[idx] = (int)(((unsigned)(int)b0 & 0xffffu) | ((unsigned)(int)b1 << 16));
     }
     // 1 / den and den of the columns li and 16 + li (padding columns: 1)
-    const float dn0 = (li < R) ? gt[li * LRF_GTB_LD + LRF_GTB_DEN] : 1.f;
-    const float dn1 = (16 + li < R) ? gt[(16 + li) * LRF_GTB_LD + LRF_GTB_DEN] : 1.f;
+    const float dn0 = (li < R) ? MEM::ld(gt + li * LRF_GTB_LD + LRF_GTB_DEN) : 1.f;
+    const float dn1 = (16 + li < R) ? MEM::ld(gt + (16 + li) * LRF_GTB_LD + LRF_GTB_DEN) : 1.f;
     const float rd0 = 1.0f / dn0, rd1 = 1.0f / dn1;
     const int* tabl = tab16 + li;
 
     // prefetch registers: xq[T][q] = X[r0 + 16T + 4q + lq][4li .. +3] (each load instruction: four whole rows, 1 KB);
-    // upre = the old int8 row of this lane: dword d from byte offset min(4d, R - 4).  Rows past the block's end: its last row.
+    // upre = the old int8 row of this lane.  MemLaunch: dword d from byte offset min(4d, R - 4) (unaligned loads); MemSc1: the
+    // nine ALIGNED dwords that cover a row of up to 32 bytes at any offset, as compiler-tracked sc1 loads (w16_load_row's
+    // scheme), funnel-shifted when the row is used.  Rows past the block's end: its last row.
     f32x4 xq[4][4];
-    unsigned upre[8];
+    constexpr int NRAW = MEM::kSc1 ? 9 : 8;
+    unsigned upre[NRAW];
+    unsigned ush = 0u; // MemSc1: the byte offset of the prefetched row inside its first aligned dword
     // `live` false (no next sub-tile): the registers are cleared instead — a load under a bare `if` would keep their old
     // values alive across the whole body (76 spilled registers at NP = 16)
     auto issue_x = [&](int t, int T0, int T1, bool live) {
@@ -213,15 +211,27 @@ void k_bcd_w32(const float* __restrict__ X, const PlaneDesc* __restrict__ planes
             }
         }
     };
-    auto load_u = [&](int t, unsigned (&w)[8], bool live) {
+    auto load_u = [&](int t, unsigned (&w)[NRAW], unsigned& sh, bool live) {
         int row = t * 64 + lane;
         row = row < nrows ? row : nrows - 1;
         const int8_t* up = Ub + (long)row * R;
+        if constexpr (MEM::kSc1) {
+            const uintptr_t a0 = reinterpret_cast<uintptr_t>(up);
+            const uintptr_t base = a0 & ~(uintptr_t)3, last = (a0 + R - 1) & ~(uintptr_t)3;
+            sh = (unsigned)(a0 & 3);
 #pragma unroll
-        for (int d = 0; d < 8; d++) {
-            const int off = 4 * d < R - 4 ? 4 * d : R - 4; // wave-uniform
-            if (live) w[d] = *reinterpret_cast<const u32_unaligned*>(up + off);
-            else w[d] = 0u;
+            for (int d = 0; d < NRAW; d++) {
+                const uintptr_t a = base + 4 * d <= last ? base + 4 * d : last;
+                if (live) w[d] = MEM::ld_u32(reinterpret_cast<const unsigned*>(a));
+                else w[d] = 0u;
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < 8; d++) {
+                const int off = 4 * d < R - 4 ? 4 * d : R - 4; // wave-uniform
+                if (live) w[d] = *reinterpret_cast<const u32_unaligned*>(up + off);
+                else w[d] = 0u;
+            }
         }
     };
     // the partial dword (index R / 4 when R is not a multiple of 4) was loaded from offset R - 4: its row bytes sit in its
@@ -255,7 +265,7 @@ void k_bcd_w32(const float* __restrict__ X, const PlaneDesc* __restrict__ planes
 #endif
     W32STAMP(t_begin);
     issue_x(0, 0, 4, true);
-    load_u(0, upre, true);
+    load_u(0, upre, ush, true);
     for (int t = 0; t < nsub; t++) {
         const int r0 = t * 64;
         W32STAMP(s0);
@@ -274,20 +284,22 @@ void k_bcd_w32(const float* __restrict__ X, const PlaneDesc* __restrict__ planes
                 *reinterpret_cast<f32x4*>(&Xs[m * 64 + 4 * (li ^ (4 * q + lq))]) = xq[T][q];
             }
         int W[16];
-        auto row_to_pairs = [&](const unsigned (&w8)[8]) {
+        auto row_to_pairs = [&](const unsigned (&w8)[NRAW], const unsigned sh) {
 #pragma unroll
             for (int d = 0; d < 8; d++) {
-                const unsigned w = (d == part_dw) ? (w8[d] >> part_sh) : w8[d];
+                unsigned w;
+                if constexpr (MEM::kSc1) w = __builtin_amdgcn_alignbyte(w8[d + 1 < NRAW ? d + 1 : d], w8[d], sh);
+                else w = (d == part_dw) ? (w8[d] >> part_sh) : w8[d];
                 w32_bytes_to_pairs(w, W[2 * d], W[2 * d + 1]);
             }
 #pragma unroll
             for (int p = NP; p < 16; p++) W[p < 16 ? p : 15] = 0;
         };
-        row_to_pairs(upre);
+        row_to_pairs(upre, ush);
         const int tn = t + 1;
         const bool more = tn < nsub;
         issue_x(tn, 0, 1, more);
-        load_u(tn, upre, more);
+        load_u(tn, upre, ush, more);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -309,8 +321,8 @@ void k_bcd_w32(const float* __restrict__ X, const PlaneDesc* __restrict__ planes
             float a1[NC];
 #pragma unroll
             for (int c = 0; c < NC; c++) a1[c] = 0.f;
-#pragma unroll
-            for (int h = 0; h < 4; h++) { // the operand reads in four quarters of 16 registers
+            static_for<4>([&](auto hc) { // the operand reads in four quarters of 16 registers
+                constexpr int h = decltype(hc)::value;
                 float bx[4][4];
 #pragma unroll
                 for (int s = 0; s < 4; s++)
@@ -344,7 +356,7 @@ void k_bcd_w32(const float* __restrict__ X, const PlaneDesc* __restrict__ planes
                          ...);
                     }(std::make_integer_sequence<int, 16>{});
                 }
-            }
+            });
 #ifdef LRF_W32_STAMPS
             asm volatile("" ::"v"(acc[3][NT - 1][3]), "v"(acc[0][0][0]));
             s3 = stamp_now();
@@ -369,9 +381,9 @@ void k_bcd_w32(const float* __restrict__ X, const PlaneDesc* __restrict__ planes
         if (__any(w32_solve<NP, true>(a, W, tabl, rd0, rd1, dn0, dn1, gp, std::make_integer_sequence<int, 2 * NP>{}))) {
             // rare: repeat with the reference's IEEE division; the old row is read again (its stores come after the solve)
             // rather than kept in sixteen registers across the solve
-            unsigned wr[8];
-            load_u(t, wr, true);
-            row_to_pairs(wr);
+            unsigned wr[NRAW], wsh = 0u;
+            load_u(t, wr, wsh, true);
+            row_to_pairs(wr, wsh);
             w32_solve<NP, false>(a, W, tabl, rd0, rd1, dn0, dn1, gp, std::make_integer_sequence<int, 2 * NP>{});
         }
         // int16 pairs -> bytes: dword d = columns 4d .. 4d+3 (rows past the block's end: zero)
@@ -395,10 +407,10 @@ void k_bcd_w32(const float* __restrict__ X, const PlaneDesc* __restrict__ planes
         if (row < nrows) {
             int8_t* uo = Ub + (long)row * R;
 #pragma unroll
-            for (int d = 0; d < 4; d++) *reinterpret_cast<u32_unaligned*>(uo + 4 * d) = o[d]; // R >= 16
+            for (int d = 0; d < 4; d++) MEM::st_u32(uo + 4 * d, o[d]); // R >= 16
 #pragma unroll
             for (int d = 4; d < 8; d++)
-                if (4 * d + 4 <= R) *reinterpret_cast<u32_unaligned*>(uo + 4 * d) = o[d]; // wave-uniform
+                if (4 * d + 4 <= R) MEM::st_u32(uo + 4 * d, o[d]); // wave-uniform
             if (R & 3) { // bytes R-4 .. R-1: the tail of the last full dword and the head of the partial one
                 const int dl = R >> 2; // 4 .. 7
                 unsigned lo_w = o[3], hi_w = o[4];
@@ -408,7 +420,7 @@ void k_bcd_w32(const float* __restrict__ X, const PlaneDesc* __restrict__ planes
                         lo_w = o[d - 1];
                         hi_w = o[d];
                     }
-                *reinterpret_cast<u32_unaligned*>(uo + R - 4) = __builtin_amdgcn_alignbyte(hi_w, lo_w, (unsigned)(R & 3));
+                MEM::st_u32(uo + R - 4, __builtin_amdgcn_alignbyte(hi_w, lo_w, (unsigned)(R & 3)));
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -463,9 +475,9 @@ void k_bcd_w32(const float* __restrict__ X, const PlaneDesc* __restrict__ planes
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 #ifdef LRF_W32_STAMPS
-    if (lane == 0 && blk < 16384) {
+    if (lane == 0 && blk_id < 16384) {
         W32STAMP(t_end);
-        unsigned long long* o = g_stamps + 8 * blk;
+        unsigned long long* o = g_stamps + 8 * blk_id;
         o[0] = t_end - t_begin; o[1] = c_w1; o[2] = c_w2; o[3] = c_w3; o[4] = c_w4; o[5] = c_w5; o[6] = c_w6; o[7] = c_w7;
     }
 #endif
@@ -477,7 +489,7 @@ void k_bcd_w32(const float* __restrict__ X, const PlaneDesc* __restrict__ planes
 #pragma unroll
         for (int tt = 0; tt < 2; tt++)
 #pragma unroll
-            for (int reg = 0; reg < 4; reg++) Pp[(4 * (4 * lq + reg) + c) * LRF_RPB + 16 * tt + li] = accP[c][tt][reg];
+            for (int reg = 0; reg < 4; reg++) MEM::st(Pp + (4 * (4 * lq + reg) + c) * LRF_RPB + 16 * tt + li, accP[c][tt][reg]);
     // b' partial: D[i = 4*lq + reg][j = li] of tile (ti, tj), exact integers (below 384 mx^2)
     float* Qp = Qpart + slot * LRF_RPB * LRF_RPB;
 #pragma unroll
@@ -485,7 +497,24 @@ void k_bcd_w32(const float* __restrict__ X, const PlaneDesc* __restrict__ planes
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
-            for (int reg = 0; reg < 4; reg++) Qp[(16 * i + 4 * lq + reg) * LRF_RPB + 16 * j + li] = (float)accQ[i][j][reg];
+            for (int reg = 0; reg < 4; reg++) MEM::st(Qp + (16 * i + 4 * lq + reg) * LRF_RPB + 16 * j + li, (float)accQ[i][j][reg]);
+    (void)blk_id;
+}
+
+template <int NP>
+__global__ __launch_bounds__(64 * LRF_BCDW32_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_bcd_w32(const float* __restrict__ X, const PlaneDesc* __restrict__ planes, const BlockDesc* __restrict__ blocks,
+               const float* __restrict__ Vf, const float* __restrict__ Bf, int8_t* __restrict__ U, float* __restrict__ Ppart,
+               float* __restrict__ Qpart, GsParams gp, int nblocks)
+{
+    extern __shared__ __attribute__((aligned(16))) float bcdw32_lds[]; // LRF_BCDW32_LDS bytes, per wave: X tile, int8 u, table
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int blk = blockIdx.x * LRF_BCDW32_WAVES + wave;
+    if (blk >= nblocks) return; // the waves of a workgroup never synchronise with each other
+    float* Xs = reinterpret_cast<float*>(reinterpret_cast<char*>(bcdw32_lds) + wave * LRF_BCDW32_WAVE_LDS(NP));
+    const BlockDesc bd = blocks[blk];
+    const PlaneDesc pd = planes[bd.plane];
+    w32_block<NP, MemLaunch>(X, pd, bd, Vf, Bf, U, Ppart, Qpart, gp, Xs, (int)(threadIdx.x & 63), blk);
 }
 
 // =====================================================================================================================

@@ -19,8 +19,6 @@
 // Two waves per SIMD (18 KB LDS per wave): while one wave is in its VALU phases the other feeds the MFMA pipe; the
 // next sub-tile's global loads are in flight during steps 2 to 4.
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned __attribute__((aligned(1))) u32_unaligned;
 
 // diagnostic stamps of this kernel: -DLRF_STAMPS -DLRF_W_STAMPS (tools/dev_stamps_w.py)
 #if defined(LRF_STAMPS) && defined(LRF_W_STAMPS)

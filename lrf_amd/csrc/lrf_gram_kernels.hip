@@ -19,22 +19,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "lrf_device.h"
+
 #include "lrf_internal.h"
 
-typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 #define LRF_GRAM_BITS 35
-#define LRF_GRAM_ROWS 1536            // rows per chunk: 24 blocks of 64
-#define LRF_GRAM_PAIRS 10             // upper-triangle pairs of the four 16-column tiles
-#define LRF_GRAM_SLOT (LRF_GRAM_PAIRS * 256) // 128-bit sums per partial, [pair][reg][lane]
-#define LRF_GRAM_EXP_FROM_DATA (-100000)
-
-struct GramChunk {
-    int plane; // index into the PlaneDesc table
-    int row0;  // first row of the chunk
-    int slot;  // partial slot (pd.gch0 + chunk number)
-    int nrows;
-};
 
 // E with max|x| < 2^E per matrix, from the largest magnitude's bit pattern (oracle: lrf_oracle_gram_exponent)
 __global__ __launch_bounds__(256) void k_gram_exponent(const float* __restrict__ X, const PlaneDesc* __restrict__ planes,

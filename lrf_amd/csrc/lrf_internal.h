@@ -6,6 +6,24 @@
 #define LRF_RP 16    // rank padded to one 16-wide MFMA tile (== LRF_MAX_RANK)
 #define LRF_KC 384   // rows per X^T U reduction block (the reference's MKL K-blocking)
 
+// Table layout ("gt") of b = v.mT @ v at rank pitch 16, LRF_GT_LD floats per column r, so that one column's operands are
+// contiguous:  gt[r*LD + n], n < R-1 : b[j_n][r] for the j != r in increasing order (the `bb` vector of qmf.py:114);
+//   gt[r*LD + 16] = 1/den[r],  gt[r*LD + 17] = den[r] = (b[r][r] + 0) + eps
+#define LRF_GT_LD 20
+#define LRF_GT_RDEN 16
+#define LRF_GT_DEN 17
+#define LRF_GT_STRIDE (LRF_RP * LRF_GT_LD)
+// ranks above 16: rank pitch 64 (lrf_bigrank_kernels.hip)
+#define LRF_RPB 64                      // padded rank
+#define LRF_GTB_LD 68                   // gt table pitch: <= 63 `bb` entries, [64] = 1/den (unused here), [65] = den
+#define LRF_GTB_DEN 65
+#define LRF_GTB_STRIDE (LRF_RPB * LRF_GTB_LD)
+// the exact Gram pass (lrf_gram_kernels.hip)
+#define LRF_GRAM_ROWS 1536            // rows per chunk: 24 blocks of 64
+#define LRF_GRAM_PAIRS 10             // upper-triangle pairs of the four 16-column tiles
+#define LRF_GRAM_SLOT (LRF_GRAM_PAIRS * 256) // 128-bit sums per partial, [pair][reg][lane]
+#define LRF_GRAM_EXP_FROM_DATA (-100000)
+
 // geometry of one colour plane of an image (lrf/compression/qmf.py:230-242)
 struct PlaneGeom {
     int h, w;          // plane size (chroma: floor(H/2), floor(W/2))
@@ -43,5 +61,19 @@ struct BlockDesc {
     int row0;          // first row of the block
     int blk;           // block number inside the plane
     int pad;
+};
+struct GramChunk {
+    int plane; // index into the PlaneDesc table
+    int row0;  // first row of the chunk
+    int slot;  // partial slot (pd.gch0 + chunk number)
+    int nrows;
+};
+
+struct GsParams {
+    float lo, hi;      // clamp
+    float flimit;      // |q~| >= flimit: certainly outside [lo,hi] after rounding
+    float fthr;        // |q~ - rint(q~)| <= fthr: rint(q~) == rint(fl(num/den))
+    int exact_int;     // iterations >= 2 only: every term and partial sum of `uu @ bb` is an exact integer in fp32 for the
+                       // call's largest rank and bounds ((R-1) 64 mx^3 < 2^24), so the order of that sum is immaterial
 };
 #endif

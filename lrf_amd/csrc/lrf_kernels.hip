@@ -18,65 +18,11 @@
 
 #include "lrf_internal.h"
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef double f64x4 __attribute__((ext_vector_type(4)));
-typedef double d16 __attribute__((ext_vector_type(16)));
-
-#define LRF_EPS 1e-16f
-// Householder columns whose squared norm is at or below this are skipped (oracle: tridiagonalize): cascaded rounding noise of
-// rank-deficient Gram matrices lands in the denormal range, where t = 2 / |v|^2 overflows
-#define LRF_SIGMA_TINY 1e-280
-
-// Diagnostic build only (-DLRF_STAMPS, never shipped): per-phase cycle sums of k_bcd, wave 0 of each workgroup.
-#if defined(LRF_STAMPS) || defined(LRF_INIT_STAMPS) || defined(LRF_BLK_STAMPS) || defined(LRF_REG_STAMPS)
-__device__ unsigned long long g_stamps[8 * 16384];
-__device__ __forceinline__ unsigned long long stamp_now()
-{
-    unsigned long long t;
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    __builtin_amdgcn_sched_barrier(0);
-    return t;
-}
-#endif
-#ifdef LRF_STAMPS
-#define STAMP(var) unsigned long long var = stamp_now()
-#define STAMP_ADD(acc, a, b) acc += (b) - (a)
-__device__ unsigned long long g_gsp[4 * 16384];
-#ifndef LRF_GS_PROBE
-#define LRF_GS_PROBE 0
-#endif
-static constexpr int getenv_probe_dummy = LRF_GS_PROBE;
-#define GSP_ADD(slot, a, b)                                                                     \
-    if ((threadIdx.x & 63) == 0 && blockIdx.x < 16384) atomicAdd(&g_gsp[4 * blockIdx.x + (slot)], (b) - (a))
-#else
-#define STAMP(var)
-#define STAMP_ADD(acc, a, b)
-#define GSP_ADD(slot, a, b)
-#endif
+#include "lrf_device.h"
 
 // ------------------------------------------------------------------------------------------------
 // K1: uint8 RGB -> patch matrices (YCbCr, area down-sampled chroma, reflect pad, patchify)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int reflect_idx(int i, int n)
-{
-    if (i < 0) i = -i;
-    if (i >= n) i = 2 * (n - 1) - i;
-    return i;
-}
-
-// offset + einsum("ij,j...->i...") for one pixel: k-ordered fma chain from 0 (sgemm, K = 3), then offset + acc.
-// ycc from three already-loaded channel bytes
-__device__ __forceinline__ float ycc_of(float r, float g, float b, int c)
-{
-    const float T[3][3] = {{0.299f, 0.587f, 0.114f}, {-0.168736f, -0.331264f, 0.5f}, {0.5f, -0.418688f, -0.081312f}};
-    float acc = 0.f;
-    acc = fmaf(T[c][0], r, acc);
-    acc = fmaf(T[c][1], g, acc);
-    acc = fmaf(T[c][2], b, acc);
-    return (c ? 128.f : 0.f) + acc;
-}
-
 // One workgroup per (patch row, image): a luma patch row consumes 8 image rows, a chroma patch row 16 (+ 1) and yields the
 // patch row of BOTH chroma planes — the two planes have the same geometry and share every source byte, so the Cb and Cr
 // samples of a window come from one set of loads (separate workgroups per chroma plane read the image three times:
@@ -564,47 +510,6 @@ __global__ __launch_bounds__(256) void k_planes_strip(const uint8_t* __restrict_
 // One workgroup (4 waves) per matrix.  Mirrors oracle/lrf_oracle.c (lrf_oracle_gram_exact, tridiagonalize, sturm_count,
 // top_eigenvalues, twisted_vector, lrf_oracle_top_eig_f64, init_from_gram) operation for operation.
 // ------------------------------------------------------------------------------------------------
-// tree64 of the oracle: lane i ends with s[i] + s[i+off] for off = 32..1; lane 0 holds the result,
-// which is broadcast.  (Lanes >= off compute unused values.)
-// The partner fetches of the tree without the LDS crossbar: lane i needs lane i + off.
-//   off = 32: v_permlane32_swap (upper half of one register <-> lower half of the other)
-//   off = 16: v_permlane16_swap (odd 16-lane rows <-> even rows)
-//   off <= 8: DPP row_shl inside the 16-lane row
-// Only lanes < off need a correct partner, which is exactly what these give; lane 0 ends with the tree sum.
-__device__ __forceinline__ double partner_32(double v)
-{
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-    auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-    return __hiloint2double(b[1], a[1]); // second result: lanes 0-31 hold the former lanes 32-63
-}
-__device__ __forceinline__ double partner_16(double v)
-{
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-    auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-    return __hiloint2double(b[1], a[1]); // second result: even rows hold the former odd rows
-}
-template <int OFF>
-__device__ __forceinline__ double partner_row(double v)
-{
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x100 + OFF, 0xf, 0xf, true); // row_shl:OFF -> lane i reads lane i + OFF
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x100 + OFF, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double wave_tree64(double v)
-{
-    v = v + partner_32(v);
-    v = v + partner_16(v);
-    v = v + partner_row<8>(v);
-    v = v + partner_row<4>(v);
-    v = v + partner_row<2>(v);
-    v = v + partner_row<1>(v);
-    int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
-    return __hiloint2double(hi, lo);
-}
-
 // LDS carve of k_init; ZR = 8 or 16 eigenvectors' worth of scratch (chosen on the host from the largest rank
 // of the call, so that R <= 8 batches fit three workgroups per CU)
 template <int ZR>
@@ -619,8 +524,14 @@ struct InitLds {
     int flag[4];
 };
 
-template <int ZR>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_init(const ulonglong2* __restrict__ Gpart, const int* __restrict__ gexp,
+// NW waves per workgroup: 4 hold the matrix during the tridiagonalisation; with NW = 8 (ranks above 8: ZR = 16 / 64, where LDS
+// leaves a CU two workgroups or one and its SIMDs mostly idle) waves 4..7 wait at the barriers of that stage and then take
+// their share of what scales with the rank — sixteen eigenvalue searches and sixteen back-transformations per round instead of
+// eight (round 5: k_init<16> 197 -> see DESIGN.md, k_init<64> at rank 26: 298 ->).  Which wave computes a vector does not change a bit of it.
+// Waves per SIMD: 3 (three 4-wave workgroups per CU at ZR = 8) or 4 (two 8-wave workgroups at ZR = 16; the bound is a maximum too:
+// with 3 a second 8-wave workgroup does not fit and 512 chroma planes of rank 13 ran in two rounds, 362 us).
+template <int ZR, int NW = (ZR > 8 ? 8 : 4)>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8 ? 4 : 3, NW == 8 ? 4 : 3))) void k_init(const ulonglong2* __restrict__ Gpart, const int* __restrict__ gexp,
                                               int fixed_exp, const PlaneDesc* __restrict__ planes,
                                               const int8_t* __restrict__ sign, float* __restrict__ Vf,
                                               float* __restrict__ Wf, int debug_stop, int rp, int plane0 /* first plane of this launch's run */)
@@ -647,7 +558,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         long long hi[NE];
 #pragma unroll
         for (int m = 0; m < NE; m++) { lo[m] = 0; hi[m] = 0; }
-        for (int c = 0; c < pd.ngch; c++) {
+        for (int c = 0; c < (wave < 4 ? pd.ngch : 0); c++) {
             ulonglong2 v[NE];
 #pragma unroll
             for (int m = 0; m < NE; m++) v[m] = gp[(long)c * LRF_GRAM_SLOT + tid + 256 * m];
@@ -659,7 +570,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             }
         }
 #pragma unroll
-        for (int m = 0; m < NE; m++) {
+        for (int m = 0; m < (wave < 4 ? NE : 0); m++) {
             const int e = tid + 256 * m;
             const double g = i128_to_double_rne(lo[m], hi[m]) * back;
             int ti, tj;
@@ -678,8 +589,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     // the Gram matrix is dead from here on and its rows are reused for the Householder vectors v_k (read again by the
     // back-transformation).  Terms the oracle skips (j <= k) are fma(a, 0, c) = c here: v_k[j] = 0 there.
     d16 Ar; // a vector, not an array: row k is picked with a wave-uniform register index (s_set_gpr_idx), not 15 selects
+    const int wrow = wave & 3; // (waves 4..7 of an eight-wave workgroup hold nothing: they only keep the barriers of this stage)
 #pragma unroll
-    for (int jj = 0; jj < 16; jj++) Ar[jj] = G[(16 * wave + jj) * 64 + lane];
+    for (int jj = 0; jj < 16; jj++) Ar[jj] = G[(16 * wrow + jj) * 64 + lane];
     __syncthreads();
 #ifdef LRF_INIT_STAMPS
     unsigned long long acc_a = 0, acc_b = 0, acc_c = 0, acc_d = 0;
@@ -720,10 +632,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         if (L.flag[k & 1]) { // flag double-buffered like v: a wave that skips ahead must not overwrite what others still read
             double vj[16];
 #pragma unroll
-            for (int jj = 0; jj < 16; jj++) vj[jj] = vbuf[16 * wave + jj];
+            for (int jj = 0; jj < 16; jj++) vj[jj] = vbuf[16 * wrow + jj];
             double t = 0.0;
             if (wave == 0) t = 1.0 / L.scal[0]; // 2 / |v|^2: the division runs under the chains below
-            { // matvec partial chains: thread (row i, column group g), two chains of eight
+            if (wave < 4) { // matvec partial chains: thread (row i, column group g), two chains of eight
                 double ca = 0.0, cb = 0.0;
 #pragma unroll
                 for (int jj = 0; jj < 8; jj++) {
@@ -750,13 +662,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #endif
             { // rank-2 update A -= v w^T + w v^T: the two products are rounded, then added (commutative), so element (r, c) and
               // its mirror image get the same bits without choosing an order per element.  v and w are zero up to index k,
-              // which leaves the finished rows and columns as they are.
+              // which leaves the finished rows and columns as they are.  (Waves 4..7 would repeat waves 0..3's rows: skipped.)
                 const double vc = vbuf[lane], wc = wbuf[lane];
+                if (wave < 4) {
 #pragma unroll
-                for (int jj = 0; jj < 16; jj++) {
-                    const double wr = wbuf[16 * wave + jj];
-                    const double m1 = vj[jj] * wc, m2 = wr * vc;
-                    Ar[jj] = Ar[jj] - (m1 + m2);
+                    for (int jj = 0; jj < 16; jj++) {
+                        const double wr = wbuf[16 * wrow + jj];
+                        const double m1 = vj[jj] * wc, m2 = wr * vc;
+                        Ar[jj] = Ar[jj] - (m1 + m2);
+                    }
                 }
             }
 #ifdef LRF_INIT_STAMPS
@@ -777,7 +691,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     __syncthreads();
     { // d = diag, e[62] = A[63][62]
         const int i = lane;
-        if (wave == (i >> 4)) {
+        if (wave == (i >> 4)) { // (waves 0..3)
             double dv = Ar[0];
 #pragma unroll
             for (int jj = 1; jj < 16; jj++) dv = ((i & 15) == jj) ? Ar[jj] : dv;
@@ -819,7 +733,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     __syncthreads();
     {
         const int sc = L.flag[2];
-        // A wave runs two searches at once (eigenvalues r0 and r0 + 4, 64 shifts per pass each): at three workgroups per CU the
+        // A wave runs two searches at once (eigenvalues r0 and r0 + NW, 64 shifts per pass each): at three workgroups per CU the
         // stage is paced by the LDS reads of the table, and one read now serves both.  A minor that comes out as zero needs
         // the oracle's replacement rule: such passes (hardly ever) are redone by sturm_count_slow.
         auto sturm_count_slow = [&](double x) {
@@ -851,7 +765,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         };
         auto search = [&](int r0, auto two_tag) {
             constexpr bool TWO = decltype(two_tag)::value;
-            const int r1 = r0 + 4;
+            const int r1 = r0 + NW;
             const int kk0 = 63 - r0, kk1 = 63 - r1;
             double a0 = L.scal[2], b0 = L.scal[3], a1 = a0, b1 = b0;
             for (int pass = 0; pass < 10; pass++) {
@@ -903,8 +817,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 if constexpr (TWO) L.lam[r1] = ldexp(0.5 * (a1 + b1), sc);
             }
         };
-        for (int r0 = wave; r0 < Rc; r0 += 8) {
-            if (r0 + 4 < Rc) search(r0, std::true_type{}); // wave-uniform
+        for (int r0 = wave; r0 < Rc; r0 += 2 * NW) {
+            if (r0 + NW < Rc) search(r0, std::true_type{}); // wave-uniform
             else search(r0, std::false_type{});
         }
     }
@@ -1006,12 +920,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     // ---- back-transformation x <- H_0 ... H_61 x, sign, scaling, output: one wave per vector
     float* Vp = Vf + (long)pli * 64 * rp; // rp: padded rank (row pitch) of the V / W tables, a power of two
     float* Wp = Wf + (long)pli * 64 * rp;
-    for (int i = tid; i < 64 * rp; i += 256) {
+    for (int i = tid; i < 64 * rp; i += 64 * NW) {
         if ((i & (rp - 1)) >= Rc) { Vp[i] = 0.f; Wp[i] = 0.f; } // padding and the r >= min(M,N) columns
     }
-    for (int r0 = wave; r0 < Rc; r0 += 8) { // two vectors per wave and pass (r0 and r0 + 4): their reduction trees interleave
+    for (int r0 = wave; r0 < Rc; r0 += 2 * NW) { // two vectors per wave and pass (r0 and r0 + NW): their reduction trees interleave
         const int i = lane;
-        const int r1 = r0 + 4;
+        const int r1 = r0 + NW;
         const bool two = r1 < Rc; // wave-uniform
         double xa = L.Z[r0 * 64 + i], xb = two ? L.Z[r1 * 64 + i] : 0.0;
         for (int k = 61; k >= 0; k--) {
@@ -1052,271 +966,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 // Division: the reference computes round(fl(num / den)).  q~ = num * rden is within 3 ulp of that
 // quotient, so unless q~ sits within `1/2 - fthr` of a rounding tie its nearest integer is the same;
 // only then (or never, beyond the clamp range) is the IEEE division evaluated.  Results are identical.
-// ------------------------------------------------------------------------------------------------
-// Table layout ("gt"), LRF_GT_LD floats per column r, so that one column's operands are contiguous:
-//   gt[r*LD + n], n < R-1 : b[j_n][r] for the j != r in increasing order (the `bb` vector of qmf.py:114)
-//   gt[r*LD + 16] = 1/den[r],  gt[r*LD + 17] = den[r] = (b[r][r] + 0) + eps
-#define LRF_GT_LD 20
-#define LRF_GT_RDEN 16
-#define LRF_GT_DEN 17
-#define LRF_GT_STRIDE (LRF_RP * LRF_GT_LD)
-
-struct GsParams {
-    float lo, hi;      // clamp
-    float flimit;      // |q~| >= flimit: certainly outside [lo,hi] after rounding
-    float fthr;        // |q~ - rint(q~)| <= fthr: rint(q~) == rint(fl(num/den))
-    int exact_int;     // iterations >= 2 only: every term and partial sum of `uu @ bb` is an exact integer in fp32 for the
-                       // call's largest rank and bounds ((R-1) 64 mx^3 < 2^24), so the order of that sum is immaterial
-};
-
-// acc += b * u with a wave-uniform b (SGPR operand).  Spelled in assembly so that the SLP vectoriser does not pair the
-// independent accumulators of the exact Gauss-Seidel into v_pk_fma_f32 (which costs thousands of register moves there).
-__device__ __forceinline__ void fmac_su(float& acc, float b_uniform, float u)
-{
-    asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "s"(b_uniform), "v"(u));
-}
-// acc += tab[lane N of each 16-lane row] * x, and the broadcast alone: a wave-uniform table kept in VGPRs reaches the VALU
-// through DPP row_newbcast with no memory latency at all (the same device k_bcd_w uses for V and its b table)
-template <int N>
-__device__ __forceinline__ void fmac_bc16(float& acc, float tab, float x)
-{
-    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(tab), "v"(x), "n"(N));
-}
-template <int N>
-__device__ __forceinline__ float get_bc16(float tab)
-{
-    float out;
-    asm("v_mov_b32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(out) : "v"(tab), "n"(N));
-    return out;
-}
-// Exact-integer Gauss-Seidel of ranks 9..16 (see gs_row_lds) on a table in seventeen VGPRs: tabv[j], lane l = b[j][l & 15]
-// (symmetric, the diagonal holds den).  T[r] += u0[J] b[J][r] for r < J;  T[r'] += u_R0 b[R0][r'] for r' > R0.
-template <int R, int J, int... Rs>
-__device__ __forceinline__ void gsx_s_row(float (&T)[R], float tab, float u, std::integer_sequence<int, Rs...>)
-{
-    (fmac_bc16<Rs>(T[Rs], tab, u), ...);
-}
-template <int R, int J>
-__device__ __forceinline__ void gsx_s(float (&T)[R], const float (&tabv)[17], const float (&u0)[R])
-{
-    if constexpr (J < R) {
-        gsx_s_row<R, J>(T, tabv[J], u0[J], std::make_integer_sequence<int, J>{});
-        gsx_s<R, J + 1>(T, tabv, u0);
-    }
-}
-template <int R, int R0, int... Is>
-__device__ __forceinline__ void gsx_p_row(float (&T)[R], float tab, float u, std::integer_sequence<int, Is...>)
-{
-    (fmac_bc16<R0 + 1 + Is>(T[R0 + 1 + Is], tab, u), ...);
-}
-// FAST: the quotient as num * (1 / den) with the tie / range test of gs_row (returns "some column was too close to call":
-// the caller then repeats the row with the IEEE division); the division sits on the column-to-column dependency chain,
-// which is what bounds this solve.
-template <int R, int R0, bool FAST>
-__device__ __forceinline__ bool gsx_p(float (&T)[R], const float (&tabv)[17], float rdenv, const float (&a)[R], float (&u)[R],
-                                      const GsParams& gp)
-{
-    if constexpr (R0 < R) {
-        const float num = (a[R0] - T[R0]) + LRF_EPS;
-        float val;
-        bool unsafe = false;
-        if (FAST) {
-            const float q = num * get_bc16<R0>(rdenv);
-            const float nq = rintf(q);
-            const bool inside = fabsf(q) < gp.flimit;
-            unsafe = inside && !(fabsf(q - nq) <= gp.fthr);
-            val = inside ? nq : q;
-        } else {
-            val = rintf(num / get_bc16<R0>(tabv[R0]));
-        }
-        u[R0] = fminf(fmaxf(val, gp.lo), gp.hi);
-        gsx_p_row<R, R0>(T, tabv[R0], u[R0], std::make_integer_sequence<int, R - 1 - R0>{});
-        return gsx_p<R, R0 + 1, FAST>(T, tabv, rdenv, a, u, gp) || unsafe;
-    } else {
-        return false;
-    }
-}
-
-// keeps the scalar loads of one table row next to their use (hoisted together they overflow the SGPR file)
-#define LRF_TABLE_ROW_FENCE() asm volatile("" ::: "memory")
-
-
-// term2 = uu . bb in the reference's order (qmf.py:115): ATen native chain or the MKL single-column tree
-template <int K, bool NATIVE>
-__device__ __forceinline__ float gs_term2(const float* uu, const float* bb)
-{
-    if (K == 0) return 0.f;
-    if (NATIVE) {
-        float acc = 0.f;
-#pragma unroll
-        for (int k = 0; k < K; k++) {
-            float p = uu[k] * bb[k];
-            acc = acc + p;
-        }
-        return acc;
-    }
-    if (K == 1) return uu[0] * bb[0];
-    float odd = fmaf(uu[1], bb[1], uu[0] * bb[0]); // oracle/lrf_oracle.c dot_mkl_n1
-    constexpr int last_odd = ((K - 1) & 1) ? K - 1 : K - 2;
-#pragma unroll
-    for (int k = last_odd; k >= 3; k -= 2) odd = odd + uu[k] * bb[k];
-    if (K < 3) return odd;
-    float even = uu[2] * bb[2];
-#pragma unroll
-    for (int k = 4; k < K; k += 2) even = even + uu[k] * bb[k];
-    return odd + even;
-}
-
-// One row, all R columns.  EXACT = false: branch-free speculative solve with q~ = num * (1/den); returns true
-// when some column sat too close to a rounding tie (or anything else made the shortcut unsafe) — the caller
-// then re-solves the row with EXACT = true (IEEE division), which is what the reference computes.
-template <int R, bool NATIVE, bool EXACT>
-__device__ __forceinline__ bool gs_row(const float* a, float* u, const float* __restrict__ gt, const GsParams gp)
-{
-    constexpr int K = R - 1;
-    // Preload the whole table in straight-line code: one batch of (scalar or LDS) loads and a single wait.
-    float bbv[R][K > 0 ? K : 1], rden[R], den[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-#pragma unroll
-        for (int k = 0; k < K; k++) bbv[r][k] = gt[r * LRF_GT_LD + k];
-        rden[r] = gt[r * LRF_GT_LD + LRF_GT_RDEN];
-        den[r] = gt[r * LRF_GT_LD + LRF_GT_DEN];
-    }
-#ifdef LRF_STAMPS
-    STAMP(gq0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    STAMP(gq1);
-    if (!EXACT) GSP_ADD(1, gq0, gq1);
-#endif
-    bool unsafe = false;
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        float uu[K > 0 ? K : 1];
-        int n = 0;
-#pragma unroll
-        for (int j = 0; j < R; j++)
-            if (j != r) uu[n++] = u[j];
-        float num = (a[r] - gs_term2<K, NATIVE>(uu, bbv[r])) + LRF_EPS;
-        float val;
-        if (EXACT) {
-            val = rintf(num / den[r]);
-        } else {
-            float q = num * rden[r];
-            float nq = rintf(q);
-            bool inside = fabsf(q) < gp.flimit;          // false for NaN: falls to val = q, clamp handles it
-            unsafe |= inside && !(fabsf(q - nq) <= gp.fthr);
-            val = inside ? nq : q;
-        }
-        u[r] = fminf(fmaxf(val, gp.lo), gp.hi);
-    }
-#ifdef LRF_STAMPS
-    asm volatile("" ::"v"(u[R - 1]));
-    STAMP(gq2);
-    if (!EXACT) GSP_ADD(2, gq1, gq2);
-#endif
-    return unsafe;
-}
-
-// One row through LDS: a_row[0..R) in, u_row[0..LRF_RP) out (zero padded).  The old row comes from int8 bytes
-// (uold_row, packed R per row) when FROM_I8, else from u_row itself.  All loops have compile-time bounds so the
-// LDS reads/writes are issued as batches (a runtime-R loop costs one exposed LDS latency per element).
-template <int R, bool FROM_I8>
-__device__ __forceinline__ void gs_row_lds(const float* a_row, float* u_row, const int8_t* uold_row,
-                                           const float* __restrict__ gt, bool native, const GsParams gp, const float (&tabv)[17])
-{
-    float a[R], u0[R], u[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        a[r] = a_row[r];
-        u0[r] = FROM_I8 ? (float)uold_row[r] : u_row[r];
-        u[r] = u0[r];
-    }
-#ifdef LRF_STAMPS
-    STAMP(gl0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    STAMP(gl1);
-    GSP_ADD(0, gl0, gl1);
-#endif
-    if (FROM_I8 && R > 8 && gp.exact_int) {
-        // Ranks 9..16 from the second iteration on: integer u, integer b, sums below 2^24 — the reference's dependent chain
-        // per column (and the R (R-1)-entry register copy of the table it needs) becomes R (R-1) independent fmas on R
-        // accumulators: T[r] starts as the sum over the columns j > r still holding old values and receives u_r b[r][r']
-        // for every later column as soon as u_r is known.  Bit-identical; the table sits in sixteen VGPRs (tabv) and is
-        // broadcast by DPP (scalar loads of it, even fenced row by row, left one exposed scalar-cache latency per row).
-        float T[R];
-#pragma unroll
-        for (int r = 0; r < R; r++) T[r] = 0.f;
-        gsx_s<R, 1>(T, tabv, u0);
-        float T0[R];
-#pragma unroll
-        for (int r = 0; r < R; r++) T0[r] = T[r];
-        const float rdenv = tabv[16]; // lane l: 1 / den[l & 15]
-        if (__any(gsx_p<R, 0, true>(T, tabv, rdenv, a, u, gp))) { // rare: repeat with the reference's IEEE division
-#pragma unroll
-            for (int r = 0; r < R; r++) T[r] = T0[r];
-            gsx_p<R, 0, false>(T, tabv, rdenv, a, u, gp);
-        }
-    } else {
-        bool unsafe = native ? gs_row<R, true, false>(a, u, gt, gp) : gs_row<R, false, false>(a, u, gt, gp);
-        if (__any(unsafe)) { // rare (about one wave in a few hundred): redo with the reference's IEEE division
-#pragma unroll
-            for (int r = 0; r < R; r++) u[r] = u0[r];
-            if (native) gs_row<R, true, true>(a, u, gt, gp);
-            else gs_row<R, false, true>(a, u, gt, gp);
-        }
-    }
-#ifdef LRF_STAMPS
-    STAMP(gl2);
-    GSP_ADD(3, gl1, gl2);
-#endif
-    float o[LRF_RP];
-#pragma unroll
-    for (int r = 0; r < LRF_RP; r++) o[r] = (r < R) ? u[r < R ? r : 0] : 0.f;
-#pragma unroll
-    for (int r = 0; r < LRF_RP; r += 4) *reinterpret_cast<f32x4*>(u_row + r) = (f32x4){o[r], o[r + 1], o[r + 2], o[r + 3]};
-}
-
-template <int RMAX, bool FROM_I8>
-__device__ __forceinline__ void gs_dispatch(int R, const float* a_row, float* u_row, const int8_t* uold_rows, int lane,
-                                            const float* __restrict__ gt, bool native, const GsParams gp, const float (&tabv)[17])
-{
-    switch (R) {
-#define LRF_CASE(r)                                                                                              \
-    case r:                                                                                                      \
-        if (r <= RMAX) gs_row_lds<(r <= RMAX ? r : 1), FROM_I8>(a_row, u_row, uold_rows + lane * r, gt, native, gp, tabv); \
-        break;
-        LRF_CASE(1) LRF_CASE(2) LRF_CASE(3) LRF_CASE(4) LRF_CASE(5) LRF_CASE(6) LRF_CASE(7) LRF_CASE(8)
-        LRF_CASE(9) LRF_CASE(10) LRF_CASE(11) LRF_CASE(12) LRF_CASE(13) LRF_CASE(14) LRF_CASE(15) LRF_CASE(16)
-#undef LRF_CASE
-    }
-}
-
-// gt table of b = v.mT @ v (R x R) from a [depth][LRF_RP] factor: thread (j, r).
-// ATen uses its native kernel when depth*R*R < 400, MKL (k-ordered fma chain) otherwise.
-__device__ __forceinline__ void make_gtable(const float* Vp, int depth, int R, float* gt, int tid, int nthreads)
-{
-    bool native = (long)depth * R * R < 400;
-    for (int i = tid; i < R * R; i += nthreads) {
-        int j = i / R, r = i - j * R;
-        float acc = 0.f;
-        if (native) {
-            for (int k = 0; k < depth; k++) {
-                float p = Vp[k * LRF_RP + j] * Vp[k * LRF_RP + r];
-                acc = acc + p;
-            }
-        } else {
-            for (int k = 0; k < depth; k++) acc = fmaf(Vp[k * LRF_RP + j], Vp[k * LRF_RP + r], acc);
-        }
-        if (j == r) {
-            float den = (acc + 0.f) + LRF_EPS;
-            gt[r * LRF_GT_LD + LRF_GT_DEN] = den;
-            gt[r * LRF_GT_LD + LRF_GT_RDEN] = 1.0f / den;
-        } else {
-            gt[r * LRF_GT_LD + (j < r ? j : j - 1)] = acc;
-        }
-    }
-}
+#include "lrf_gs.h"
 
 // b table of the initial V (after k_init or k_load_v0): one workgroup per matrix
 __global__ __launch_bounds__(256) void k_bprep(const PlaneDesc* __restrict__ planes, const float* __restrict__ Vf,

@@ -77,59 +77,6 @@ __device__ __forceinline__ bool mid_gs_steps(const MidLds<0>& L, int R, int q, c
 }
 
 
-// The ordered Gauss-Seidel of one row (qmf.py:108-119) with the row in REGISTERS:
-// u[0..32) in/out, a[0..32), the b table read from LDS with wave-uniform addresses (gt_l: pitch LRF_GTB_LD, row r = the `bb`
-// vector of column r, [LRF_GTB_DEN] = den).  Every index below is a compile-time constant, so the R (R-1) terms are register
-// multiplies and adds in the reference's MKL single-column order (oracle dot_mkl_n1: the odd terms descending after
-// fma(u1, b1, u0 b0), then the even ones ascending) with no memory latency inside the chains; the run-time rank only
-// guards terms (wave-uniform branches).  Not for the ATen-native order (tiny matrices): callers keep gs_term2_generic there.
-template <int RR>
-__device__ __forceinline__ float mid_term2(int K, const float (&u)[32], const float (&bb)[32])
-{
-    // uu[n] = u[n < RR ? n : n + 1]
-#define MID_UU(n) u[(n) < RR ? (n) : ((n) + 1 < 32 ? (n) + 1 : 31)]
-    if (K <= 0) return 0.f;
-    if (K == 1) return MID_UU(0) * bb[0];
-    float odd = fmaf(MID_UU(1), bb[1], MID_UU(0) * bb[0]);
-#pragma unroll
-    for (int n = 29; n >= 3; n -= 2)
-        if (n < K) odd = odd + MID_UU(n) * bb[n];
-    if (K < 3) return odd;
-    float even = MID_UU(2) * bb[2];
-#pragma unroll
-    for (int n = 4; n <= 30; n += 2)
-        if (n < K) even = even + MID_UU(n) * bb[n];
-#undef MID_UU
-    return odd + even;
-}
-
-template <int RR>
-__device__ __forceinline__ void mid_ordered_col(int R, const float (&a)[32], float (&u)[32], const float* __restrict__ gt_l, float lo, float hi)
-{
-    if (RR < R) {
-        // the whole `bb` row up front (eight wave-uniform 16-byte reads, pitch LRF_GTB_LD * 4 = 272 bytes): a read inside each
-        // guarded term would put an LDS round trip into every link of the chain
-        float bb[32];
-#pragma unroll
-        for (int n = 0; n < 32; n += 4) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(gt_l + RR * LRF_GTB_LD + n);
-            bb[n] = v[0]; bb[n + 1] = v[1]; bb[n + 2] = v[2]; bb[n + 3] = v[3];
-        }
-        const float den = gt_l[RR * LRF_GTB_LD + LRF_GTB_DEN];
-        const float term2 = mid_term2<RR>(R - 1, u, bb);
-        const float num = (a[RR] - term2) + LRF_EPS;
-        const float val = rintf(num / den);
-        u[RR] = fminf(fmaxf(val, lo), hi);
-    }
-}
-
-template <int... Rs>
-__device__ __forceinline__ void mid_ordered_row(int R, const float (&a)[32], float (&u)[32], const float* __restrict__ gt_l, float lo, float hi,
-                                                std::integer_sequence<int, Rs...>)
-{
-    (mid_ordered_col<Rs>(R, a, u, gt_l, lo, hi), ...);
-}
-
 template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_bcd_mid(const float* __restrict__ X, const PlaneDesc* __restrict__ planes,
                                                  const BlockDesc* __restrict__ blocks, const float* __restrict__ Vf,

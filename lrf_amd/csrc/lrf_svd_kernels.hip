@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "lrf_device.h"
+
 // ---- "c (h p) (w q) -> (h w) (c p q)" with reflect padding: one workgroup per (patch row, image) ----
 // T = float: the matrix the factorisation kernels take.  T = uint8_t (round 3, svd_encode): the same matrix as bytes — a quarter
 // of the traffic for the three passes of svd_encode over it (this one, the exact Gram matrix, u = X w).

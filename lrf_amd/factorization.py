@@ -16,7 +16,8 @@ class QMF:
     option of it: `bounds` or none, `factor` subsets (the default (0, 1, 2) also refits the affine pair w every iteration),
     `l2` / `l1_ratio`.  The configuration `qmf_encode` uses — factor=(0, 1), integer bounds within int8, no penalties — runs on
     the tuned int8 kernels (lrf_qmf_decompose_f32); everything else on the general entry point (lrf_qmf_decompose_ex_f32,
-    float factors), also `eps` and `num_levels` (round 3).  Not covered: a user `project`.  Extra keyword (not in the
+    float factors), also `eps` and `num_levels` (round 3); `verbose=True` prints the loss before every iteration in the
+    reference's format (round 5).  Not covered: a user `project`.  Extra keyword (not in the
     reference): `init_sign` — int8 [R] or [B,R], the sign to impose on each initial component (include/lrf_hip.h).
     """
 
@@ -65,8 +66,8 @@ class QMF:
         if sign is not None:
             sign = torch.as_tensor(sign, dtype=torch.int8).reshape(-1, self.rank).expand(xd.shape[0], self.rank)
             sign = sign.contiguous().cuda(ctx.device)
-        if self.verbose:
-            print("QMF(verbose=True): per-iteration loss is not reported by the fused HIP path")
+        if self.verbose and self.num_iters > 0:
+            return self._decompose_verbose(ctx, xd, sign, dev_in)
         if self.num_levels:
             # SVDInit(num_levels=...) (qmf.py:56-68): both factors scaled to num_levels quantisation steps, w1 = their product.
             # The scaling itself is three elementwise torch operations on the initial factors (amax / amin / divide): the same
@@ -91,6 +92,30 @@ class QMF:
             u, v, w2 = ctx.decompose_ex(xd, self.rank, self.num_iters, self.bounds, self.l2, self.l1_ratio, self.factor, sign, eps=self.eps)
             w = w2.reshape(-1, 2, 1)
         return u.to(dev_in), v.to(dev_in), w.to(dev_in)
+
+    def _decompose_verbose(self, ctx, xd, sign, dev_in):
+        """verbose=True (lrf/factorization/qmf.py:206-212): before every iteration the loss of the current factors is printed
+        in the reference's format.  The iterations run ONE per library call from the previous call's factors — the same
+        arithmetic as the fused loop, bit for bit (from the second iteration on the factors are integers and every kernel
+        family reproduces the reference's ordered sums) — and the loss is the library's (lrf_qmf_loss_f32), not a torch product."""
+        B = xd.shape[0]
+        u, v = ctx.svd_init(xd, self.rank, sign)
+        w = torch.tensor([[0.0, 1.0]], device=xd.device).repeat(B, 1)
+        if self.num_levels:
+            su = (u.amax(dim=(-2, -1), keepdim=True) - u.amin(dim=(-2, -1), keepdim=True)) / self.num_levels
+            sv = (v.amax(dim=(-2, -1), keepdim=True) - v.amin(dim=(-2, -1), keepdim=True)) / self.num_levels
+            u, v = u / su, v / sv
+            w = torch.cat([torch.zeros_like(su), su * sv], dim=-2).reshape(B, 2)
+        for it in range(1, self.num_iters + 1):
+            loss = ctx.loss(xd, u, v, w).cpu()
+            print(f"iter {it}: loss = {loss}")
+            if self._int8_path:
+                u8, v8 = ctx.bcd(xd, u, v, 1, self._lo, self._hi)
+                u, v = u8.float(), v8.float()
+            else:
+                u, v, w = ctx.decompose_ex(xd, self.rank, 1, self.bounds, self.l2, self.l1_ratio, self.factor, None, init=(u, v),
+                                           eps=self.eps, w_init=w)
+        return u.to(dev_in), v.to(dev_in), w.reshape(-1, 2, 1).to(dev_in)
 
     @staticmethod
     def reconstruct(u: Tensor, v: Tensor, w: Optional[Tensor] = None) -> Tensor:

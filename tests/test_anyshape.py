@@ -455,36 +455,3 @@ def test_hip_scale_factors(name, oracle):
     assert enc == c.encoded, "from the reference's initial factors the encoder must emit the reference's bytes"
     own = lrf_amd.qmf_encode(c.image, **c.kwargs)
     assert abs(_psnr(c.image.numpy(), lrf_amd.qmf_decode(own).numpy()) - c.psnr) < 0.3
-
-
-_SWITCH_CHILD = r"""
-import hashlib, sys
-sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
-import torch, lrf_amd
-from conftest import make_image
-out = []
-for spec, kw in (({"kind": "smooth", "H": 208, "W": 304, "seed": 5}, {"quality": 18, "patch_size": (16, 16)}),
-                 ({"kind": "smooth", "H": 96, "W": 144, "seed": 6}, {"quality": 30, "patch_size": (4, 4)}),
-                 ({"kind": "randint", "H": 260, "W": 300, "seed": 7}, {"quality": 25, "patch": False})):
-    img = make_image(spec)
-    out.append(hashlib.sha256(lrf_amd.qmf_encode(img, **kw)).hexdigest())
-print(" ".join(out))
-"""
-
-
-@pytest.mark.gpu
-def test_round3_kernels_equal_the_ones_they_replaced():
-    """The round-3 kernels of the any-shape path (fp64-MFMA Gram matrix, tiled and thin products, byte-row Gauss-Seidel) claim
-    the bits of the kernels they replaced, which stay behind developer switches read at library load: the same three encodes
-    (16x16 and 4x4 patches, no patches: sides 208..300, ranks up to 65) in a child process with every switch set."""
-    import os, subprocess, sys
-    from conftest import ROOT
-
-    def run(env_extra):
-        env = dict(os.environ, **env_extra)
-        r = subprocess.run([sys.executable, "-c", _SWITCH_CHILD, ROOT], env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        return r.stdout.strip().splitlines()[-1].split()
-    new = run({})
-    old = run({"LRF_ANY_GRAM_VALU": "1", "LRF_ANY_PROD_SMALL": "1", "LRF_ANY_GS_F32": "1"})
-    assert len(new) == 3 and new == old

@@ -246,11 +246,14 @@ def test_persistent_kernel_other_iteration_counts_bounds_and_ranks():
     """k_bcd_p forced from 1024 blocks on (LRF_PERSIST=1, a child process: tests/_persist_worker.py) with what the default
     workloads of the test above do not vary: K = 2 (a single iteration in the launch), 3, 4, 5 and 10, narrow / wide /
     symmetric bounds, ranks 1..8 in every plane position, 48 images of 512x768 and 272 ragged 173x264 ones — against the
-    launch-per-iteration kernels on chunks of eight of the same images, bit for bit, and against the oracle on one image."""
+    launch-per-iteration kernels on chunks of eight of the same images, bit for bit, and against the oracle on one image.
+    Round 5: the same for the rank families 9..16 and 17..32 and their mixes (k_bcd_p<F16, NP32>: (16,8,8), (26,13,13),
+    (17,8,8), (32,16,16), ...), with the number of persistent launches of every case checked (bounds outside a family's
+    exact-integer range must take the launch-per-iteration kernels)."""
     import subprocess
     import sys
     from conftest import ROOT
     env = dict(os.environ, LRF_PERSIST="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_persist_worker.py")], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
-    assert r.stdout.count("ok ") == 6 and "persistent launches seen" in r.stdout, r.stdout
+    assert r.stdout.count("ok ") == 18 and "persistent launches seen" in r.stdout, r.stdout

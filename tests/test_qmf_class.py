@@ -121,3 +121,43 @@ def test_num_levels_and_eps_through_the_class():
     assert abs(lrf_amd.QMF.loss(x, u, v, w).item() - float(z["loss"])) < 1e-5
     with pytest.raises(NotImplementedError):
         lrf_amd.QMF(rank=3, project=lambda t: t)
+
+
+@pytest.mark.gpu
+def test_verbose_prints_the_loss_before_every_iteration(capsys, oracle):
+    """QMF(verbose=True) (lrf/factorization/qmf.py:206-212): one line per iteration, `iter k: loss = tensor([...])`, the loss of the
+    factors BEFORE that iteration — the initial factors at k = 1 — in the reference's format; the values equal the oracle's
+    factors' loss (numpy, fp64) to 1e-6, and the returned factors are those of the non-verbose call, bit for bit.  Tuned int8
+    path (what qmf_encode configures) on two matrices of a batch, and the general path (unbounded, affine pair refitted)."""
+    import re
+    import lrf_amd
+    from lrf_amd import _lib
+    ctx = _lib.context(0)
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randint(0, 256, (2, 480, 64), generator=g).float() * 0.5 + 40.0)
+    K, R = 4, 5
+    u, v, w = lrf_amd.QMF(rank=R, num_iters=K, bounds=(-16, 15), factor=(0, 1), verbose=True).decompose(x)
+    lines = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("iter ")]
+    assert len(lines) == K and all(re.fullmatch(rf"iter {k + 1}: loss = tensor\(\[[0-9.e+-]+, [0-9.e+-]+\]\)", ln) for k, ln in enumerate(lines)), lines
+    got = np.array([[float(t) for t in re.findall(r"[0-9.]+(?:e[+-]?[0-9]+)?", ln.split("tensor")[1])] for ln in lines])
+    for b in range(2):
+        X = x[b].numpy()
+        u0, v0 = oracle.svd_init(X, R)
+        for k in range(K):
+            uk, vk = (u0, v0) if k == 0 else oracle.bcd(X, u0, v0, k, (-16, 15))
+            want = _loss(X, uk, vk, (0.0, 1.0))
+            assert abs(got[k, b] - want) < 6e-5, (b, k, got[k, b], want)  # (torch prints four decimals)
+            lib = ctx.loss(x[b:b + 1].cuda(), torch.from_numpy(np.ascontiguousarray(uk, np.float32))[None].cuda(),
+                           torch.from_numpy(np.ascontiguousarray(vk, np.float32))[None].cuda())
+            assert abs(float(lib[0]) - want) < 1e-6 * max(1.0, want), (b, k, float(lib[0]), want)  # lrf_qmf_loss_f32 itself
+    u2, v2, w2 = lrf_amd.QMF(rank=R, num_iters=K, bounds=(-16, 15), factor=(0, 1)).decompose(x)
+    assert torch.equal(u, u2) and torch.equal(v, v2) and torch.equal(w, w2)
+    # the general path: unbounded factors, w refitted every iteration
+    u, v, w = lrf_amd.QMF(rank=3, num_iters=3, verbose=True).decompose(x[:1])
+    lines = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("iter ")]
+    assert len(lines) == 3
+    u2, v2, w2 = lrf_amd.QMF(rank=3, num_iters=3).decompose(x[:1])
+    assert torch.equal(u, u2) and torch.equal(v, v2) and torch.allclose(w, w2, rtol=0, atol=0)
+    losses = [float(re.findall(r"[0-9.]+(?:e[+-]?[0-9]+)?", ln.split("tensor")[1])[0]) for ln in lines]
+    assert all(0 < v_ < 1 for v_ in losses)
+    assert abs(lrf_amd.QMF.loss(x[:1], u, v, w).item() - losses[-1]) < 0.05  # (the last line is the loss before the last iteration)
