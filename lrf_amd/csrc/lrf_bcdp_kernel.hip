@@ -569,11 +569,12 @@ __global__ __launch_bounds__(64 * LRF_BCDW_WAVES) __attribute__((amdgpu_waves_pe
             leave();
             return;
         }
-#ifdef LRF_BCDP_ROT
-        const int it = idx / nblocks, blk = (idx - it * nblocks + 100) % nblocks; // debug: which item is pulled first
-#else
+        // (iteration-major, the blocks of an iteration in table order.  Tried and not kept, round 5: the rank families of a call
+        // interleaved within an iteration — luma blocks beside chroma blocks on a SIMD: within noise —, and chunks of ~86 images
+        // (2064 blocks, 200 MB of X) running all their iterations before the next chunk, so that X stays in the 256 MB Infinity
+        // Cache: 139 -> 164 us per iteration at (7,3,3), 246 -> 353 at (26,13,13): a chunk is barely one round of the resident
+        // waves, so blocks poll for V tables that are still being computed — and the kernel is not bound by HBM bandwidth)
         const int it = idx / nblocks, blk = idx - it * nblocks;
-#endif
 #ifdef LRF_BCDP_DEBUG
         atomicAdd(&sync->cell[2 * nplanes + blk], 1 + 1000 * it); // every active lane
 #endif

@@ -264,6 +264,9 @@ __device__ __forceinline__ void w16_block(const float* __restrict__ X, const Pla
     for (int d = 0; d < 5; d++) upre.d[d] = 0u;
     upre.sh = 0u;
     auto issue_x = [&](int t, int T0, int T1) {
+#ifdef LRF_W16_NO_X // ablation (timing only): the X tile is loaded once per block
+        if (t > 0) return;
+#endif
         const int r0 = t * 64;
 #pragma unroll
         for (int T = T0; T < T1; T++) {
@@ -277,6 +280,9 @@ __device__ __forceinline__ void w16_block(const float* __restrict__ X, const Pla
     };
     auto issue_u = [&](int t) {
         if (MODE != 0) return;
+#ifdef LRF_W16_NO_ULOAD // ablation (timing only)
+        if (t > 0) return;
+#endif
         int row = t * 64 + lane;
         row = row < nrows ? row : nrows - 1;
         const int8_t* up = Ub + (long)row * R;
@@ -344,6 +350,7 @@ __device__ __forceinline__ void w16_block(const float* __restrict__ X, const Pla
 #pragma unroll
                     for (int T = 0; T < 4; T++)
                         bx[s][T] = *reinterpret_cast<const float*>(xrow_b + T * 16 * 256 + ((16 * (8 * h + s)) ^ g16));
+#ifndef LRF_W16_NO_A // ablation (timing only)
 #pragma unroll
                 for (int s = 0; s < 8; s++)
 #pragma unroll
@@ -351,6 +358,10 @@ __device__ __forceinline__ void w16_block(const float* __restrict__ X, const Pla
                         acc[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[8 * h + s], bx[s][T], acc[T], 0, 0, 0);
                         if constexpr (MODE == 1) accw[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[8 * h + s], bx[s][T], accw[T], 0, 0, 0);
                     }
+#else
+#pragma unroll
+                for (int T = 0; T < 4; T++) acc[T][0] += bx[0][T] + bx[7][T] + va[8 * h];
+#endif
             }
             w16_tiles_to_rows(acc, a);
             if constexpr (MODE == 1) w16_tiles_to_rows(accw, uf);
@@ -358,6 +369,10 @@ __device__ __forceinline__ void w16_block(const float* __restrict__ X, const Pla
         if (more) issue_x(tn, 2, 3);
         __builtin_amdgcn_sched_barrier(0);
         // ---- 3. Gauss-Seidel in registers: w = old int8 row in (MODE 0, exact-integer form), new int8 row out
+#ifdef LRF_W16_NO_GS // ablation (timing only)
+        w = make_uint4(__float_as_uint(a[0]) ^ wraw.d[0], __float_as_uint(a[5]), __float_as_uint(a[10]) ^ wraw.d[1], __float_as_uint(a[15]));
+        if (false)
+#endif
         switch (R) {
 #define LRF_CASE(r) case r: if constexpr (MODE == 1) w = w16_row_first<r>(a, uf, tabv, gp); else w = w16_row<r>(a, w16_row_dwords<r, MEM>(wraw), tabv, gp); break;
             LRF_CASE(1) LRF_CASE(2) LRF_CASE(3) LRF_CASE(4) LRF_CASE(5) LRF_CASE(6) LRF_CASE(7) LRF_CASE(8)
@@ -371,7 +386,11 @@ __device__ __forceinline__ void w16_block(const float* __restrict__ X, const Pla
         __builtin_amdgcn_sched_barrier(0);
         // ---- 4. the int8 row to LDS (operand of the partial products) and to global memory
         *reinterpret_cast<uint4*>(us8 + lane * 16) = w;
+#ifdef LRF_W16_NO_USTORE // ablation (timing only)
+        if (row < nrows && t == 0) {
+#else
         if (row < nrows) {
+#endif
             int8_t* uo = Ub + (long)row * R;
             switch (R) {
 #define LRF_CASE(r) case r: w16_store_row<r, MEM>(uo, w); break;
@@ -385,6 +404,7 @@ __device__ __forceinline__ void w16_block(const float* __restrict__ X, const Pla
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_sched_barrier(0);
+#ifndef LRF_W16_NO_PQ // ablation (timing only)
         // ---- 5. a' += X^T u (four strided column tiles per LDS read), b' += u^T u
         float pu[16];
 #pragma unroll
@@ -401,6 +421,7 @@ __device__ __forceinline__ void w16_block(const float* __restrict__ X, const Pla
                 accQ = __builtin_amdgcn_mfma_f32_16x16x4f32(pu[8 * h + s], pu[8 * h + s], accQ, 0, 0, 0);
             }
         }
+#endif
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -419,11 +440,10 @@ __device__ __forceinline__ void w16_block(const float* __restrict__ X, const Pla
     for (int reg = 0; reg < 4; reg++) MEM::st(Qp + (4 * lq + reg) * LRF_RP + li, accQ[reg]);
 }
 
-#ifndef LRF_W16_WAVES_PER_EU_MODE1
-#define LRF_W16_WAVES_PER_EU_MODE1 1
-#endif
+// Two waves per SIMD for both modes.  Left to itself the compiler gave MODE 1 (both MFMA operand sets resident) 264 registers, one
+// wave per SIMD; bounded to 256 it needs 232 and spills nothing: 256 x 512x768 at (16,8,8) 2.40 -> 2.35 ms (round 5).
 template <int MODE>
-__global__ __launch_bounds__(64 * LRF_BCDW16_WAVES) __attribute__((amdgpu_waves_per_eu(MODE == 1 ? LRF_W16_WAVES_PER_EU_MODE1 : 2, 2))) void k_bcd_w16(const float* __restrict__ X, const PlaneDesc* __restrict__ planes,
+__global__ __launch_bounds__(64 * LRF_BCDW16_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_bcd_w16(const float* __restrict__ X, const PlaneDesc* __restrict__ planes,
                                                                   const BlockDesc* __restrict__ blocks, const float* __restrict__ Vf,
                                                                   const float* __restrict__ Wf, const float* __restrict__ Bf, int8_t* __restrict__ U,
                                                                   float* __restrict__ Ppart, float* __restrict__ Qpart, GsParams gp,

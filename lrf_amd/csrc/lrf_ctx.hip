@@ -262,7 +262,6 @@ int upload_tables(lrf_ctx* c, Tables& t)
         std::swap(c->planes, a.planes);
         std::swap(c->blocks, a.blocks);
         std::swap(c->gchunks, a.gchunks);
-        std::swap(c->qblocks, a.qblocks);
         c->table_key.swap(a.key);
         a.stamp = ++c->tstamp;
     }
@@ -274,29 +273,6 @@ int upload_tables(lrf_ctx* c, Tables& t)
     if (rc) return rc;
     rc = upload(c, c->gchunks, t.gchunks.data(), t.gchunks.size() * sizeof(GramChunk));
     if (rc) return rc;
-    {
-        // The queue order of the persistent kernel (k_bcd_p): within an iteration the blocks of the call's runs INTERLEAVED in
-        // proportion to their sizes (a Bresenham merge; one run: the table order).  The table orders the planes luma first, so
-        // in table order the resident waves would all run the luma family's body, then all the chroma family's; interleaved,
-        // the two waves of a SIMD mostly run different bodies — the matrix-core-bound one of ranks 9..16 / 17..32 beside the
-        // VALU-bound one of ranks <= 8 — and the pipes overlap.  Order-free for the results (a block's arithmetic is its own).
-        const std::vector<FamRun> runs = plan_runs(t);
-        std::vector<BlockDesc> q;
-        q.reserve(t.blocks.size());
-        std::vector<long> done(runs.size(), 0);
-        const long total = (long)t.blocks.size();
-        for (long i = 0; i < total; i++) {
-            size_t best = 0;
-            double lag = -1e300;
-            for (size_t r = 0; r < runs.size(); r++) {
-                if (done[r] >= runs[r].nblocks) continue;
-                const double l = (double)(i + 1) * runs[r].nblocks / (double)total - (double)done[r]; // how far run r is behind its share
-                if (l > lag) { lag = l; best = r; }
-            }
-            q.push_back(t.blocks[(size_t)runs[best].block0 + (size_t)done[best]++]);
-        }
-        if ((rc = upload(c, c->qblocks, q.data(), q.size() * sizeof(BlockDesc)))) return rc;
-    }
     if ((rc = ensure(c, c->gpart, t.gchunks.size() * (size_t)LRF_GRAM_SLOT * sizeof(ulonglong2)))) return rc;
     if ((rc = ensure(c, c->gexp, t.planes.size() * sizeof(int)))) return rc;
     size_t np = t.planes.size(), nb = t.blocks.size();
@@ -381,14 +357,14 @@ void lrf_ctx_destroy(lrf_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     fold_events(c);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-    DevBuf* bufs[] = {&c->gchunks, &c->gpart, &c->gexp, &c->planes, &c->blocks, &c->qblocks, &c->vf, &c->wf, &c->bf, &c->ppart, &c->qpart, &c->x, &c->sign,
+    DevBuf* bufs[] = {&c->gchunks, &c->gpart, &c->gexp, &c->planes, &c->blocks, &c->vf, &c->wf, &c->bf, &c->ppart, &c->qpart, &c->x, &c->sign,
                       &c->sx, &c->sg, &c->svn, &c->swn, &c->suf, &c->smm,
                       &c->any_uf, &c->any_vf, &c->any_a, &c->any_b, &c->any_p, &c->any_e2, &c->any_g, &c->any_td,
                       &c->vf16, &c->wf16, &c->bf16, &c->pp16, &c->qp16};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto& a : c->talt) {
-        DevBuf* tb[] = {&a.planes, &a.blocks, &a.gchunks, &a.qblocks};
+        DevBuf* tb[] = {&a.planes, &a.blocks, &a.gchunks};
         for (DevBuf* b : tb)
             if (b->p) (void)hipFree(b->p);
     }
@@ -443,13 +419,13 @@ int lrf_ctx_check(lrf_ctx* c)
 size_t lrf_ctx_workspace_bytes(const lrf_ctx* c)
 {
     if (!c) return 0;
-    const DevBuf* bufs[] = {&c->gchunks, &c->gpart, &c->gexp, &c->planes, &c->blocks, &c->qblocks, &c->vf, &c->wf, &c->bf, &c->ppart, &c->qpart, &c->x, &c->sign,
+    const DevBuf* bufs[] = {&c->gchunks, &c->gpart, &c->gexp, &c->planes, &c->blocks, &c->vf, &c->wf, &c->bf, &c->ppart, &c->qpart, &c->x, &c->sign,
                             &c->sx, &c->sg, &c->svn, &c->swn, &c->suf, &c->smm,
                             &c->any_uf, &c->any_vf, &c->any_a, &c->any_b, &c->any_p, &c->any_e2, &c->any_g, &c->any_td,
                       &c->vf16, &c->wf16, &c->bf16, &c->pp16, &c->qp16};
     size_t total = 0;
     for (const DevBuf* b : bufs) total += b->cap;
-    for (const auto& a : c->talt) total += a.planes.cap + a.blocks.cap + a.gchunks.cap + a.qblocks.cap;
+    for (const auto& a : c->talt) total += a.planes.cap + a.blocks.cap + a.gchunks.cap;
     return total;
 }
 
@@ -458,7 +434,7 @@ int lrf_ctx_trim(lrf_ctx* c)
     if (!c) return set_err(LRF_EINVAL, "ctx is NULL");
     LRF_ON_DEVICE(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
-    DevBuf* bufs[] = {&c->gchunks, &c->gpart, &c->gexp, &c->planes, &c->blocks, &c->qblocks, &c->vf,
+    DevBuf* bufs[] = {&c->gchunks, &c->gpart, &c->gexp, &c->planes, &c->blocks, &c->vf,
                       &c->wf, &c->bf, &c->ppart, &c->qpart, &c->x, &c->sign, &c->sx, &c->sg, &c->svn, &c->swn, &c->suf, &c->smm,
                       &c->any_uf, &c->any_vf, &c->any_a, &c->any_b, &c->any_p, &c->any_e2, &c->any_g, &c->any_td,
                       &c->vf16, &c->wf16, &c->bf16, &c->pp16, &c->qp16};
@@ -468,7 +444,7 @@ int lrf_ctx_trim(lrf_ctx* c)
         b->cap = 0;
     }
     for (auto& a : c->talt) {
-        DevBuf* tb[] = {&a.planes, &a.blocks, &a.gchunks, &a.qblocks};
+        DevBuf* tb[] = {&a.planes, &a.blocks, &a.gchunks};
         for (DevBuf* b : tb) {
             if (b->p) HIP_TRY(hipFree(b->p));
             b->p = nullptr;

@@ -133,8 +133,7 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
             // the table sets of the two rank pitches (run_bufs): a call without ranks above 16 has only the pitch-16 one
             FamBufs f16{nullptr, nullptr, nullptr, nullptr, nullptr}, f64 = f16;
             for (const FamRun& r : runs) (r.pitch == 16 ? f16 : f64) = run_bufs(c, r, mixed);
-            // (the runs of a call cover its whole table: the queue-order copy of the block table starts at the same block)
-            int rcp = bcdp_launch(c, persist, X, pl, (const BlockDesc*)c->qblocks.p + r0.block0, (int)nb, (int)np, r0.plane0, f16, f64, U, V, gp, K - 1);
+            int rcp = bcdp_launch(c, persist, X, pl, bl + r0.block0, (int)nb, (int)np, r0.plane0, f16, f64, U, V, gp, K - 1);
             if (rcp) return rcp;
             break;
         }

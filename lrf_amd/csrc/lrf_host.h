@@ -76,7 +76,6 @@ struct lrf_ctx {
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
     DevBuf planes, blocks, gchunks, vf, wf, bf, ppart, qpart, x, sign;
-    DevBuf qblocks; // the blocks in the queue order of k_bcd_p (upload_tables: the rank families of a call interleaved)
     DevBuf gpart, gexp; // exact Gram partials (128-bit integers per chunk) and per-matrix grid exponents (lrf_gram_kernels.hip)
     DevBuf sx, sg, svn, swn, suf, smm; // SVD baseline workspace
     DevBuf any_uf, any_vf, any_a, any_b, any_p, any_e2, any_g, any_td; // any-shape path (lrf_anyshape_host.inc)
@@ -96,7 +95,7 @@ struct lrf_ctx {
     // earlier tables, least recently used one replaced: calls that alternate between a few geometries (a pipeline slot sees
     // its full sub-batch size and the two or three sizes of the tapered tail) find them resident and skip the synchronising upload
     struct TableSet {
-        DevBuf planes, blocks, gchunks, qblocks;
+        DevBuf planes, blocks, gchunks;
         std::vector<char> key;
         unsigned long stamp = 0;
     };
