@@ -196,6 +196,23 @@ int lrf_qmf_encode_rgb_u8(lrf_ctx* ctx, const uint8_t* rgb, int64_t B, int64_t H
                           int K, int lo, int hi, const int8_t* sign, int8_t* U, int8_t* V);
 
 /*
+ * The same encode for ONE batch at Q rank triples in one call: the R-D sweep of the reference's experiments
+ * (experiments/comparison/eval.py:83-110 calls qmf_encode per image and quality; BASELINE config 3: 24 images x quality 1..32).
+ * What does not depend on the rank is computed once per image (patch matrices, exact Gram matrices), the SVD initialisation
+ * once per (image, channel) at the largest rank asked for that channel — the lower ranks take its leading columns, which are
+ * the same singular pairs bit for bit — and the BCD of all (triple, image) pairs runs as one call of Q x B matrices sets that
+ * share X (large launches per rank family; the persistent kernel from 3584 blocks).  Every (triple, image) result is
+ * byte-identical to lrf_qmf_encode_rgb_u8's for that triple.
+ *   R     [Q][3] ranks (Y, Cb, Cr) per triple, each 1..32 (larger ranks: one lrf_qmf_encode_rgb_u8 call per triple)
+ *   sign  optional [B][Rmax_Y + Rmax_Cb + Rmax_Cr] int8 (Rmax_c = the largest rank of channel c over the triples): the signs
+ *         of the initial components; every triple uses the leading ones of its ranks
+ *   U, V  for q = 0 .. Q-1 the factors of the B images at triple q back to back, each block in lrf_qmf_encode_rgb_u8's
+ *         layout: U offset sum_{q' < q} B u_img(q'), u_img(q) = sum_c M_c R[q][c]; V likewise with 64 R[q][c]
+ */
+int lrf_qmf_encode_sweep_rgb_u8(lrf_ctx* ctx, const uint8_t* rgb, int64_t B, int64_t H, int64_t W, int Q, const int* R, int K, int lo, int hi,
+                                const int8_t* sign, int8_t* U, int8_t* V);
+
+/*
  * Fused decode of B images: QMF.reconstruct, depatchify, unpad_image, chroma_upsampling(nearest),
  * ycbcr_to_rgb, to_dtype(uint8): lrf/compression/qmf.py:329-351, lrf/factorization/qmf.py:216-223,
  * lrf/compression/utils.py:50-73,98-105,135-182.  U, V laid out as lrf_qmf_encode_rgb_u8 writes them.

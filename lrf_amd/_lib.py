@@ -71,6 +71,8 @@ def load():
         lib.lrf_qmf_loss_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_void_p]
         lib.lrf_qmf_encode_rgb_u8.argtypes = [c_void_p, c_void_p, c_i64, c_i64, c_i64, ctypes.POINTER(c_int), c_int, c_int,
                                               c_int, c_void_p, c_void_p, c_void_p]
+        lib.lrf_qmf_encode_sweep_rgb_u8.argtypes = [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, ctypes.POINTER(c_int), c_int, c_int,
+                                                    c_int, c_void_p, c_void_p, c_void_p]
         lib.lrf_qmf_decode_rgb_u8.argtypes = [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, ctypes.POINTER(c_int),
                                               c_void_p]
         lib.lrf_svd_encode_rgb_u8.argtypes = [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
@@ -116,7 +118,7 @@ EXPORTS = ["lrf_last_error", "lrf_device_count", "lrf_version", "lrf_ctx_create"
            "lrf_ctx_synchronize", "lrf_ctx_check", "lrf_ctx_workspace_bytes", "lrf_ctx_trim", "lrf_ctx_profile", "lrf_ctx_profile_kernels", "lrf_ctx_kernel_time",
            "lrf_ctx_profile_reset", "lrf_malloc", "lrf_free", "lrf_memcpy_h2d", "lrf_memcpy_d2h", "lrf_plane_dims",
            "lrf_qmf_planes_from_rgb_u8", "lrf_qmf_decompose_f32", "lrf_qmf_decompose_ex_f32", "lrf_qmf_bcd_f32", "lrf_qmf_svd_init_f32", "lrf_qmf_loss_f32",
-           "lrf_qmf_encode_rgb_u8", "lrf_qmf_decode_rgb_u8", "lrf_svd_encode_rgb_u8", "lrf_svd_decode_rgb_u8",
+           "lrf_qmf_encode_rgb_u8", "lrf_qmf_encode_sweep_rgb_u8", "lrf_qmf_decode_rgb_u8", "lrf_svd_encode_rgb_u8", "lrf_svd_decode_rgb_u8",
            "lrf_qmf_rgbspace_encode_u8", "lrf_qmf_rgbspace_decode_u8", "lrf_rgbspace_dims_any", "lrf_qmf_rgbspace_matrix_u8",
            "lrf_qmf_rgbspace_decode_any_u8", "lrf_quantize_u8", "lrf_svd_decode_any_u8",
            "lrf_plane_dims_any", "lrf_qmf_planes_any_u8", "lrf_qmf_decode_any_u8", "lrf_plane_dims_any_hw", "lrf_qmf_planes_any_hw_u8",
@@ -357,6 +359,27 @@ class Context:
         self.use_torch_stream()
         check(self._lib.lrf_qmf_encode_rgb_u8(self._h, _dptr(rgb), B, H, W, R, K, lo, hi, _dptr(sign), _dptr(U), _dptr(V)))
         return U, V
+
+    def encode_sweep_rgb(self, rgb, triples, K, lo, hi, sign=None):
+        """rgb uint8 [B,3,H,W] (CUDA) at every rank triple of `triples` in ONE call (lrf_qmf_encode_sweep_rgb_u8) ->
+        [(U int8 [B, sum M_c R_c], V int8 [B, 64 sum R_c]) per triple] (views of two flat buffers)"""
+        import torch
+        B, C, H, W = rgb.shape
+        assert C == 3 and rgb.dtype == torch.uint8 and len(triples) >= 1
+        dims = plane_dims(H, W)
+        nus = [sum(d[4] * int(r) for d, r in zip(dims, t)) for t in triples]
+        nvs = [64 * sum(int(r) for r in t) for t in triples]
+        U = torch.empty((B * sum(nus),), dtype=torch.int8, device=rgb.device)
+        V = torch.empty((B * sum(nvs),), dtype=torch.int8, device=rgb.device)
+        R = (c_int * (3 * len(triples)))(*[int(r) for t in triples for r in t])
+        self.use_torch_stream()
+        check(self._lib.lrf_qmf_encode_sweep_rgb_u8(self._h, _dptr(rgb), B, H, W, len(triples), R, K, lo, hi, _dptr(sign), _dptr(U), _dptr(V)))
+        out, uo, vo = [], 0, 0
+        for nu, nv in zip(nus, nvs):
+            out.append((U[uo:uo + B * nu].view(B, nu), V[vo:vo + B * nv].view(B, nv)))
+            uo += B * nu
+            vo += B * nv
+        return out
 
     def decode_rgb(self, U, V, H, W, ranks):
         import torch

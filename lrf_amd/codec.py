@@ -80,6 +80,44 @@ def qmf_factorize_batch(images: torch.Tensor, ranks: Sequence[int], num_iters: i
                           sign, out=out)
 
 
+def qmf_encode_sweep(images: torch.Tensor, qualities=None, ranks=None, bounds=(-16, 15), num_iters: int = 10, init_sign=None,
+                     pack_workers: Optional[int] = None) -> list:
+    """qmf_encode of a batch [B,3,H,W] at every quality of `qualities` (or every rank / rank triple of `ranks`) in ONE GPU
+    call (lrf_qmf_encode_sweep_rgb_u8: the R-D sweep of experiments/comparison/eval.py:83-110; default branch — YCbCr, 8x8
+    patches).  Returns one list of B byte streams per quality, each stream byte-identical to `qmf_encode(image, quality=q)`.
+    Qualities that give the same rank triple are computed once; rank triples above 32 fall back to one call each."""
+    assert (qualities is None) != (ranks is None), "give either qualities or ranks"
+    H, W = images.shape[-2:]
+    params = list(qualities) if qualities is not None else list(ranks)
+    triples = [tuple(qmf_ranks((H, W), None, p)) if qualities is not None else tuple(qmf_ranks((H, W), p, None)) for p in params]
+    if images.dtype != torch.uint8:
+        raise NotImplementedError("HIP path takes uint8 images")
+    ctx = _lib.context(images.device.index if images.is_cuda else None)
+    dev = (images if images.is_cuda else images.cuda(ctx.device)).contiguous()
+    B = dev.shape[0]
+    lo, hi = math.ceil(bounds[0]), math.floor(bounds[1])
+    unique = sorted(set(triples))
+    fused = [t for t in unique if max(t) <= 32]
+    factors = {}
+    if fused and num_iters >= 1:
+        rmax = [max(t[c] for t in fused) for c in range(3)]
+        sign = None
+        if init_sign is not None:  # [Rmax_Y + Rmax_Cb + Rmax_Cr] or [B, ...]: the signs of the largest ranks' components
+            sign = torch.as_tensor(init_sign, dtype=torch.int8).reshape(-1, sum(rmax)).expand(B, sum(rmax)).contiguous().cuda(dev.device)
+        for t, (U, V) in zip(fused, ctx.encode_sweep_rgb(dev, fused, num_iters, lo, hi, sign)):
+            factors[t] = (U, V)
+    out = {}
+    for t in unique:
+        if t in factors:
+            Uh, Vh = (x.numpy() for x in ctx.to_host(*factors[t]))
+            out[t] = pack_streams_native(Uh, Vh, (H, W), list(t), bounds, (8, 8), "uint8", threads=pack_workers or default_pack_threads())
+        else:  # ranks above 32 (or num_iters = 0): the per-triple encoder
+            if init_sign is not None:
+                raise NotImplementedError("init_sign with rank triples outside the fused sweep")
+            out[t] = qmf_encode_batch(dev, rank=list(t), bounds=bounds, num_iters=num_iters, pack_workers=pack_workers)
+    return [out[t] for t in triples]
+
+
 def qmf_factorize_host(images: torch.Tensor, ranks: Sequence[int], num_iters: int = 10, bounds=(-16, 15), init_sign=None,
                        out=None, slots: int = 2, sub_batch: int = 0, device=None):
     """Host -> host form of qmf_factorize_batch: `images` is a uint8 CPU tensor [B,3,H,W]

@@ -119,6 +119,7 @@ void add_plane(Tables& t, long x_off, long u_off, long v_off, long u0_off, long 
     pd.native_t2_u = ((long)(R - 1) * M < 400) ? 1 : 0;
     pd.sign_off = sign_off;
     int pi = (int)t.planes.size();
+    pd.init_src = pi; // (a sweep call's table builder points the lower-rank planes of a matrix at its largest-rank plane)
     for (int b = 0; b < pd.nblk; b++) t.blocks.push_back(BlockDesc{pi, b * LRF_KC, b, 0});
     pd.gch0 = 0; // the Gram chunks are cut when the table is complete (finish_gram_chunks)
     pd.ngch = 0;
@@ -155,23 +156,28 @@ bool bcd_wave_variant()
     static const bool v = !dev_flag("LRF_BCD_WG"); // LRF_BCD_WG=1 (dev build): the workgroup kernel k_bcd instead of k_bcd_w
     return v;
 }
-std::vector<FamRun> plan_runs(const Tables& t)
+// Since the families of a call run side by side on streams of their own (round 3) — or in one persistent launch (round 5) — the
+// split pays from 1024 blocks on (64 x 512x768: (16,8,8) 0.93 -> 0.89 ms, (20,10,10) 2.04 -> 1.36 with k_bcd_w32 on the luma run);
+// calls with a rank above 16 split from 256 blocks (24 images: (20,10,10) 1.27 -> 1.04 ms, 12 images 1.06 -> 0.99).
+bool plan_splits(long nblocks, int rmax_t)
 {
     static const bool no_split = dev_flag("LRF_NO_FAMILY_SPLIT");
-    const int rmax_t = table_rmax(t);
-    // since the families of a call run side by side on streams of their own (round 3) the split pays from 1024 blocks on
-    // (64 x 512x768: (16,8,8) 0.93 -> 0.89 ms, (20,10,10) 2.04 -> 1.36 with k_bcd_w32 on the luma run); calls with a rank above
-    // 16 split from 256 blocks (24 images: (20,10,10) 1.27 -> 1.04 ms, 12 images 1.06 -> 0.99).  It was 3072 while the runs shared one stream.
     static const long env_blocks = env_long("LRF_FAMILY_SPLIT_BLOCKS", -1); // test hook (lrf_env.h)
     const long min_blocks = env_blocks >= 0 ? env_blocks : (rmax_t > 16 ? 256 : 1024);
-    const bool split = !no_split && bcd_wave_variant() && rmax_t <= LRF_BIG_TO_ANY_RANK && (long)t.blocks.size() >= min_blocks;
+    return !no_split && bcd_wave_variant() && rmax_t <= LRF_BIG_TO_ANY_RANK && nblocks >= min_blocks;
+}
+std::vector<FamRun> plan_runs(const Tables& t)
+{
+    const int rmax_t = table_rmax(t);
+    const bool split = plan_splits((long)t.blocks.size(), rmax_t);
     std::vector<FamRun> runs;
     for (int p = 0; p < (int)t.planes.size(); p++) {
         const PlaneDesc& pd = t.planes[p];
         const int fam = split ? fam_of_rank(pd.R) : (rmax_t > 16 ? 2 : fam_of_rank(rmax_t));
-        if (runs.empty() || runs.back().fam != fam) runs.push_back(FamRun{p, 0, pd.blk0, 0, 1, fam, fam == 2 ? LRF_RPB : 16, pd.R, false});
+        if (runs.empty() || runs.back().fam != fam) runs.push_back(FamRun{p, 0, pd.blk0, 0, 1, fam, fam == 2 ? LRF_RPB : 16, pd.R, false, 0});
         FamRun& r = runs.back();
         r.any_native = r.any_native || pd.native_t2_u != 0;
+        if (pd.init_src == p && r.nbase == r.nplanes) r.nbase++; // (the table builders put a run's self-initialising planes first)
         r.nplanes++;
         r.nblocks += pd.nblk;
         r.rmax = pd.R > r.rmax ? pd.R : r.rmax;
@@ -225,14 +231,15 @@ int fam_join_streams(lrf_ctx* c, size_t nruns)
 static void finish_gram_chunks(Tables& t)
 {
     long rows = 0;
-    for (const PlaneDesc& pd : t.planes) rows += pd.M;
+    for (size_t pi = 0; pi < t.planes.size(); pi++)
+        if (t.planes[pi].init_src == (int)pi) rows += t.planes[pi].M; // (planes that share another's initialisation need no Gram matrix)
     int per = LRF_GRAM_ROWS;
     while (per > 384 && rows / per < 768) per >>= 1;
     t.gchunks.clear();
     for (int pi = 0; pi < (int)t.planes.size(); pi++) {
         PlaneDesc& pd = t.planes[pi];
         pd.gch0 = (int)t.gchunks.size();
-        pd.ngch = (pd.M + per - 1) / per;
+        pd.ngch = pd.init_src == pi ? (pd.M + per - 1) / per : 0;
         for (int g = 0; g < pd.ngch; g++) {
             const int row0 = g * per;
             t.gchunks.push_back(GramChunk{pi, row0, pd.gch0 + g, pd.M - row0 < per ? pd.M - row0 : per});

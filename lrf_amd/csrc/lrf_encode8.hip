@@ -52,8 +52,9 @@ static int run_init(lrf_ctx* c, const float* X, const Tables& t, const int8_t* s
         const FamRun& r = runs[ri];
         hipStream_t rs = run_stream(c, ri);
         const FamBufs fb = run_bufs(c, r, mixed);
+        if (r.nbase == 0) continue; // (a sweep call: every plane of this run takes its columns from a plane of another run)
 #define LRF_LAUNCH_INIT(ZR)                                                                                          \
-    hipLaunchKernelGGL(k_init<ZR>, dim3(r.nplanes), dim3(ZR > 8 ? 512 : 256), sizeof(InitLds<ZR>), rs, (const ulonglong2*)c->gpart.p, \
+    hipLaunchKernelGGL(k_init<ZR>, dim3(r.nbase), dim3(ZR > 8 ? 512 : 256), sizeof(InitLds<ZR>), rs, (const ulonglong2*)c->gpart.p, \
                        (const int*)c->gexp.p, gram_exp, (const PlaneDesc*)c->planes.p, sign_dev, fb.vf, fb.wf, c->init_sweeps, r.pitch, r.plane0)
         if (r.rmax <= 8) LRF_LAUNCH_INIT(8);
         else if (r.rmax <= 16) LRF_LAUNCH_INIT(16);
@@ -62,9 +63,18 @@ static int run_init(lrf_ctx* c, const float* X, const Tables& t, const int8_t* s
         LAUNCH_CHECK();
     }
     (void)rmax;
-    (void)rp;
-    (void)nplanes;
-    if (init_only_fork) return fam_join_streams(c, runs.size());
+    if (init_only_fork) {
+        int rcj = fam_join_streams(c, runs.size());
+        if (rcj) return rcj;
+    }
+    bool shares = false;
+    for (const FamRun& r : runs) shares = shares || r.nbase != r.nplanes;
+    if (shares) { // a sweep call (its entry point keeps one stream): the other ranks' planes take their columns from the base planes
+        if (c->fam_forked) return set_err(LRF_EINVAL, "internal: a call that shares initialisations between planes must not fork its families");
+        hipLaunchKernelGGL(k_init_share, dim3(nplanes), dim3(256), 0, c->stream, (const PlaneDesc*)c->planes.p, (float*)c->vf.p, (float*)c->wf.p,
+                           (float*)c->vf16.p, (float*)c->wf16.p, plan_splits((long)t.blocks.size(), table_rmax(t)) ? 1 : 0, mixed ? 1 : 0, rp);
+        LAUNCH_CHECK();
+    }
     return LRF_OK;
 }
 
@@ -426,6 +436,89 @@ int lrf_qmf_encode_rgb_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_t H, 
     c->init_parallel = !c->fam_parallel;
     rc = run_init(c, X, t, sign, LRF_PLANES_GRAM_EXP);
     c->fam_parallel = c->init_parallel = false;
+    if (rc) {
+        (void)fam_join_streams(c, 3);
+        return rc;
+    }
+    return run_bcd(c, X, t, K, lo, hi, 1, nullptr, U, V);
+}
+
+// One batch at Q rank triples in one call (BASELINE config 3: an R-D sweep of 24 images x qualities 1..32; the reference's loop
+// experiments/comparison/eval.py:83-110 calls qmf_encode once per image and quality).  What does not depend on the rank is done
+// once per image — patch matrices, exact Gram matrices — and the SVD initialisation once per (image, channel) at the largest
+// rank asked for that channel: the lower ranks take its leading columns (k_init_share).  The BCD of ALL (quality, image) pairs
+// runs as one call of Q x B "virtual images" that share X: large per-family launches, the persistent kernel from 3584 blocks.
+// Output: for q = 0..Q-1 the factors of the B images at triple q back to back, each in lrf_qmf_encode_rgb_u8's layout
+// (U: offset sum_{q' < q} B u_img(q'), image stride u_img(q) = sum_c M_c R[q][c]; V likewise with 64 R[q][c]).
+// sign: optional [B][Rmax_Y + Rmax_Cb + Rmax_Cr] int8 (component signs of the largest ranks; every triple uses its leading ones).
+int lrf_qmf_encode_sweep_rgb_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_t H, int64_t W, int Q, const int* R /*[Q][3]*/, int K, int lo,
+                                int hi, const int8_t* sign, int8_t* U, int8_t* V)
+{
+    if (!c || !rgb || !R || !U || !V) return set_err(LRF_EINVAL, "NULL argument");
+    if (B < 1 || B > 65535) return set_err(LRF_EINVAL, "B=%ld out of range [1,65535]", (long)B);
+    if (Q < 1 || Q > 4096) return set_err(LRF_EINVAL, "Q=%d out of range [1,4096]", Q);
+    LRF_ON_DEVICE(c);
+    ImageGeom g;
+    int rc = make_geom(H, W, &g);
+    if (rc) return rc;
+    int rmaxc[3] = {0, 0, 0}, qbase[3] = {0, 0, 0}, rmax_t = 0;
+    for (int q = 0; q < Q; q++)
+        for (int ch = 0; ch < 3; ch++) {
+            const int r = R[3 * q + ch];
+            if ((rc = check_params(g.p[ch].M, 64, r, K, lo, hi))) return rc;
+            if (r > LRF_BIG_TO_ANY_RANK) return set_err(LRF_ENOTSUP, "sweep call: rank %d > %d (ranks above it iterate on the any-shape kernels: one call per triple)", r, LRF_BIG_TO_ANY_RANK);
+            if (r > rmaxc[ch]) { rmaxc[ch] = r; qbase[ch] = q; }
+            rmax_t = r > rmax_t ? r : rmax_t;
+        }
+    if ((rc = ensure(c, c->x, (size_t)B * g.img_floats * sizeof(float)))) return rc;
+    // output offsets of the triples
+    std::vector<long> uq((size_t)Q + 1, 0), vq((size_t)Q + 1, 0), u_img((size_t)Q), v_img((size_t)Q);
+    for (int q = 0; q < Q; q++) {
+        u_img[q] = v_img[q] = 0;
+        for (int ch = 0; ch < 3; ch++) { u_img[q] += (long)g.p[ch].M * R[3 * q + ch]; v_img[q] += 64L * R[3 * q + ch]; }
+        uq[q + 1] = uq[q] + B * u_img[q];
+        vq[q + 1] = vq[q] + B * v_img[q];
+    }
+    // The plane table: Q x B x 3 planes on B x 3 matrices.  Order: by kernel family (so that plan_runs finds at most three runs),
+    // inside a family the planes that compute an initialisation first (run_init launches k_init for a run's leading planes), then
+    // luma before chroma; a call too small to split its families keeps one run: all initialising planes first.
+    long nblk_img = 0;
+    for (int ch = 0; ch < 3; ch++) nblk_img += (g.p[ch].M + LRF_KC - 1) / LRF_KC;
+    const bool split = plan_splits((long)Q * B * nblk_img, rmax_t);
+    const long s_img = rmaxc[0] + rmaxc[1] + rmaxc[2];
+    const long soff[3] = {0, rmaxc[0], (long)rmaxc[0] + rmaxc[1]};
+    struct Spec { int q, ch; long b; };
+    std::vector<Spec> order;
+    order.reserve((size_t)Q * B * 3);
+    for (int fam = 0; fam < (split ? 3 : 1); fam++)
+        for (int base = 1; base >= 0; base--)
+            for (int ch = 0; ch < 3; ch++)
+                for (int q = 0; q < Q; q++) {
+                    if (split && fam_of_rank(R[3 * q + ch]) != fam) continue;
+                    if ((q == qbase[ch]) != (base == 1)) continue;
+                    for (long b = 0; b < B; b++) order.push_back(Spec{q, ch, b});
+                }
+    Tables t;
+    std::vector<int> base_index((size_t)B * 3, -1);
+    for (const Spec& sp : order) {
+        const int r = R[3 * sp.q + sp.ch];
+        long uo = uq[sp.q] + sp.b * u_img[sp.q], vo = vq[sp.q] + sp.b * v_img[sp.q];
+        for (int c2 = 0; c2 < sp.ch; c2++) { uo += (long)g.p[c2].M * R[3 * sp.q + c2]; vo += 64L * R[3 * sp.q + c2]; }
+        if (sp.q == qbase[sp.ch]) base_index[(size_t)sp.b * 3 + sp.ch] = (int)t.planes.size();
+        add_plane(t, sp.b * g.img_floats + g.p[sp.ch].xoff, uo, vo, 0, 0, g.p[sp.ch].M, r, sign ? (int)(sp.b * s_img + soff[sp.ch]) : -1);
+    }
+    for (size_t pi = 0; pi < t.planes.size(); pi++) {
+        const Spec& sp = order[pi];
+        t.planes[pi].init_src = base_index[(size_t)sp.b * 3 + sp.ch];
+    }
+    if ((rc = upload_tables(c, t))) return rc;
+    float* X = (float*)c->x.p;
+    if ((rc = lrf_qmf_planes_from_rgb_u8(c, rgb, B, H, W, X))) return rc;
+    if (c->planes_done) HIP_TRY(hipEventRecord(c->planes_done, c->stream));
+    c->fam_parallel = false; // one stream: the shared initialisations tie the families together
+    c->init_parallel = true;
+    rc = run_init(c, X, t, sign, LRF_PLANES_GRAM_EXP);
+    c->init_parallel = false;
     if (rc) {
         (void)fam_join_streams(c, 3);
         return rc;

@@ -189,8 +189,11 @@ struct FamRun {
     int plane0, nplanes, block0, nblocks, rmax, fam, pitch;
     int rmin;        // smallest rank of the run (k_bcd_w32 takes runs whose ranks are all 17..32)
     bool any_native; // some plane of the run is small enough for ATen's native order of `uu @ bb` ((R-1) M < 400)
+    int nbase;       // leading planes of the run that compute their own SVD initialisation (all of them, except in a sweep call:
+                     // there the other planes take their columns from a plane of the same matrix, PlaneDesc::init_src)
 };
-inline int fam_of_rank(int R) { return R <= 8 ? 0 : (R <= 16 ? 1 : 2); }
+inline int fam_of_rank(int R) { return LRF_FAM_OF_RANK(R); }
+bool plan_splits(long nblocks, int rmax_t); // whether a call of that size gives every plane the kernel family of its own rank
 bool bcd_wave_variant();
 std::vector<FamRun> plan_runs(const Tables& t);
 bool plan_is_mixed(const std::vector<FamRun>& runs);

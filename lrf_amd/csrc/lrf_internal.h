@@ -3,6 +3,7 @@
 #define LRF_INTERNAL_H
 #include <stdint.h>
 
+#define LRF_FAM_OF_RANK(R) ((R) <= 8 ? 0 : ((R) <= 16 ? 1 : 2)) // kernel family of a rank: k_bcd_w / k_bcd_w16 / k_bcd_w32 (+ workgroup kernels)
 #define LRF_RP 16    // rank padded to one 16-wide MFMA tile (== LRF_MAX_RANK)
 #define LRF_KC 384   // rows per X^T U reduction block (the reference's MKL K-blocking)
 
@@ -55,6 +56,9 @@ struct PlaneDesc {
     int native_t2_u;   // ATen native order for `uu @ bb` in update_u: (R-1)*M < 400
     int sign_off;      // offset into the sign vector, or -1
     int gch0, ngch;    // slots in the Gram partial table (lrf_gram_kernels.hip): one per chunk of LRF_GRAM_ROWS rows
+    int init_src;      // the plane whose SVD initialisation this plane takes its first R columns from: itself, or — in a sweep
+                       // call (lrf_qmf_encode_sweep_rgb_u8) — the plane of the same matrix X with the call's largest rank
+    int pad_;
 };
 struct BlockDesc {
     int plane;         // index into the PlaneDesc table

@@ -968,6 +968,33 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8
 // only then (or never, beyond the clamp range) is the IEEE division evaluated.  Results are identical.
 #include "lrf_gs.h"
 
+// Sweep calls (lrf_qmf_encode_sweep_rgb_u8): a plane whose matrix X is also factorised at a larger rank takes the first R columns
+// of that plane's initial tables (PlaneDesc::init_src) — the top-R singular pairs are the first R of the top-R' ones, bit for bit:
+// every stage of k_init treats component r without reference to the rank asked for (its eigenvalue search, its twisted vector,
+// its Gram-Schmidt against components < r, its back-transformation and sign).  One workgroup per plane; the two planes may sit
+// in tables of different rank pitch (V16 / W16: the pitch-16 set of a call that mixes pitches; split: every plane on the family of
+// its own rank, else all on pitch rp_main).
+__global__ __launch_bounds__(256) void k_init_share(const PlaneDesc* __restrict__ planes, float* __restrict__ Vm, float* __restrict__ Wm,
+                                                    float* __restrict__ V16, float* __restrict__ W16, int split, int mixed, int rp_main)
+{
+    const int pli = blockIdx.x;
+    const PlaneDesc pd = planes[pli];
+    if (pd.init_src == pli) return;
+    const PlaneDesc ps = planes[pd.init_src];
+    const int pitch_d = split ? (LRF_FAM_OF_RANK(pd.R) == 2 ? LRF_RPB : 16) : rp_main;
+    const int pitch_s = split ? (LRF_FAM_OF_RANK(ps.R) == 2 ? LRF_RPB : 16) : rp_main;
+    float* Vd = ((mixed && pitch_d == 16) ? V16 : Vm) + (long)pli * 64 * pitch_d;
+    float* Wd = ((mixed && pitch_d == 16) ? W16 : Wm) + (long)pli * 64 * pitch_d;
+    const float* Vs = ((mixed && pitch_s == 16) ? V16 : Vm) + (long)pd.init_src * 64 * pitch_s;
+    const float* Ws = ((mixed && pitch_s == 16) ? W16 : Wm) + (long)pd.init_src * 64 * pitch_s;
+    for (int i = threadIdx.x; i < 64 * pitch_d; i += 256) {
+        const int row = i / pitch_d, col = i - row * pitch_d;
+        const bool in = col < pd.R;
+        Vd[i] = in ? Vs[row * pitch_s + col] : 0.f;
+        Wd[i] = in ? Ws[row * pitch_s + col] : 0.f;
+    }
+}
+
 // b table of the initial V (after k_init or k_load_v0): one workgroup per matrix
 __global__ __launch_bounds__(256) void k_bprep(const PlaneDesc* __restrict__ planes, const float* __restrict__ Vf,
                                                float* __restrict__ Bf, int plane0)

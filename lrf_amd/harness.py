@@ -53,22 +53,33 @@ def rd_sweep(images, qualities, encoder: Callable, decoder: Callable, **kwargs) 
     return records
 
 
-def rd_sweep_batched(images, qualities, **kwargs) -> list:
+def rd_sweep_batched(images, qualities, fused: bool = True, **kwargs) -> list:
     """The same sweep for `qmf_encode` / `qmf_decode` with all images of one size in ONE call per quality
     (`qmf_encode_batch` / `qmf_decode_batch`): images are independent, so every stream — hence bpp, PSNR, SSIM — is the one the
     per-image loop of `rd_sweep` produces (tests/test_harness_gpu.py); the times are the batch's, divided by the images.
+    `fused` (round 5; default branch only — kwargs limited to bounds / num_iters): ALL qualities in one GPU call
+    (`qmf_encode_sweep`: patch matrices, Gram matrices and the SVD initialisation once per image, the iterations of every
+    (quality, image) pair in large launches); same streams again, the encoding time is the call's divided by qualities x images.
     images: a uint8 tensor [B,3,H,W] or a sequence of [3,H,W] tensors of one size.  kwargs: qmf_encode's (bounds, num_iters,
     patch, patch_size ...) except quality / rank."""
-    from .codec import qmf_decode_batch, qmf_encode_batch
+    from .codec import qmf_decode_batch, qmf_encode_batch, qmf_encode_sweep
     stack = images if isinstance(images, torch.Tensor) and images.dim() == 4 else torch.stack(list(images))
     B = stack.shape[0]
+    qualities = list(qualities)
     records = []
-    for q in qualities:
+    all_streams, t_fused = None, 0.0
+    if fused and set(kwargs) <= {"bounds", "num_iters"} and stack.dtype == torch.uint8 and kwargs.get("num_iters", 10) >= 1:
         _sync()
         t0 = time.perf_counter()
-        streams = qmf_encode_batch(stack, quality=float(q), **kwargs)
+        all_streams = qmf_encode_sweep(stack, qualities=[float(q) for q in qualities], **kwargs)
         _sync()
-        t_enc = 1000 * (time.perf_counter() - t0) / B
+        t_fused = 1000 * (time.perf_counter() - t0) / (B * max(len(qualities), 1))
+    for qi, q in enumerate(qualities):
+        _sync()
+        t0 = time.perf_counter()
+        streams = all_streams[qi] if all_streams is not None else qmf_encode_batch(stack, quality=float(q), **kwargs)
+        _sync()
+        t_enc = t_fused if all_streams is not None else 1000 * (time.perf_counter() - t0) / B
         t0 = time.perf_counter()
         rec_all = qmf_decode_batch(streams).cpu()
         _sync()

@@ -34,3 +34,36 @@ def test_batched_sweep_on_another_patch_size():
     for r in one:
         for k in ("bit rate (bpp)", "PSNR (dB)"):
             assert r[k] == many[key(r)][k], (key(r), k)
+
+
+def test_fused_sweep_emits_the_streams_of_the_per_quality_calls():
+    """lrf_qmf_encode_sweep_rgb_u8 (one GPU call for every quality of an R-D sweep: planes / Gram matrices / SVD initialisation
+    once per image, the lower ranks taking the leading columns of the largest rank's initialisation, the iterations of all
+    (quality, image) pairs in per-family launches) against one qmf_encode_batch call per quality: byte-identical streams —
+    12 of BASELINE config 3's 512x768 images at qualities 1..32 (twenty rank triples, all three kernel families, the
+    persistent kernel: 12 x 20 x 24 = 5760 blocks), and a small call that does not split its families, with sign vectors."""
+    import hashlib
+    import lrf_amd
+    from lrf_amd.codec import qmf_ranks
+    imgs = torch.stack([config3_image(i) for i in range(12)])
+    qualities = list(range(1, 33))
+    fused = lrf_amd.qmf_encode_sweep(imgs, qualities=qualities)
+    assert len(fused) == len(qualities) and all(len(s) == imgs.shape[0] for s in fused)
+    dev = imgs.cuda()
+    seen = {}
+    for q, streams in zip(qualities, fused):
+        t = tuple(qmf_ranks(imgs.shape[-2:], None, q))
+        if t not in seen:
+            seen[t] = lrf_amd.qmf_encode_batch(dev, quality=q)
+        assert streams == seen[t], (q, t)
+    assert len(seen) >= 18
+    # explicit rank triples, a call too small to split its families (3 images of 96x160), component signs
+    small = torch.stack([config3_image(i)[:, :96, :160].contiguous() for i in (0, 5, 23)])
+    triples = [(3, 1, 2), (12, 6, 6), (21, 10, 10), (7, 3, 3)]
+    g = torch.Generator().manual_seed(3)
+    sign = (torch.randint(0, 2, (21 + 10 + 10,), generator=g) * 2 - 1).to(torch.int8)
+    fused = lrf_amd.qmf_encode_sweep(small, ranks=triples, init_sign=sign)
+    for t, streams in zip(triples, fused):
+        offs = (0, 21, 31)
+        sg = torch.cat([sign[offs[c]:offs[c] + t[c]] for c in range(3)])
+        assert streams == lrf_amd.qmf_encode_batch(small.cuda(), rank=list(t), init_sign=sg), t
