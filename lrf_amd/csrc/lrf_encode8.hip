@@ -14,6 +14,7 @@ static int run_init(lrf_ctx* c, const float* X, const Tables& t, const int8_t* s
     if (!(c->attr_done & (1u << 0))) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_init<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InitLds<8>)));
         HIP_TRY(hipFuncSetAttribute((const void*)k_init<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InitLds<16>)));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_init<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InitLds<32>)));
         HIP_TRY(hipFuncSetAttribute((const void*)k_init<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InitLds<64>)));
         c->attr_done |= 1u << 0;
     }
@@ -58,6 +59,7 @@ static int run_init(lrf_ctx* c, const float* X, const Tables& t, const int8_t* s
                        (const int*)c->gexp.p, gram_exp, (const PlaneDesc*)c->planes.p, sign_dev, fb.vf, fb.wf, c->init_sweeps, r.pitch, r.plane0)
         if (r.rmax <= 8) LRF_LAUNCH_INIT(8);
         else if (r.rmax <= 16) LRF_LAUNCH_INIT(16);
+        else if (r.rmax <= 32) LRF_LAUNCH_INIT(32);
         else LRF_LAUNCH_INIT(64);
 #undef LRF_LAUNCH_INIT
         LAUNCH_CHECK();

@@ -512,13 +512,15 @@ __global__ __launch_bounds__(256) void k_planes_strip(const uint8_t* __restrict_
 // ------------------------------------------------------------------------------------------------
 // LDS carve of k_init; ZR = 8 or 16 eigenvectors' worth of scratch (chosen on the host from the largest rank
 // of the call, so that R <= 8 batches fit three workgroups per CU)
+// (ZR = 8: 49.4 KB, three workgroups per CU; 16: 61.6 KB — one of these beside two of the former fills a CU's 160 KB, which is how
+// the luma and chroma initialisations of a (9..16, <= 8, <= 8) call run side by side; 32: 83.6 KB, one beside one ZR = 16.)
 template <int ZR>
 struct InitLds {
     double A[64 * 64];      // Gram matrix, then (row k) the Householder vector v_k
-    double D1[64 * ZR];     // twisted factorisation scratch [i][r]
+    double D1[64 * ZR];     // twisted factorisation scratch [i][r]; before that stage its first 2 KB hold `cpart`: the matvec partial
+                            // chains of the tridiagonalisation, then the (d', e'^2) table of the eigenvalue searches
     double D2[64 * ZR];
     double Z[ZR * 64];      // eigenvectors in tridiagonal coordinates, then in the original basis
-    double cpart[4 * 64];   // matvec partial chains
     double v[128], w[128], d[64], e[64], e2[64], tau[64], lam[ZR < 16 ? 16 : ZR]; // v, w: two buffers (tridiagonalisation)
     double scal[8];         // [0] t, [1] pivmin, [2] lo, [3] hi
     int flag[4];
@@ -540,6 +542,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8
     extern __shared__ __attribute__((aligned(16))) char smem[];
     InitLds<ZR>& L = *reinterpret_cast<InitLds<ZR>*>(smem);
     double* G = L.A;
+    double* cpart = L.D1; // [4][64] (2 KB of the >= 4 KB twisted-factorisation scratch, which is written two stages later)
+    static_assert(sizeof(L.D1) >= 4 * 64 * sizeof(double), "cpart lives in D1");
 
     const PlaneDesc pd = planes[pli];
     const int M = pd.M, R = pd.R;
@@ -642,13 +646,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8
                     ca = fma(Ar[jj], vj[jj], ca);
                     cb = fma(Ar[8 + jj], vj[8 + jj], cb);
                 }
-                L.cpart[wave * 64 + lane] = (lane > k) ? ca + cb : 0.0;
+                cpart[wave * 64 + lane] = (lane > k) ? ca + cb : 0.0;
             }
             __syncthreads();
             ISTAMP(s2);
             if (wave == 0) {
                 const int i = lane;
-                double p = t * (((L.cpart[i] + L.cpart[64 + i]) + L.cpart[128 + i]) + L.cpart[192 + i]);
+                double p = t * (((cpart[i] + cpart[64 + i]) + cpart[128 + i]) + cpart[192 + i]);
                 double vi = vbuf[i];
                 double K = (0.5 * t) * wave_tree64(p * vi);
                 wbuf[i] = fma(-K, vi, p);
@@ -706,7 +710,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8
     // ---- eigenvalues: Gershgorin hull, pivmin, the matrix scaled into [-1, 1] (oracle: top_eigenvalues)
     const int rmax = M < 64 ? M : 64;
     const int Rc = R < rmax ? R : rmax;
-    double2* de = reinterpret_cast<double2*>(L.cpart); // (d'_i, e'_{i-1}^2): the matvec partials are dead
+    double2* de = reinterpret_cast<double2*>(cpart); // (d'_i, e'_{i-1}^2): the matvec partials are dead
     if (wave == 0) {
         const int i = lane;
         double ei = (i < 63) ? L.e[i] : 0.0, eim = (i > 0) ? L.e[i - 1] : 0.0;
