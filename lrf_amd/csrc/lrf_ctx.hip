@@ -198,11 +198,14 @@ FamBufs run_bufs(lrf_ctx* c, const FamRun& r, bool mixed)
 }
 
 hipStream_t run_stream(lrf_ctx* c, size_t run_idx) { return (c->fam_forked && run_idx > 0) ? c->fam_stream[run_idx - 1] : c->stream; }
-int fam_fork_streams(lrf_ctx* c, size_t nruns)
+// stage_only: the fork is joined again inside the caller's stage (run_init's initialisation kernels) — kernel profiling may stay
+// on (the stage's event pair on the caller's stream encloses fork and join); a fork that lasts into run_bcd is refused while
+// profiling is on (the per-launch event pairs are recorded on the caller's stream only).
+int fam_fork_streams(lrf_ctx* c, size_t nruns, bool stage_only)
 {
     static const bool off = dev_flag("LRF_NO_FAMILY_STREAMS");
     c->fam_forked = false;
-    if (off || !c->fam_parallel || c->profile || nruns < 2 || nruns > 3) return LRF_OK;
+    if (off || !c->fam_parallel || (c->profile && !stage_only) || nruns < 2 || nruns > 3) return LRF_OK;
     if (!c->fam_fork) HIP_TRY(hipEventCreateWithFlags(&c->fam_fork, hipEventDisableTiming));
     for (size_t i = 0; i + 1 < nruns; i++) {
         if (!c->fam_stream[i]) HIP_TRY(hipStreamCreateWithFlags(&c->fam_stream[i], hipStreamNonBlocking));

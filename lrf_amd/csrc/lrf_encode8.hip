@@ -44,7 +44,7 @@ static int run_init(lrf_ctx* c, const float* X, const Tables& t, const int8_t* s
     const bool init_only_fork = !c->fam_parallel && c->init_parallel && !init_fork_off;
     if (init_only_fork) c->fam_parallel = true;
     {
-        int rcf = fam_fork_streams(c, runs.size());
+        int rcf = fam_fork_streams(c, runs.size(), init_only_fork);
         if (init_only_fork) c->fam_parallel = false;
         if (rcf) return rcf;
     }

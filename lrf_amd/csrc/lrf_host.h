@@ -203,7 +203,7 @@ struct FamBufs {
 };
 FamBufs run_bufs(lrf_ctx* c, const FamRun& r, bool mixed);
 hipStream_t run_stream(lrf_ctx* c, size_t run_idx);
-int fam_fork_streams(lrf_ctx* c, size_t nruns);
+int fam_fork_streams(lrf_ctx* c, size_t nruns, bool stage_only = false);
 int fam_join_streams(lrf_ctx* c, size_t nruns);
 
 // ---- the 64-column encoder (lrf_encode8.hip)
