@@ -454,6 +454,7 @@ def main():
     # the package would import torch)
     if os.environ.get("LRF_BENCH_NO_BIND") == "1" or rehearsal_env:
         binding = {"bound": False, "reason": "off (LRF_BENCH_NO_BIND / rehearsal)", "numa_node": -1, "cpus": _usable_cores()}
+        placement = None
     else:
         import importlib.util
         spec = importlib.util.spec_from_file_location("lrf_placement", os.path.join(ROOT, "lrf_amd", "placement.py"))
@@ -476,6 +477,13 @@ def main():
     dev_index = local_rank % n_dev if rehearsal else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    if placement is not None and binding.get("bound"):
+        # the sysfs lookup above is an inference (KFD node order = HIP device order): compare with the PCI address the runtime
+        # reports for this rank's device and undo a binding made for another GPU's NUMA node (placement.confirm_binding)
+        props = torch.cuda.get_device_properties(dev_index)
+        bus, slot, dom = (getattr(props, a, None) for a in ("pci_bus_id", "pci_device_id", "pci_domain_id"))
+        pci = "%04x:%02x:%02x.0" % (dom or 0, bus, slot or 0) if isinstance(bus, int) else (bus if isinstance(bus, str) else None)
+        binding = placement.confirm_binding(binding, pci)
     cdev = torch.device("cpu") if rehearsal else dev  # where the collective payloads live
     backend = None
     force_dist = os.environ.get("LRF_BENCH_FORCE_DIST") == "1"

@@ -21,7 +21,11 @@ ctx = lrf_amd._lib.context(0)
 LOW = (((8, 1, 5), (-16, 15), 2, 1), ((7, 3, 3), (-3, 5), 3, 1), ((1, 2, 8), (-128, 127), 5, 1), ((4, 4, 4), (-16, 15), 10, 1))
 MIX = (((16, 8, 8), (-16, 15), 10, 1), ((10, 5, 5), (-16, 15), 3, 1), ((12, 12, 12), (-8, 7), 4, 1), ((20, 10, 10), (-16, 15), 5, 1),
        ((26, 13, 13), (-16, 15), 10, 1), ((17, 8, 8), (-22, 22), 2, 1), ((32, 16, 16), (-16, 15), 3, 1), ((23, 23, 23), (-16, 15), 3, 1),
-       ((12, 6, 6), (-128, 127), 3, 0), ((20, 10, 10), (-25, 25), 3, 0))
+       ((12, 6, 6), (-128, 127), 3, 0), ((20, 10, 10), (-25, 25), 3, 0),
+       # every pair count NP = 9..16 of ranks 17..32 is an instantiation of its own (k_bcd_p<true, NP>; <true, 12> alone was
+       # miscompiled until its operand loop became a compile-time expansion): 19 / 22 / 25 / 28 / 30 with NP = 10, 11, 13, 14, 15
+       ((19, 9, 9), (-16, 15), 3, 1), ((22, 11, 11), (-16, 15), 3, 1), ((25, 12, 12), (-16, 15), 3, 1), ((28, 14, 14), (-16, 15), 3, 1),
+       ((30, 15, 15), (-16, 15), 3, 1), ((24, 12, 6), (-16, 15), 3, 1))
 for (H, W, B), cases in (((512, 768, 48), LOW + MIX),
                          ((173, 264, 272), (((5, 8, 1), (-16, 15), 4, 1), ((8, 8, 8), (-22, 22), 2, 1), ((13, 6, 9), (-16, 15), 4, 1),
                                             ((18, 9, 4), (-16, 15), 3, 1)))):

@@ -256,4 +256,4 @@ def test_persistent_kernel_other_iteration_counts_bounds_and_ranks():
     env = dict(os.environ, LRF_PERSIST="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_persist_worker.py")], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
-    assert r.stdout.count("ok ") == 18 and "persistent launches seen" in r.stdout, r.stdout
+    assert r.stdout.count("ok ") == 24 and "persistent launches seen" in r.stdout, r.stdout
