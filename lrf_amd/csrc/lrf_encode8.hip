@@ -40,6 +40,9 @@ static int run_init(lrf_ctx* c, const float* X, const Tables& t, const int8_t* s
     // families are per-matrix latency chains that leave most of a CU idle (k_init<16> 190 us for 256 luma planes, k_init<8> 180
     // us for 512 chroma planes, one round of workgroups each), and LDS admits one workgroup of the first beside two of the
     // second: forked for this stage only, the later runs (chroma: more, smaller workgroups) enqueued first, joined at once.
+    // (The order of the enqueues does not show in the step time — measured both ways at five rank triples — because the
+    // streams' queues place their workgroups side by side either way.)  Since round 5's LDS layout (InitLds) a ZR = 32 workgroup
+    // has two ZR = 16 ones beside it as well ((26,13,13): the stage 484 -> ~340 us).
     static const bool init_fork_off = dev_flag("LRF_NO_INIT_FORK");
     const bool init_only_fork = !c->fam_parallel && c->init_parallel && !init_fork_off;
     if (init_only_fork) c->fam_parallel = true;

@@ -512,28 +512,52 @@ __global__ __launch_bounds__(256) void k_planes_strip(const uint8_t* __restrict_
 // ------------------------------------------------------------------------------------------------
 // LDS carve of k_init; ZR = 8 or 16 eigenvectors' worth of scratch (chosen on the host from the largest rank
 // of the call, so that R <= 8 batches fit three workgroups per CU)
-// (ZR = 8: 49.4 KB, three workgroups per CU; 16: 61.6 KB — one of these beside two of the former fills a CU's 160 KB, which is how
-// the luma and chroma initialisations of a (9..16, <= 8, <= 8) call run side by side; 32: 83.6 KB, one beside one ZR = 16.)
+// (ZR = 8: 36.2 KB, three workgroups per CU; 16: 44.5 KB, three per CU, or one beside two ZR = 8 ones, which is how the luma and
+// chroma initialisations of a (9..16, <= 8, <= 8) call run side by side; 32: 68.6 KB, two per CU or one beside two ZR = 16 ones.)
+#define LRF_INIT_VPACK 2016 /* doubles: v_0 .. v_61 packed take 63 + 62 + ... + 2 = 2015 */
 template <int ZR>
 struct InitLds {
-    double A[64 * 64];      // Gram matrix, then (row k) the Householder vector v_k
-    double D1[64 * ZR];     // twisted factorisation scratch [i][r]; before that stage its first 2 KB hold `cpart`: the matvec partial
-                            // chains of the tridiagonalisation, then the (d', e'^2) table of the eigenvalue searches
-    double D2[64 * ZR];
-    double Z[ZR * 64];      // eigenvectors in tridiagonal coordinates, then in the original basis
+    // The Gram matrix (32 KB); once it sits in the waves' registers: the Householder vectors v_k PACKED (v_k has 63 - k entries:
+    // LRF_INIT_VPACK doubles in all, read again by the back-transformation) and, in the 16 KB behind them, as much of the
+    // twisted-factorisation scratch D1 / D2 ([i][r], 64 * ZR doubles each) as fits: both at ZR <= 16, D1 at ZR = 32 (round 5:
+    // 49 / 62 / 84 KB -> 41 / 45 / 69 KB, so that a ZR = 32 workgroup has room for two ZR = 16 ones beside it, and a CU for three
+    // ZR = 16 or two ZR = 32 ones).  D1's first 2 KB hold `cpart` first: the matvec partial chains of the tridiagonalisation, then
+    // the (d', e'^2) table of the eigenvalue searches.
+    static constexpr int kDInA = ZR <= 16 ? 2 : (ZR == 32 ? 1 : 0); // how many of D1, D2 live inside A
+    static constexpr int kDx = (2 - kDInA) * 64 * ZR;
+    static constexpr bool kZInA = ZR == 8; // (and the eigenvectors too at ZR = 8: 37 KB, three workgroups beside a ZR = 16 one)
+    double A[64 * 64];
+    double Dx[kDx > 0 ? kDx : 2];
+    double Zx[kZInA ? 2 : ZR * 64]; // eigenvectors in tridiagonal coordinates, then in the original basis
     double v[128], w[128], d[64], e[64], e2[64], tau[64], lam[ZR < 16 ? 16 : ZR]; // v, w: two buffers (tridiagonalisation)
     double scal[8];         // [0] t, [1] pivmin, [2] lo, [3] hi
     int flag[4];
+    __device__ double* Zp() { return kZInA ? A + LRF_INIT_VPACK + 2 * 64 * ZR : Zx; }
+    __device__ double* D1() { return kDInA >= 1 ? A + LRF_INIT_VPACK : Dx; }
+    __device__ double* D2() { return kDInA == 2 ? A + LRF_INIT_VPACK + 64 * ZR : (kDInA == 1 ? Dx : Dx + 64 * ZR); }
 };
+static_assert(LRF_INIT_VPACK + 3 * 64 * 8 <= 64 * 64, "ZR = 8: packed v_k + D1 + D2 + Z inside A");
+static_assert(LRF_INIT_VPACK % 2 == 0 && LRF_INIT_VPACK >= 63 * 62 / 2 + 62 && LRF_INIT_VPACK + 2 * 64 * 16 <= 64 * 64, "packed v_k + D1 + D2 inside A");
 
 // NW waves per workgroup: 4 hold the matrix during the tridiagonalisation; with NW = 8 (ranks above 8: ZR = 16 / 64, where LDS
 // leaves a CU two workgroups or one and its SIMDs mostly idle) waves 4..7 wait at the barriers of that stage and then take
 // their share of what scales with the rank — sixteen eigenvalue searches and sixteen back-transformations per round instead of
 // eight (round 5: k_init<16> 197 -> see DESIGN.md, k_init<64> at rank 26: 298 ->).  Which wave computes a vector does not change a bit of it.
-// Waves per SIMD: 3 (three 4-wave workgroups per CU at ZR = 8) or 4 (two 8-wave workgroups at ZR = 16; the bound is a maximum too:
-// with 3 a second 8-wave workgroup does not fit and 512 chroma planes of rank 13 ran in two rounds, 362 us).
+// Waves per SIMD: 3 (three 4-wave workgroups per CU at ZR = 8) or 6 (three 8-wave workgroups: 80 registers, a dozen spilled
+// dwords; the bound is a maximum too: with 3 a second 8-wave workgroup did not fit and 512 chroma planes of rank 13 ran in two
+// rounds, 362 us; with 4 — 94 registers, no spills — two fit, and the luma workgroup of a (26,13,13) call had ONE chroma
+// workgroup beside it: 256 x 512x768 at (20,10,10) 3.09 -> 2.97 ms, (26,13,13) 3.41 -> 3.28 ms with 6 and the packed LDS layout).
+#ifndef LRF_INIT_MINW4
+#define LRF_INIT_MINW4 3
+#endif
+#ifndef LRF_INIT_MINW8
+#define LRF_INIT_MINW8 6
+#endif
+#ifndef LRF_INIT_MAXW8
+#define LRF_INIT_MAXW8 6
+#endif
 template <int ZR, int NW = (ZR > 8 ? 8 : 4)>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8 ? 4 : 3, NW == 8 ? 4 : 3))) void k_init(const ulonglong2* __restrict__ Gpart, const int* __restrict__ gexp,
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8 ? LRF_INIT_MINW8 : LRF_INIT_MINW4, NW == 8 ? LRF_INIT_MAXW8 : 4))) void k_init(const ulonglong2* __restrict__ Gpart, const int* __restrict__ gexp,
                                               int fixed_exp, const PlaneDesc* __restrict__ planes,
                                               const int8_t* __restrict__ sign, float* __restrict__ Vf,
                                               float* __restrict__ Wf, int debug_stop, int rp, int plane0 /* first plane of this launch's run */)
@@ -542,8 +566,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8
     extern __shared__ __attribute__((aligned(16))) char smem[];
     InitLds<ZR>& L = *reinterpret_cast<InitLds<ZR>*>(smem);
     double* G = L.A;
-    double* cpart = L.D1; // [4][64] (2 KB of the >= 4 KB twisted-factorisation scratch, which is written two stages later)
-    static_assert(sizeof(L.D1) >= 4 * 64 * sizeof(double), "cpart lives in D1");
+    double* const Zs = L.Zp();
+    double* cpart = L.D1(); // [4][64] (2 KB of the >= 4 KB twisted-factorisation scratch, which is written two stages later)
+    static_assert(64 * ZR >= 4 * 64, "cpart lives in D1");
 
     const PlaneDesc pd = planes[pli];
     const int M = pd.M, R = pd.R;
@@ -590,8 +615,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8
 
     // ---- Householder tridiagonalisation (oracle: tridiagonalize).  The matrix lives in registers: thread (lane i,
     // wave g) holds A[16g + jj][i] (= A[i][16g + jj], the matrix stays exactly symmetric), jj = 0..15.  The LDS copy of
-    // the Gram matrix is dead from here on and its rows are reused for the Householder vectors v_k (read again by the
-    // back-transformation).  Terms the oracle skips (j <= k) are fma(a, 0, c) = c here: v_k[j] = 0 there.
+    // the Gram matrix is dead from here on and its space is reused for the Householder vectors v_k (read again by the
+    // back-transformation) and the scratch of the later stages (InitLds).  Terms the oracle skips (j <= k) are fma(a, 0, c) = c here: v_k[j] = 0 there.
     d16 Ar; // a vector, not an array: row k is picked with a wave-uniform register index (s_set_gpr_idx), not 15 selects
     const int wrow = wave & 3; // (waves 4..7 of an eight-wave workgroup hold nothing: they only keep the barriers of this stage)
 #pragma unroll
@@ -625,7 +650,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8
                 ek = alpha;
             }
             vbuf[i] = vi;
-            if (i > k) G[k * 64 + i] = vi; // row k of the LDS matrix: v_k for the back-transformation
+            if (i > k) G[(62 * k - ((k * (k - 1)) >> 1) - 1) + i] = vi; // v_k, packed (InitLds), for the back-transformation
             if (i == 0) { L.tau[k] = 0.0; L.e[k] = ek; L.scal[0] = hk; L.flag[k & 1] = (sigma > LRF_SIGMA_TINY); }
         }
         __syncthreads();
@@ -836,8 +861,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8
         const int r = tid & 63;
         const bool fwd = tid < 64, mine = tid < 128 && r < Rc;
         const double lam = mine ? L.lam[r] : 0.0, pivmin = L.scal[1];
-        double* Dp = L.D1 + r;
-        double* Dm = L.D2 + r;
+        double* Dp = L.D1() + r;
+        double* Dm = L.D2() + r;
         if (mine && fwd) {
             double q = L.d[0] - lam;
             Dp[0] = q;
@@ -864,7 +889,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8
                 double g = fabs((Dp[i * ZR] + Dm[i * ZR]) - (L.d[i] - lam));
                 if (i == 0 || g < best) { best = g; kt = i; }
             }
-            double* x = L.Z + r * 64;
+            double* x = Zs + r * 64;
             double xv = 1.0;
             if (fwd) {
                 x[kt] = 1.0;
@@ -891,7 +916,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8
     if (wave == 0) {
         const int i = lane;
         for (int r = 0; r < Rc; r++) {
-            double x = L.Z[r * 64 + i];
+            double x = Zs[r * 64 + i];
             bool use_twisted = __all(isfinite(x));
             int uidx = 0;
             for (;;) {
@@ -904,7 +929,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8
                     uidx++;
                 }
                 for (int pr = 0; pr < r; pr++) {
-                    double pv = L.Z[pr * 64 + i];
+                    double pv = Zs[pr * 64 + i];
                     double c = wave_tree64(pv * x);
                     x = fma(-c, pv, x);
                 }
@@ -915,7 +940,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8
                 }
                 use_twisted = false;
             }
-            L.Z[r * 64 + i] = x;
+            Zs[r * 64 + i] = x;
         }
     }
     __syncthreads();
@@ -931,23 +956,23 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8
         const int i = lane;
         const int r1 = r0 + NW;
         const bool two = r1 < Rc; // wave-uniform
-        double xa = L.Z[r0 * 64 + i], xb = two ? L.Z[r1 * 64 + i] : 0.0;
+        double xa = Zs[r0 * 64 + i], xb = two ? Zs[r1 * 64 + i] : 0.0;
         for (int k = 61; k >= 0; k--) {
             double tk = L.tau[k];
             if (tk == 0.0) continue;
-            double v = (i > k) ? G[k * 64 + i] : 0.0;
+            double v = (i > k) ? G[(62 * k - ((k * (k - 1)) >> 1) - 1) + i] : 0.0; // (packed: InitLds)
             double sa = tk * wave_tree64(v * xa);
             double sb = tk * wave_tree64(v * xb);
             xa = fma(-sa, v, xa);
             xb = fma(-sb, v, xb);
         }
-        L.Z[r0 * 64 + i] = xa;
-        if (two) L.Z[r1 * 64 + i] = xb;
+        Zs[r0 * 64 + i] = xa;
+        if (two) Zs[r1 * 64 + i] = xb;
       for (int half = 0; half < (two ? 2 : 1); half++) {
         const int r = half ? r1 : r0;
         const double x = half ? xb : xa;
         double dot = 0.0;
-        for (int j = 0; j < 64; j++) dot = fma((double)(j + 1), L.Z[r * 64 + j], dot); // every lane: same chain
+        for (int j = 0; j < 64; j++) dot = fma((double)(j + 1), Zs[r * 64 + j], dot); // every lane: same chain
         double lam = L.lam[r];
         double sigma = sqrt(lam > 1e-200 ? lam : 0.0); // noise-floor eigenvalues count as zero (oracle: same)
         double sr = sqrt(sigma);
