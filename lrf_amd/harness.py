@@ -34,6 +34,7 @@ def eval_compression(image, encoder: Callable, decoder: Callable, reconstruct: b
         "bit rate (bpp)": bits_per_pixel(image.shape[-2:], encoded),
         "PSNR (dB)": psnr(image, reconstructed).item(),
         "SSIM": ssim(image, reconstructed).item(),
+        "SSIM pinned to scikit-image": False,  # (metrics.ssim: a restatement; scikit-image is absent)
         "encoding time (ms)": encoding_time,
         "decoding time (ms)": decoding_time,
     }
@@ -91,6 +92,7 @@ def rd_sweep_batched(images, qualities, fused: bool = True, **kwargs) -> list:
                 "bit rate (bpp)": bits_per_pixel(image.shape[-2:], encoded),
                 "PSNR (dB)": psnr(image, reconstructed).item(),
                 "SSIM": ssim(image, reconstructed).item(),
+                "SSIM pinned to scikit-image": False,
                 "encoding time (ms)": t_enc,
                 "decoding time (ms)": t_dec,
                 "image": idx,
