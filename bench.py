@@ -347,8 +347,8 @@ def sweep_leg(torch, lrf_amd, _lib, ctx, images, H, W, steps=10):
         p_ms, p_n = ctx.kernel_time(_lib.LRF_K_BCD_PERSIST)
         ctx.profile(False)
         alg = n * (sum(d[4] for d in dims) * 64 * 4 + sum(d[4] * r for d, r in zip(dims, ranks)))  # one U-update pass over all planes
-        if p_n:  # iterations 2..K in one launch
-            kname, k_ms, k_bytes = "k_bcd_p", p_ms / p_n, (NUM_ITERS - 1) * alg
+        if p_n:  # iterations 2..K in one launch — or all K of them (ranks <= 16: no U-update launch of its own is left)
+            kname, k_ms, k_bytes = "k_bcd_p", p_ms / p_n, (NUM_ITERS - (1 if bcd_n else 0)) * alg
         else:  # one U-update launch per iteration (a call of several rank families: their launches of an iteration together)
             kname, k_ms, k_bytes = "k_bcd (launch per iteration)", bcd_ms / bcd_n, alg
         out.append({"workload": label, "ranks": list(ranks), "images": n, "ms_per_step": round(dt * 1e3, 4),
@@ -631,9 +631,11 @@ def main():
             traffic = None
             tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
             if bcdp_launches:
-                # iterations 2..K run in ONE launch (k_bcd_p: the U-update passes pulled from a queue, the V updates inside):
-                # algorithmic bytes of that launch = (K - 1) passes
-                passes = NUM_ITERS - 1
+                # the iterations run in ONE launch (k_bcd_p: the U-update passes pulled from a queue, the V updates inside):
+                # all K of them since round 5 (no k_bcd launch is seen then), iterations 2..K before; algorithmic bytes of that
+                # launch = that many passes
+                first_inside = bcd_launches == 0
+                passes = NUM_ITERS if first_inside else NUM_ITERS - 1
                 bcd_ms = bcdp_total_ms / bcdp_launches  # live, from the timed regions (rank 0's GPU)
                 achieved = passes * alg_bytes / (bcd_ms * 1e-3) / 1e9
                 if args.config == "kodak" and B == 256 and os.path.exists(tfile):
@@ -648,9 +650,11 @@ def main():
                         "traffic_source": ("profiles/traffic_latest.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                            "command on the same sources (tools/run_profiles_r04.sh, tools/make_traffic.py) — a committed "
                                            "measurement, not collected in this run") if traffic is not None else None,
-                        "note": "k_bcd_p = iterations 2..%d in one launch (%d U-update passes of %d B each + the per-matrix V updates, "
-                                "which the launch-per-iteration path ran as k_vupdate); the first iteration is k_bcd_w<1>: "
-                                "%.5f ms per launch" % (NUM_ITERS, passes, alg_bytes, bcd_total_ms / max(bcd_launches, 1))}
+                        "note": ("k_bcd_p = iterations 1..%d in one launch (%d U-update passes of %d B each + the per-matrix V updates, "
+                                 "which the launch-per-iteration path ran as k_vupdate)" % (NUM_ITERS, passes, alg_bytes)) if first_inside else
+                                ("k_bcd_p = iterations 2..%d in one launch (%d U-update passes of %d B each + the per-matrix V updates, "
+                                 "which the launch-per-iteration path ran as k_vupdate); the first iteration is k_bcd_w<1>: "
+                                 "%.5f ms per launch" % (NUM_ITERS, passes, alg_bytes, bcd_total_ms / max(bcd_launches, 1)))}
             else:
                 bcd_ms = bcd_total_ms / bcd_launches  # live, from the timed regions (rank 0's GPU)
                 achieved = alg_bytes / (bcd_ms * 1e-3) / 1e9
@@ -697,10 +701,10 @@ def main():
             # 75.1 algorithmic bytes per input pixel for the whole encode at K = 10
             "whole_encode_frac_of_hbm_peak": round(75.1 * total_px / world / dt / 8e12, 4) if args.config != "svd" else None,
             "kernels": {k: {a: round(b, 5) for a, b in v.items()} for k, v in kern.items()},
-            "kernels_note": "per-kernel breakdown from a separate untimed pass with every launch bracketed by events (k_bcd = the "
-                            "first iteration's launch, k_bcd_persist = iterations 2..K in one launch where k_bcd_p runs; the V "
-                            "updates of those iterations happen inside it); roofline.avg_launch_ms is measured inside the timed "
-                            "regions (events on the BCD launches only)",
+            "kernels_note": "per-kernel breakdown from a separate untimed pass with every launch bracketed by events (k_bcd_persist = "
+                            "the iterations in one launch where k_bcd_p runs — all K of them at ranks <= 16, the V updates inside; "
+                            "k_bcd / k_vupdate appear only where an iteration is a launch of its own); roofline.avg_launch_ms is "
+                            "measured inside the timed regions (events on the BCD launches only)",
         }
         out["ranks"] = rank_stats
         out["forced_dist"] = force_dist

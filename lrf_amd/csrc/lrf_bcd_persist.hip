@@ -1,5 +1,6 @@
-// lrf_bcd_persist.hip — iterations 2..K of a large call of the 64-column path in ONE launch (k_bcd_p<F16, NP32>,
-// lrf_bcdp_kernel.hip): which calls take it (bcdp_plan) and its launch (bcdp_launch: queue state, error word, grid).
+// lrf_bcd_persist.hip — the iterations of a large call of the 64-column path in ONE launch (k_bcd_p<F16, NP32, FIRST>,
+// lrf_bcdp_kernel.hip: iterations 2..K, or all K at ranks <= 16): which calls take it (bcdp_plan) and its launch (bcdp_launch:
+// queue state, error word, grid).
 // lrf/factorization/qmf.py:93-139, 197-214 (the num_iters loop).
 #include "lrf_host.h"
 #include "lrf_gs.h"
@@ -45,27 +46,32 @@ PersistPlan bcdp_plan(lrf_ctx* c, const std::vector<FamRun>& runs, int K, int lo
     pp.use = true;
     pp.f16 = f16 || np32 != 0; // (the instantiations with ranks 17..32 carry the 9..16 body too: their chroma planes)
     pp.np32 = np32;
+    // the call's first iteration inside the launch too (k_bcd_p<.., 0, true>): ranks <= 16 only — the caller adds its own
+    // conditions (the old U comes from the initialisation's W0, run_bcd)
+    static const bool first_off = dev_flag("LRF_NO_PERSIST_FIRST");
+    pp.first = np32 == 0 && !first_off;
     return pp;
 }
 
-template <bool F16, int NP32>
+template <bool F16, int NP32, bool FIRST = false>
 static int bcdp_launch_t(lrf_ctx* c, int attr_bit, int wgs, int wave_lds, const float* X, const PlaneDesc* pl, const BlockDesc* bl, int nblocks,
                          int nplanes, int plane0, const BcdpTabs& t16, const BcdpTabs& t64, int8_t* U, int8_t* V, GsParams gp, int niter)
 {
     if (!(c->attr_persist & (1u << attr_bit))) {
-        HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_p<F16, NP32>, hipFuncAttributeMaxDynamicSharedMemorySize, LRF_BCDW_WAVES * wave_lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_bcd_p<F16, NP32, FIRST>, hipFuncAttributeMaxDynamicSharedMemorySize, LRF_BCDW_WAVES * wave_lds));
         c->attr_persist |= 1u << attr_bit;
     }
     Prof p(c, LRF_K_BCD_PERSIST);
-    hipLaunchKernelGGL((k_bcd_p<F16, NP32>), dim3((unsigned)wgs), dim3(64 * LRF_BCDW_WAVES), (size_t)LRF_BCDW_WAVES * wave_lds, c->stream, X, pl, bl, t16,
+    hipLaunchKernelGGL((k_bcd_p<F16, NP32, FIRST>), dim3((unsigned)wgs), dim3(64 * LRF_BCDW_WAVES), (size_t)LRF_BCDW_WAVES * wave_lds, c->stream, X, pl, bl, t16,
                        t64, U, V, gp, nblocks, niter, nplanes, plane0, (BcdpSync*)c->psync.p, c->h_perr, 2 * nplanes, ++c->pseq, wave_lds);
     LAUNCH_CHECK();
     return LRF_OK;
 }
 
 int bcdp_launch(lrf_ctx* c, const PersistPlan& pp, const float* X, const PlaneDesc* pl, const BlockDesc* bl, int nblocks, int nplanes, int plane0,
-                const FamBufs& f16, const FamBufs& f64, int8_t* U, int8_t* V, GsParams gp, int niter)
+                const FamBufs& f16, const FamBufs& f64, int8_t* U, int8_t* V, GsParams gp, int niter, bool first)
 {
+    if (first && (!pp.first || pp.np32 != 0)) return set_err(LRF_EINVAL, "internal: first iteration inside k_bcd_p with ranks above 16");
     if (!c->h_perr) {
         HIP_TRY(hipHostMalloc((void**)&c->h_perr, sizeof(int), hipHostMallocDefault));
         *c->h_perr = 0;
@@ -86,11 +92,15 @@ int bcdp_launch(lrf_ctx* c, const PersistPlan& pp, const float* X, const PlaneDe
     // LDS per wave: the largest share a family of the call needs
     int wave_lds = (64 * 64 + 64 * 8) * 4; // ranks <= 8 (LRF_BCDW_LDS / LRF_BCDW_WAVES)
     if (pp.f16 && LRF_BCDW16_WAVE_LDS > wave_lds) wave_lds = LRF_BCDW16_WAVE_LDS;
-    const BcdpTabs t16{f16.vf, f16.bf, f16.pp, f16.qp}, t64{f64.vf, f64.bf, f64.pp, f64.qp};
+    const BcdpTabs t16{f16.vf, f16.bf, f16.pp, f16.qp, f16.wf}, t64{f64.vf, f64.bf, f64.pp, f64.qp, f64.wf};
     gp.exact_int = 1;
 #define LRF_P(F16, NP, BIT)                                                                                                          \
     return bcdp_launch_t<F16, NP>(c, BIT, (int)wgs, NP ? (LRF_BCDW32_WAVE_LDS(NP) > wave_lds ? LRF_BCDW32_WAVE_LDS(NP) : wave_lds) : wave_lds, X, pl, bl, \
                                   nblocks, nplanes, plane0, t16, t64, U, V, gp, niter)
+    if (first) { // (niter = K: item iteration 0 is the call's first iteration)
+        if (!pp.f16) return bcdp_launch_t<false, 0, true>(c, 10, (int)wgs, wave_lds, X, pl, bl, nblocks, nplanes, plane0, t16, t64, U, V, gp, niter);
+        return bcdp_launch_t<true, 0, true>(c, 11, (int)wgs, wave_lds, X, pl, bl, nblocks, nplanes, plane0, t16, t64, U, V, gp, niter);
+    }
     if (!pp.f16) LRF_P(false, 0, 0);
     switch (pp.np32) {
     case 0: LRF_P(true, 0, 1);

@@ -1,5 +1,6 @@
-// lrf_bcdp_kernel.hip — k_bcd_p<F16, NP32>: iterations 2..K of a large call in ONE launch, for every rank family of the 64-column
-// path (round 4: ranks <= 8; round 5: the planes of ranks 9..16 and 17..32 and their mixes — (16,8,8), (26,13,13), ... — too).
+// lrf_bcdp_kernel.hip — k_bcd_p<F16, NP32, FIRST>: the iterations of a large call in ONE launch, for every rank family of the
+// 64-column path (round 4: ranks <= 8, iterations 2..K; round 5: the planes of ranks 9..16 and 17..32 and their mixes — (16,8,8),
+// (26,13,13), ... — too, and, FIRST, at ranks <= 16 the call's first iteration as well: all K in the launch).
 // Included by lrf_bcd_persist.hip after the block bodies it repeats operation for operation — ranks <= 8: k_bcd_w<0>
 // (lrf_bcdw_kernel.hip; restated here with sc1 accesses, bcdp_w_block), 9..16: w16_block (lrf_bcdw16_kernel.hip), 17..32:
 // w32_block (lrf_bcdw32_kernel.hip) — so the outputs are bit-identical to the launch-per-iteration path.
@@ -45,6 +46,7 @@ struct BcdpSync {
 // the tables of one rank pitch: 16 (ranks <= 16: LRF_RP, gt pitch LRF_GT_LD) or 64 (ranks 17..32: LRF_RPB, LRF_GTB_LD)
 struct BcdpTabs {
     float *vf, *bf, *pp, *qp;
+    const float* wf; // the initialisation's W0 = V0 / sigma (k_bcd_p<.., .., true>: the first iteration's old U is X @ W0)
 };
 
 __device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -339,8 +341,11 @@ __device__ __forceinline__ void bcdp_vupdate32(const PlaneDesc& pd, int pli, con
 // ---- ranks <= 8: one (matrix, 384-row block) on one wave — k_bcd_w<0> (lrf_bcdw_kernel.hip) operation for operation, with the
 // V table, the b table, the old int8 rows and the partial tables reached through sc1 accesses.  Xs: the wave's LDS share
 // (X tile 16 KB, then the fp32 u tile 2 KB).
+// MODE 1 (round 5, k_bcd_p<.., .., true>): the call's FIRST iteration, k_bcd_w<1> — the old U is X @ W0 (the initialisation's
+// table Wf, written before the launch), no int8 rows are read.
+template <int MODE>
 __device__ __forceinline__ void bcdp_w_block(const float* __restrict__ X, const PlaneDesc& pd, const BlockDesc& bd, const float* __restrict__ Vf,
-                                             const float* __restrict__ Bf, int8_t* __restrict__ U, float* __restrict__ Ppart,
+                                             const float* __restrict__ Wf, const float* __restrict__ Bf, int8_t* __restrict__ U, float* __restrict__ Ppart,
                                              float* __restrict__ Qpart, const GsParams& gp, float* Xs, const int lane)
 {
     constexpr int RMAX = 8;
@@ -363,11 +368,14 @@ __device__ __forceinline__ void bcdp_w_block(const float* __restrict__ X, const 
     const int nsub = (nrows + 63) >> 6;
     const bool native = pd.native_t2_u != 0;
 
-    float vreg[8][4];
+    float vreg[8][4], wreg[MODE == 1 ? 8 : 1][4];
 #pragma unroll
     for (int r = 0; r < 8; r++)
 #pragma unroll
-        for (int kb = 0; kb < 4; kb++) vreg[r][kb] = ld_sc1(Vp + (16 * kb + li) * LRF_RP + r);
+        for (int kb = 0; kb < 4; kb++) {
+            vreg[r][kb] = ld_sc1(Vp + (16 * kb + li) * LRF_RP + r);
+            if constexpr (MODE == 1) wreg[r][kb] = Wf[((long)bd.plane * 64 + 16 * kb + li) * LRF_RP + r];
+        }
     float tab[5];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -421,7 +429,7 @@ __device__ __forceinline__ void bcdp_w_block(const float* __restrict__ X, const 
 #pragma unroll
     for (int c = 0; c < 4; c++) accP[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    issue_u(0);
+    if constexpr (MODE == 0) issue_u(0);
     issue_x(0, 0, 4, true);
     for (int t = 0; t < nsub; t++) {
         const int r0 = t * 64;
@@ -435,7 +443,7 @@ __device__ __forceinline__ void bcdp_w_block(const float* __restrict__ X, const 
             }
         float u[RMAX];
         const int row = r0 + lane;
-        {
+        if constexpr (MODE == 0) {
             unsigned lo, hi;
             row_bytes(lo, hi);
 #pragma unroll
@@ -446,7 +454,9 @@ __device__ __forceinline__ void bcdp_w_block(const float* __restrict__ X, const 
         }
         const int tn = t + 1;
         const bool more = tn < nsub;
-        if (more) issue_u(tn);
+        if constexpr (MODE == 0) {
+            if (more) issue_u(tn);
+        }
         issue_x(tn, 0, 2, more);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -456,6 +466,11 @@ __device__ __forceinline__ void bcdp_w_block(const float* __restrict__ X, const 
 #pragma unroll
         for (int r = 0; r < RMAX; r++) a[r] = 0.f;
         row_times_v_dispatch(R, xrow, g16, vreg, a);
+        if constexpr (MODE == 1) {
+#pragma unroll
+            for (int r = 0; r < RMAX; r++) u[r] = 0.f;
+            row_times_v_dispatch(R, xrow, g16, wreg, u);
+        }
         issue_x(tn, 2, 3, more);
         __builtin_amdgcn_sched_barrier(0);
         gs_regs_dispatch<RMAX>(R, a, u, tab, native, gp);
@@ -530,7 +545,10 @@ __device__ __forceinline__ void bcdp_w_block(const float* __restrict__ X, const 
 // F16: planes of ranks 9..16 may occur (w16_block); NP32 > 0: planes of ranks 2 NP32 - 1 / 2 NP32 (17..32) may occur
 // (w32_block<NP32>).  t16 / t64: the table sets of the two rank pitches (a call without ranks above 16 has only t16).
 // wave_lds: bytes of LDS per wave (the largest share a family of the call needs; the V updates fit the smallest).
-template <bool F16, int NP32>
+// FIRST (round 5; only without ranks above 16): item iteration 0 is the call's FIRST iteration — the bodies of k_bcd_w<1> /
+// k_bcd_w16<1>, old U = X @ W0 from the initialisation's tables, which are complete before the launch: no flag to wait for —,
+// so that the launch covers all K iterations and the call has no U-update or V-update launch of its own.
+template <bool F16, int NP32, bool FIRST = false>
 __global__ __launch_bounds__(64 * LRF_BCDW_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_bcd_p(
     const float* __restrict__ X, const PlaneDesc* __restrict__ planes, const BlockDesc* __restrict__ blocks, const BcdpTabs t16,
     const BcdpTabs t64, int8_t* __restrict__ U, int8_t* __restrict__ V8, GsParams gp, int nblocks, int niter, int nplanes, int plane0,
@@ -608,9 +626,21 @@ __global__ __launch_bounds__(64 * LRF_BCDW_WAVES) __attribute__((amdgpu_waves_pe
         int ln = lane;
         asm volatile("" : "+v"(ln));
         const int fam = (!F16 || pd.R <= 8) ? 0 : ((NP32 == 0 || pd.R <= 16) ? 1 : 2);
-        if (fam == 0) bcdp_w_block(X, pd, bd, t16.vf, t16.bf, U, t16.pp, t16.qp, gp, Xs, ln);
+        static_assert(!FIRST || NP32 == 0, "the first iteration of ranks 17..32 stays a launch of its own (k_bcd_w32f)");
+        const bool first = FIRST && it == 0; // wave-uniform
+        if (fam == 0) {
+            if (first) {
+                if constexpr (FIRST) bcdp_w_block<1>(X, pd, bd, t16.vf, t16.wf, t16.bf, U, t16.pp, t16.qp, gp, Xs, ln);
+            } else
+                bcdp_w_block<0>(X, pd, bd, t16.vf, nullptr, t16.bf, U, t16.pp, t16.qp, gp, Xs, ln);
+        }
         if constexpr (F16) {
-            if (fam == 1) w16_block<0, MemSc1>(X, pd, bd, t16.vf, nullptr, t16.bf, U, t16.pp, t16.qp, gp, Xs, ln);
+            if (fam == 1) {
+                if (first) {
+                    if constexpr (FIRST) w16_block<1, MemSc1>(X, pd, bd, t16.vf, t16.wf, t16.bf, U, t16.pp, t16.qp, gp, Xs, ln);
+                } else
+                    w16_block<0, MemSc1>(X, pd, bd, t16.vf, nullptr, t16.bf, U, t16.pp, t16.qp, gp, Xs, ln);
+            }
         }
         if constexpr (NP32 > 0) {
             if (fam == 2) w32_block<NP32, MemSc1>(X, pd, bd, t64.vf, t64.bf, U, t64.pp, t64.qp, gp, Xs, ln, 0);
@@ -650,7 +680,7 @@ __global__ __launch_bounds__(64 * LRF_BCDW_WAVES) __attribute__((amdgpu_waves_pe
             // the compiler thread lane 0 through both and retire it from the loop alone — lanes 1..63 then went on with item 0)
 #ifdef LRF_BCDP_TEST_SKIP_FLAG // tests/test_persist_error.py, tools/dev_persist_expiry.py: in a call of FOUR iterations matrix 0 never
                                // publishes its first V update, its later blocks' polls expire; other calls of that build work
-            if (!(pl == 0 && it == 0 && niter == 3))
+            if (!(pl == 0 && it == (FIRST ? 1 : 0) && niter == (FIRST ? 4 : 3)))
 #endif
             __hip_atomic_store(&flag[pl], it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }

@@ -140,15 +140,19 @@ static int run_bcd(lrf_ctx* c, const float* X, const Tables& t, int K, int lo, i
     // and planes pulled from a queue, each matrix's V update done by the last of its blocks to finish (bcdp_plan says which
     // calls).  Such a call never forks its families onto streams (plan_fam_parallel).
     const PersistPlan persist = bcdp_plan(c, runs, K, lo, hi);
+    // ... and the first iteration as well when its old U is X @ W0 of the initialisation just run (first_mode 1) and no plane of
+    // ranks 9..16 is small enough for ATen's native order (bcdp_plan has checked that already): then the b tables above are
+    // the last launch before k_bcd_p.
+    const bool persist_first = persist.use && persist.first && first_mode == 1;
     for (int it = 0; it < K; it++) {
-        if (persist.use && it == 1) {
+        if (persist.use && it == (persist_first ? 0 : 1)) {
             const FamRun& r0 = runs.front();
             long nb = 0, np = 0;
             for (const FamRun& r : runs) { nb += r.nblocks; np += r.nplanes; }
             // the table sets of the two rank pitches (run_bufs): a call without ranks above 16 has only the pitch-16 one
             FamBufs f16{nullptr, nullptr, nullptr, nullptr, nullptr}, f64 = f16;
             for (const FamRun& r : runs) (r.pitch == 16 ? f16 : f64) = run_bufs(c, r, mixed);
-            int rcp = bcdp_launch(c, persist, X, pl, bl + r0.block0, (int)nb, (int)np, r0.plane0, f16, f64, U, V, gp, K - 1);
+            int rcp = bcdp_launch(c, persist, X, pl, bl + r0.block0, (int)nb, (int)np, r0.plane0, f16, f64, U, V, gp, persist_first ? K : K - 1, persist_first);
             if (rcp) return rcp;
             break;
         }

@@ -242,10 +242,11 @@ struct PersistPlan {
     bool use = false;
     bool f16 = false; // planes of ranks 9..16 occur
     int np32 = 0;     // pairs of rank columns of the planes of ranks 17..32 (0: none)
+    bool first = false; // the launch may carry the call's first iteration too (ranks <= 16)
 };
 PersistPlan bcdp_plan(lrf_ctx* c, const std::vector<FamRun>& runs, int K, int lo, int hi);
 int bcdp_launch(lrf_ctx* c, const PersistPlan& pp, const float* X, const PlaneDesc* pl, const BlockDesc* bl, int nblocks, int nplanes, int plane0,
-                const FamBufs& t16, const FamBufs& t64, int8_t* U, int8_t* V, GsParams gp, int niter);
+                const FamBufs& t16, const FamBufs& t64, int8_t* U, int8_t* V, GsParams gp, int niter, bool first);
 
 // ---- the any-shape path (lrf_any.hip: other patch sizes, patch=False, the RGB colour space, ranks 33..64 of the 64-column path)
 int any_workspace(lrf_ctx* c, int B, int M, int N, int R);
