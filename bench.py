@@ -648,7 +648,7 @@ def main():
                         "algorithmic_bytes_per_launch": passes * alg_bytes, "avg_launch_ms": round(bcd_ms, 5),
                         "launches_measured": bcdp_launches,
                         "traffic_source": ("profiles/traffic_latest.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                           "command on the same sources (tools/run_profiles_r04.sh, tools/make_traffic.py) — a committed "
+                                           "command on the same sources (tools/run_profiles_r05.sh, tools/make_traffic.py) — a committed "
                                            "measurement, not collected in this run") if traffic is not None else None,
                         "note": ("k_bcd_p = iterations 1..%d in one launch (%d U-update passes of %d B each + the per-matrix V updates, "
                                  "which the launch-per-iteration path ran as k_vupdate)" % (NUM_ITERS, passes, alg_bytes)) if first_inside else
@@ -668,7 +668,7 @@ def main():
                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(bcd_ms, 5),
                         "launches_measured": bcd_launches,
                         "traffic_source": ("profiles/traffic_latest.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                           "command on the same sources (tools/run_profiles_r04.sh, tools/make_traffic.py) — a committed "
+                                           "command on the same sources (tools/run_profiles_r05.sh, tools/make_traffic.py) — a committed "
                                            "measurement, not collected in this run") if traffic is not None else None}
         out = {
             "metric": metric,

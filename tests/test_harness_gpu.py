@@ -67,3 +67,27 @@ def test_fused_sweep_emits_the_streams_of_the_per_quality_calls():
         offs = (0, 21, 31)
         sg = torch.cat([sign[offs[c]:offs[c] + t[c]] for c in range(3)])
         assert streams == lrf_amd.qmf_encode_batch(small.cuda(), rank=list(t), init_sign=sg), t
+
+
+def test_fused_sweep_entry_point_edges():
+    """lrf_qmf_encode_sweep_rgb_u8 through the context binding: one triple = the plain call; repeated triples and a triple whose
+    chroma rank is the largest of the call; an odd-sized image (padded planes, k_planes_strip); K = 1 and K = 2; what it refuses."""
+    import lrf_amd
+    from lrf_amd import _lib
+    ctx = _lib.context(0)
+    g = torch.Generator().manual_seed(11)
+    for (B, H, W), triples, K in (((5, 64, 96), [(7, 3, 3)], 10), ((3, 77, 131), [(2, 5, 1), (2, 5, 1), (9, 2, 4), (1, 1, 17)], 2),
+                                  ((2, 48, 48), [(6, 6, 6), (3, 3, 3)], 1)):
+        base = torch.rand(B, 3, H // 4 + 1, W // 4 + 1, generator=g) * 255
+        imgs = (torch.nn.functional.interpolate(base, size=(H, W), mode="bilinear", align_corners=False)
+                + torch.randn(B, 3, H, W, generator=g) * 5).clamp(0, 255).to(torch.uint8).cuda()
+        got = ctx.encode_sweep_rgb(imgs, triples, K, -16, 15)
+        assert len(got) == len(triples)
+        for t, (U, V) in zip(triples, got):
+            Ur, Vr = lrf_amd.qmf_factorize_batch(imgs, t, num_iters=K)
+            assert torch.equal(U, Ur) and torch.equal(V, Vr), ((B, H, W), t, K)
+    with pytest.raises(_lib.LrfError):
+        ctx.encode_sweep_rgb(imgs, [(33, 3, 3)], 10, -16, 15)  # ranks above 32: one call per triple (any-shape kernels)
+    with pytest.raises(_lib.LrfError):
+        ctx.encode_sweep_rgb(imgs, [(3, 3, 3)], 0, -16, 15)  # K = 0: lrf_qmf_svd_init_f32
+    ctx.check()
