@@ -201,7 +201,7 @@ int lrf_qmf_encode_rgb_u8(lrf_ctx* ctx, const uint8_t* rgb, int64_t B, int64_t H
  * What does not depend on the rank is computed once per image (patch matrices, exact Gram matrices), the SVD initialisation
  * once per (image, channel) at the largest rank asked for that channel — the lower ranks take its leading columns, which are
  * the same singular pairs bit for bit — and the BCD of all (triple, image) pairs runs as one call of Q x B matrices sets that
- * share X (large launches per rank family; the persistent kernel from 3584 blocks).  Every (triple, image) result is
+ * share X (large launches per rank family; the persistent kernel from 3584 blocks, 2304 for one rank family).  Every (triple, image) result is
  * byte-identical to lrf_qmf_encode_rgb_u8's for that triple.
  *   R     [Q][3] ranks (Y, Cb, Cr) per triple, each 1..32 (larger ranks: one lrf_qmf_encode_rgb_u8 call per triple)
  *   sign  optional [B][Rmax_Y + Rmax_Cb + Rmax_Cr] int8 (Rmax_c = the largest rank of channel c over the triples): the signs

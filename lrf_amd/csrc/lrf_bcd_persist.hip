@@ -16,8 +16,10 @@
 //     2^24; ranks 17..32: that and 64 mx^2 <= 32767, one pair count NP for all such planes; no plane of ranks above 8 small
 //     enough for ATen's native order of `uu @ bb`;
 //   * the call has LRF_PERSIST_MIN_BLOCKS blocks or more (256 x 512x768 at ranks <= 8: 2.05 -> 1.92 ms per step; 48 / 64 such
-//     images lose 15 %: a round and a half of the 2048 wave slots; tools/dev_persist_threshold.py).  LRF_PERSIST=0 turns it
-//     off, =1 lowers the threshold to LRF_BCDW_MIN_BLOCKS (tests).
+//     images lose 15 %: a round and a half of the 2048 wave slots; tools/dev_persist_threshold.py) — from
+//     LRF_PERSIST_MIN_BLOCKS_ONE_FAMILY when all planes are of one rank family (96 x 512x768: (7,3,3) 0.96 -> 0.92 ms, (12,12,12)
+//     1.25 -> 1.13, (20,20,20) 1.83 -> 1.72; calls that mix families lose at 96 and 128 images: tools/run_r05_o.sh).
+//     LRF_PERSIST=0 turns it off, =1 lowers the threshold to LRF_BCDW_MIN_BLOCKS (tests).
 PersistPlan bcdp_plan(lrf_ctx* c, const std::vector<FamRun>& runs, int K, int lo, int hi)
 {
     PersistPlan pp;
@@ -42,7 +44,8 @@ PersistPlan bcdp_plan(lrf_ctx* c, const std::vector<FamRun>& runs, int K, int lo
             np32 = np;
         }
     }
-    if (nblocks < (persist_env == 1 ? LRF_BCDW_MIN_BLOCKS : LRF_PERSIST_MIN_BLOCKS)) return pp;
+    const long min_blocks = runs.size() == 1 ? LRF_PERSIST_MIN_BLOCKS_ONE_FAMILY : LRF_PERSIST_MIN_BLOCKS;
+    if (nblocks < (persist_env == 1 ? LRF_BCDW_MIN_BLOCKS : min_blocks)) return pp;
     pp.use = true;
     pp.f16 = f16 || np32 != 0; // (the instantiations with ranks 17..32 carry the 9..16 body too: their chroma planes)
     pp.np32 = np32;

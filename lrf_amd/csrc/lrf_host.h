@@ -27,7 +27,8 @@
 #define LRF_TABLE_SETS 6 // descriptor-table sets a context keeps resident (upload_tables)
 #define LRF_BCDW_MIN_BLOCKS 1024 // smaller rank <= 8 runs iterate on the workgroup kernel k_bcd (run_bcd)
 #define LRF_BCDW16_MIN_BLOCKS 1024 // likewise for rank <= 16 runs and k_bcd_w16
-#define LRF_PERSIST_MIN_BLOCKS 3584 // a rank <= 8 call of this many blocks runs its iterations 2..K in one launch (k_bcd_p)
+#define LRF_PERSIST_MIN_BLOCKS 3584 // a call of this many blocks runs its iterations in one launch (k_bcd_p) ...
+#define LRF_PERSIST_MIN_BLOCKS_ONE_FAMILY 2304 // ... of this many when all its planes are of one rank family (lrf_bcd_persist.hip)
 #define LRF_BCDW32_MIN_BLOCKS 128  // likewise for rank 17..32 runs and k_bcd_w32 / k_bcd_w32f (12 images: 1.06 -> 0.99 ms at (20,10,10))
 
 int set_err(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));

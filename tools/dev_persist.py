@@ -1,6 +1,6 @@
 """The persistent iteration kernel k_bcd_p against the launch-per-iteration path (LRF_PERSIST=0): factors' hashes (after one and
 after 26 runs) and ms per batch for a few rank triples / batch sizes.  Run once with LRF_PERSIST=0 and once with LRF_PERSIST=1
-(forced from 1024 blocks on) or unset (the default: from 3584 blocks) and compare the lines; LRF_SOAK=n repeats the first case n
+(forced from 1024 blocks on) or unset (the default: from 3584 blocks; 2304 for one rank family) and compare the lines; LRF_SOAK=n repeats the first case n
 times and checks every result against the first."""
 import hashlib, os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
