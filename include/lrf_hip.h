@@ -82,8 +82,9 @@ int lrf_ctx_trim(lrf_ctx* ctx);
 #define LRF_K_VUPDATE 3      /* V update                       */
 #define LRF_K_DECODE 4       /* factors -> rgb                 */
 #define LRF_K_GRAM 5         /* exact Gram matrices (input of the SVD initialisation) */
-#define LRF_K_BCD_PERSIST 6  /* iterations 2..K of a large rank <= 8 call in ONE launch (k_bcd_p: U updates + V updates) */
-#define LRF_K_COUNT 7
+#define LRF_K_BCD_PERSIST 6  /* the iterations of a large call in ONE launch (k_bcd_p: U updates + V updates) */
+#define LRF_K_PLANES_GRAM 7  /* rgb -> patch matrices + the luma planes' exact Gram partials in one kernel (k_planes16_gram: large calls) */
+#define LRF_K_COUNT 8
 int lrf_ctx_profile(lrf_ctx* ctx, int enable);
 /* The same for a subset of the kernels: bit (1 << LRF_K_x) per kernel id, 0 = off.  An event pair costs a few
  * microseconds of stream time per launch (0.15 ms per 22-launch encode when every kernel is timed); bench.py times

@@ -10,9 +10,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblrf_hip.so")
 
 LRF_MAX_RANK = 64
-LRF_K_PLANES, LRF_K_INIT, LRF_K_BCD, LRF_K_VUPDATE, LRF_K_DECODE, LRF_K_GRAM, LRF_K_BCD_PERSIST = range(7)
+LRF_K_PLANES, LRF_K_INIT, LRF_K_BCD, LRF_K_VUPDATE, LRF_K_DECODE, LRF_K_GRAM, LRF_K_BCD_PERSIST, LRF_K_PLANES_GRAM = range(8)
 KERNEL_NAMES = {LRF_K_PLANES: "k_planes", LRF_K_GRAM: "k_gram", LRF_K_INIT: "k_init", LRF_K_BCD: "k_bcd",
-                LRF_K_VUPDATE: "k_vupdate", LRF_K_DECODE: "k_decode", LRF_K_BCD_PERSIST: "k_bcd_persist"}
+                LRF_K_VUPDATE: "k_vupdate", LRF_K_DECODE: "k_decode", LRF_K_BCD_PERSIST: "k_bcd_persist",
+                LRF_K_PLANES_GRAM: "k_planes_gram"}
 
 _lib = None
 _lock = threading.Lock()

@@ -238,15 +238,27 @@ static void finish_gram_chunks(Tables& t)
         if (t.planes[pi].init_src == (int)pi) rows += t.planes[pi].M; // (planes that share another's initialisation need no Gram matrix)
     int per = LRF_GRAM_ROWS;
     while (per > 384 && rows / per < 768) per >>= 1;
+    // the fused planes (k_planes16_gram: two workgroups per CU, 512 of them a round): chunks of LRF_GRAM_ROWS_FUSED rows
+    long rows_f = 0;
+    for (size_t pi = 0; pi < t.planes.size(); pi++)
+        if (t.planes[pi].init_src == (int)pi && t.planes[pi].gram_fused) rows_f += t.planes[pi].M;
+    int per_f = LRF_GRAM_ROWS_FUSED;
+    while (per_f > 384 && rows_f / per_f < 768) per_f >>= 1;
+    const int per_k = per;
     t.gchunks.clear();
-    for (int pi = 0; pi < (int)t.planes.size(); pi++) {
-        PlaneDesc& pd = t.planes[pi];
-        pd.gch0 = (int)t.gchunks.size();
-        pd.ngch = pd.init_src == pi ? (pd.M + per - 1) / per : 0;
-        for (int g = 0; g < pd.ngch; g++) {
-            const int row0 = g * per;
-            t.gchunks.push_back(GramChunk{pi, row0, pd.gch0 + g, pd.M - row0 < per ? pd.M - row0 : per});
+    for (int pass = 0; pass < 2; pass++) { // the chunks of k_gram64 first, then those the planes kernel computes (k_planes16_gram)
+        per = pass ? per_f : per_k;
+        for (int pi = 0; pi < (int)t.planes.size(); pi++) {
+            PlaneDesc& pd = t.planes[pi];
+            if ((pd.gram_fused != 0) != (pass == 1)) continue;
+            pd.gch0 = (int)t.gchunks.size();
+            pd.ngch = pd.init_src == pi ? (pd.M + per - 1) / per : 0;
+            for (int g = 0; g < pd.ngch; g++) {
+                const int row0 = g * per;
+                t.gchunks.push_back(GramChunk{pi, row0, pd.gch0 + g, pd.M - row0 < per ? pd.M - row0 : per});
+            }
         }
+        if (pass == 0) t.ngram_rest = (int)t.gchunks.size();
     }
 }
 

@@ -4,6 +4,7 @@
 #include "lrf_host.h"
 #include "lrf_gram_kernels.hip"
 #include "lrf_kernels.hip"
+#include "lrf_planes_gram_kernel.hip"
 #include "lrf_bcdw_kernel.hip"
 #include "lrf_bcdw16_kernel.hip"
 
@@ -25,13 +26,18 @@ static int run_init(lrf_ctx* c, const float* X, const Tables& t, const int8_t* s
             hipLaunchKernelGGL(k_gram_exponent, dim3(nplanes), dim3(256), 0, c->stream, X, (const PlaneDesc*)c->planes.p, (int*)c->gexp.p);
             LAUNCH_CHECK();
         }
-        if (gram_exp == LRF_PLANES_GRAM_EXP)
-            hipLaunchKernelGGL(k_gram64<true>, dim3((unsigned)t.gchunks.size()), dim3(256), 0, c->stream, X, (const PlaneDesc*)c->planes.p,
-                               (const GramChunk*)c->gchunks.p, (const int*)c->gexp.p, gram_exp, (ulonglong2*)c->gpart.p);
-        else
-            hipLaunchKernelGGL(k_gram64<false>, dim3((unsigned)t.gchunks.size()), dim3(256), 0, c->stream, X, (const PlaneDesc*)c->planes.p,
-                               (const GramChunk*)c->gchunks.p, (const int*)c->gexp.p, gram_exp, (ulonglong2*)c->gpart.p);
-        LAUNCH_CHECK();
+        // (t.ngram_rest: all chunks, or — behind k_planes16_gram, which has written the luma planes' partials itself — the chroma ones)
+        if (t.ngram_rest != (int)t.gchunks.size() && gram_exp != LRF_PLANES_GRAM_EXP)
+            return set_err(LRF_EINVAL, "internal: fused Gram partials exist only for the planes of qmf_encode");
+        if (t.ngram_rest > 0) {
+            if (gram_exp == LRF_PLANES_GRAM_EXP)
+                hipLaunchKernelGGL(k_gram64<true>, dim3((unsigned)t.ngram_rest), dim3(256), 0, c->stream, X, (const PlaneDesc*)c->planes.p,
+                                   (const GramChunk*)c->gchunks.p, (const int*)c->gexp.p, gram_exp, (ulonglong2*)c->gpart.p);
+            else
+                hipLaunchKernelGGL(k_gram64<false>, dim3((unsigned)t.ngram_rest), dim3(256), 0, c->stream, X, (const PlaneDesc*)c->planes.p,
+                                   (const GramChunk*)c->gchunks.p, (const int*)c->gexp.p, gram_exp, (ulonglong2*)c->gpart.p);
+            LAUNCH_CHECK();
+        }
     }
     Prof p(c, LRF_K_INIT);
     const std::vector<FamRun> runs = plan_runs(t);
@@ -238,6 +244,36 @@ static bool plan_fam_parallel(lrf_ctx* c, const Tables& t, int K, int lo, int hi
 // ---- C ABI ------------------------------------------------------------------------------------
 extern "C" {
 
+} // extern "C"
+
+// Whether an encode call forms its patch matrices with k_planes16_gram (lrf_planes_gram_kernel.hip): the sizes and alignment
+// k_planes16 asks for, and a batch of two full rounds of that kernel's workgroups or more (1024 chunks of LRF_GRAM_ROWS_FUSED luma
+// rows = 256 x 512x768).  The kernel is bound by the SUM of what its two halves issue — on a SIMD the int8 MFMAs of the Gram
+// blocks and the vector instructions of the colour conversion and the digit extraction do not overlap — so all it saves is the
+// re-read of the luma matrices: 256 x 512x768: 238 + 67 us (the chroma planes' k_gram64) against 146 + 183; below that size the
+// two-kernel form is as fast or faster (128 images: +15 us), tools/run_r05_p.sh / _q.sh / _r.sh.
+// The caller marks the luma planes that compute an initialisation `gram_fused` before the tables are uploaded, and calls
+// planes_gram_from_rgb instead of lrf_qmf_planes_from_rgb_u8.
+bool planes_gram_eligible(const uint8_t* rgb, int64_t B, int64_t H, int64_t W)
+{
+    static const bool off = dev_flag("LRF_NO_FUSED_GRAM") || dev_flag("LRF_PLANES_NO_TILED");
+    static const long min_chunks = env_long("LRF_FUSED_GRAM_MIN_CHUNKS", 1024); // test hook (lrf_env.h): 1 = every eligible call
+    if (off || H % 16 != 0 || W % 16 != 0 || (reinterpret_cast<uintptr_t>(rgb) & 7) != 0 || (long)H * W * 3 >= (1L << 31)) return false;
+    return min_chunks <= 1 || B * (H / 8) * (W / 8) >= min_chunks * LRF_GRAM_ROWS_FUSED; // (luma rows of the call)
+}
+int planes_gram_from_rgb(lrf_ctx* c, const uint8_t* rgb, int64_t H, int64_t W, const ImageGeom& g, const Tables& t, float* X)
+{
+    const int nfused = (int)t.gchunks.size() - t.ngram_rest;
+    if (nfused < 1) return set_err(LRF_EINVAL, "internal: no plane is marked for k_planes16_gram");
+    Prof p(c, LRF_K_PLANES_GRAM);
+    hipLaunchKernelGGL(k_planes16_gram, dim3((unsigned)nfused), dim3(256), 0, c->stream, rgb, (int)H, (int)W, g, X, (const PlaneDesc*)c->planes.p,
+                       (const GramChunk*)c->gchunks.p + t.ngram_rest, (ulonglong2*)c->gpart.p);
+    LAUNCH_CHECK();
+    return LRF_OK;
+}
+
+extern "C" {
+
 int lrf_qmf_planes_from_rgb_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_t H, int64_t W, float* X)
 {
     if (!c || !rgb || !X) return set_err(LRF_EINVAL, "NULL argument");
@@ -385,7 +421,7 @@ int lrf_qmf_svd_init_f32(lrf_ctx* c, const float* X, int64_t B, int64_t M, int64
 } // extern "C"
 
 int encode_rgb_prepare(lrf_ctx* c, int64_t B, int64_t H, int64_t W, const int R[3], int K, int lo, int hi, bool with_sign,
-                              EncodePlan& ep)
+                       bool fuse_gram /* planes_gram_eligible(rgb, H, W): the luma planes' Gram partials come from k_planes16_gram */, EncodePlan& ep)
 {
     if (B < 1 || B > 65535) return set_err(LRF_EINVAL, "B=%ld out of range [1,65535]", (long)B);
     int rc = make_geom(H, W, &ep.g);
@@ -408,10 +444,12 @@ int encode_rgb_prepare(lrf_ctx* c, int64_t B, int64_t H, int64_t W, const int R[
         ep.v0c[ch + 1] = ep.v0c[ch] + B * 64L * R[ch];
     }
     for (int ch = 0; ch < 3; ch++)
-        for (int64_t b = 0; b < B; b++)
+        for (int64_t b = 0; b < B; b++) {
             add_plane(ep.t, b * g.img_floats + g.p[ch].xoff, b * ep.u_img + ep.uoff[ch], b * ep.v_img + ep.voff[ch],
                       ep.u0c[ch] + b * (long)g.p[ch].M * R[ch], ep.v0c[ch] + b * 64L * R[ch], g.p[ch].M, R[ch],
                       with_sign ? (int)(b * s_img + soff[ch]) : -1);
+            if (fuse_gram && ch == 0) ep.t.planes.back().gram_fused = 1;
+        }
     return upload_tables(c, ep.t);
 }
 
@@ -423,14 +461,15 @@ int lrf_qmf_encode_rgb_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64_t H, 
     if (!c || !rgb || !R || !U || !V) return set_err(LRF_EINVAL, "NULL argument");
     LRF_ON_DEVICE(c);
     EncodePlan ep;
-    int rc = encode_rgb_prepare(c, B, H, W, R, K, lo, hi, sign != nullptr, ep);
+    const bool fuse = planes_gram_eligible(rgb, B, H, W);
+    int rc = encode_rgb_prepare(c, B, H, W, R, K, lo, hi, sign != nullptr, fuse, ep);
     if (rc) return rc;
     const ImageGeom& g = ep.g;
     Tables& t = ep.t;
     const long u_img = ep.u_img, v_img = ep.v_img;
     const long *uoff = ep.uoff, *voff = ep.voff, *u0c = ep.u0c, *v0c = ep.v0c;
     float* X = (float*)c->x.p;
-    if ((rc = lrf_qmf_planes_from_rgb_u8(c, rgb, B, H, W, X))) return rc;
+    if ((rc = fuse ? planes_gram_from_rgb(c, rgb, H, W, g, t, X) : lrf_qmf_planes_from_rgb_u8(c, rgb, B, H, W, X))) return rc;
     if (c->planes_done) HIP_TRY(hipEventRecord(c->planes_done, c->stream)); // the RGB bytes are not read again
     if (table_rmax(t) > LRF_BIG_TO_ANY_RANK) {
         float *U0, *V0;
@@ -516,13 +555,15 @@ int lrf_qmf_encode_sweep_rgb_u8(lrf_ctx* c, const uint8_t* rgb, int64_t B, int64
         if (sp.q == qbase[sp.ch]) base_index[(size_t)sp.b * 3 + sp.ch] = (int)t.planes.size();
         add_plane(t, sp.b * g.img_floats + g.p[sp.ch].xoff, uo, vo, 0, 0, g.p[sp.ch].M, r, sign ? (int)(sp.b * s_img + soff[sp.ch]) : -1);
     }
+    const bool fuse = planes_gram_eligible(rgb, B, H, W);
     for (size_t pi = 0; pi < t.planes.size(); pi++) {
         const Spec& sp = order[pi];
         t.planes[pi].init_src = base_index[(size_t)sp.b * 3 + sp.ch];
+        if (fuse && sp.ch == 0 && t.planes[pi].init_src == (int)pi) t.planes[pi].gram_fused = 1; // one luma plane per image
     }
     if ((rc = upload_tables(c, t))) return rc;
     float* X = (float*)c->x.p;
-    if ((rc = lrf_qmf_planes_from_rgb_u8(c, rgb, B, H, W, X))) return rc;
+    if ((rc = fuse ? planes_gram_from_rgb(c, rgb, H, W, g, t, X) : lrf_qmf_planes_from_rgb_u8(c, rgb, B, H, W, X))) return rc;
     if (c->planes_done) HIP_TRY(hipEventRecord(c->planes_done, c->stream));
     c->fam_parallel = false; // one stream: the shared initialisations tie the families together
     c->init_parallel = true;

@@ -7,6 +7,7 @@
 //   LRF_BCDW16_MIN_BLOCKS / LRF_BCDW32_MIN_BLOCKS  blocks from which the wave kernels of ranks 9..16 / 17..32 run
 //   LRF_DEBUG_INIT_SWEEPS    stops k_init after a stage / forces the Sturm replacement loop       (tests/test_hip_parity.py)
 //   LRF_PIPE_BULK / LRF_PIPE_TAIL  the pipe's piece sizes                                          (tests/test_pipeline.py)
+//   LRF_FUSED_GRAM_MIN_CHUNKS  from how many luma Gram chunks on k_planes16_gram forms the patch matrices (tests/test_fused_gram.py)
 //
 // Developer comparison switches (LRF_PLANES_NO_TILED, LRF_BCD_WG, LRF_NO_BCDW32, LRF_ANY_*, ...: the kernels a later one
 // replaced, kept for A/B timing) exist only in a -DLRF_DEV build (`make -C lrf_amd/csrc dev` -> liblrf_hip_dev.so): in

@@ -169,7 +169,8 @@ int make_geom(int64_t H, int64_t W, ImageGeom* g);
 struct Tables {
     std::vector<PlaneDesc> planes;
     std::vector<BlockDesc> blocks;
-    std::vector<GramChunk> gchunks;
+    std::vector<GramChunk> gchunks; // the chunks k_gram64 computes first, then those of the gram_fused planes (k_planes16_gram)
+    int ngram_rest = 0;             // how many of them k_gram64 computes (finish_gram_chunks)
 };
 
 void add_plane(Tables& t, long x_off, long u_off, long v_off, long u0_off, long v0_off, int M, int R, int sign_off);
@@ -216,7 +217,9 @@ struct EncodePlan {
     Tables t;
     long u_img = 0, v_img = 0, uoff[3], voff[3], u0c[4] = {0, 0, 0, 0}, v0c[4] = {0, 0, 0, 0};
 };
-int encode_rgb_prepare(lrf_ctx* c, int64_t B, int64_t H, int64_t W, const int R[3], int K, int lo, int hi, bool with_sign, EncodePlan& ep);
+int encode_rgb_prepare(lrf_ctx* c, int64_t B, int64_t H, int64_t W, const int R[3], int K, int lo, int hi, bool with_sign, bool fuse_gram,
+                       EncodePlan& ep);
+bool planes_gram_eligible(const uint8_t* rgb, int64_t B, int64_t H, int64_t W);
 
 // ---- kernels of other translation units behind launch functions ---------------------------------------------------------
 // one BCD half-iteration of a run (U update + partials of the V update): what every family's kernel takes

@@ -21,6 +21,7 @@
 #define LRF_GTB_STRIDE (LRF_RPB * LRF_GTB_LD)
 // the exact Gram pass (lrf_gram_kernels.hip)
 #define LRF_GRAM_ROWS 1536            // rows per chunk: 24 blocks of 64
+#define LRF_GRAM_ROWS_FUSED 1536 // rows per Gram chunk of a plane whose partials k_planes16_gram computes
 #define LRF_GRAM_PAIRS 10             // upper-triangle pairs of the four 16-column tiles
 #define LRF_GRAM_SLOT (LRF_GRAM_PAIRS * 256) // 128-bit sums per partial, [pair][reg][lane]
 #define LRF_GRAM_EXP_FROM_DATA (-100000)
@@ -58,7 +59,7 @@ struct PlaneDesc {
     int gch0, ngch;    // slots in the Gram partial table (lrf_gram_kernels.hip): one per chunk of LRF_GRAM_ROWS rows
     int init_src;      // the plane whose SVD initialisation this plane takes its first R columns from: itself, or — in a sweep
                        // call (lrf_qmf_encode_sweep_rgb_u8) — the plane of the same matrix X with the call's largest rank
-    int pad_;
+    int gram_fused;    // 1: a luma plane whose Gram partials the planes kernel itself computes (k_planes16_gram); k_gram64 skips it
 };
 struct BlockDesc {
     int plane;         // index into the PlaneDesc table

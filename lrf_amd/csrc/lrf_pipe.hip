@@ -238,7 +238,8 @@ int lrf_pipe_qmf_encode_submit(lrf_pipe* p, const uint8_t* rgb_host, int64_t B, 
         if (seen.size() <= LRF_TABLE_SETS) // (more sizes than table sets: the calls below upload as they go, still correct)
             for (int64_t nb : seen) {
                 EncodePlan ep;
-                if ((rc = encode_rgb_prepare(s.ctx, nb, H, W, R, K, lo, hi, sign_host != nullptr, ep))) return rc;
+                if ((rc = encode_rgb_prepare(s.ctx, nb, H, W, R, K, lo, hi, sign_host != nullptr, planes_gram_eligible((const uint8_t*)s.rgb.p, nb, H, W), ep)))
+                    return rc;
             }
     }
     // upload of sub-batch i: on the upload stream, once the planes kernel of the sub-batch that used the slot before has read
