@@ -1,12 +1,12 @@
-# round 5: time line of a step with k_planes16_gram (dev library)
+# round 5: k_planes16_gram with and without the compiler's packed fp32 math (variant noslp: lrf_encode8 built with -fno-slp-vectorize)
 set -e
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r05_q
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r05_t
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for v in 0 1; do
-  export LRF_NO_FUSED_GRAM=$v
-  rocprofv3 --kernel-trace --output-format csv -d $OUT/tr -o run -- python3 $GRAFT_REPO_ROOT/tools/dev_lib_rank.py ${LIBQ:-liblrf_hip_dev.so} 7,3,3 256 > $OUT/tr.log 2>&1
+for lib in liblrf_hip.so liblrf_hip_noslp.so; do
+  rocprofv3 --kernel-trace --output-format csv -d $OUT/tr -o run -- python3 $GRAFT_REPO_ROOT/tools/dev_lib_rank.py $lib 7,3,3 256 > $OUT/tr_$lib.log 2>&1
   f=$(find $OUT/tr -name 'run_kernel_trace.csv' | head -1)
+  echo "== $lib"; tail -1 $OUT/tr_$lib.log
   python3 - $f <<'PY'
 import csv, sys, re, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
