@@ -1,3 +1,4 @@
+#pragma once
 // lrf_anyshape_kernels.hip — QMF for matrices of any shape [M, N] and any rank: the branches of qmf_encode that do not
 // produce 64-column patch matrices (lrf/compression/qmf.py:227-286 with patch_size = (4,4), (16,16), (32,32) — the sweep of
 // experiments/ablation_patchsize/eval.py:49-55 — and patch=False, where X is the whole plane [H, W]).

@@ -1,3 +1,4 @@
+#pragma once
 // lrf_bcdp_kernel.hip — k_bcd_p<F16, NP32, FIRST>: the iterations of a large call in ONE launch, for every rank family of the
 // 64-column path (round 4: ranks <= 8, iterations 2..K; round 5: the planes of ranks 9..16 and 17..32 and their mixes — (16,8,8),
 // (26,13,13), ... — too, and, FIRST, at ranks <= 16 the call's first iteration as well: all K in the launch).

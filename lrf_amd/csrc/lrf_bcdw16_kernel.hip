@@ -1,3 +1,4 @@
+#pragma once
 // lrf_bcdw16_kernel.hip — k_bcd_w16: the BCD half-iteration (U update + partials of the V update) of iterations >= 2 for
 // ranks up to 16 with one *wave* per (matrix, 384-row block) and no workgroup barrier — k_bcd_w's shape for the rank
 // family 9..16 (lrf/factorization/qmf.py:93-126, 128-139).  Included by lrf_api.hip after lrf_bcdw_kernel.hip.

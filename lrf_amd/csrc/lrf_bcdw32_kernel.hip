@@ -1,3 +1,4 @@
+#pragma once
 // lrf_bcdw32_kernel.hip — k_bcd_w32: the BCD half-iteration (U update + partials of the V update) of iterations >= 2 for
 // ranks 17..32 with one *wave* per (matrix, 384-row block) and no workgroup barrier — k_bcd_w16's frame for the rank
 // family the reference's quality sweep reaches beyond quality 25 (lrf/factorization/qmf.py:93-126, 128-139;

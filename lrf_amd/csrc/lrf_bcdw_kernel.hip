@@ -1,3 +1,4 @@
+#pragma once
 // lrf_bcdw_kernel.hip — k_bcd_w: the BCD half-iteration (U update + partials of the V update) for ranks <= 8 with
 // one *wave* per (matrix, 384-row block) and no workgroup barrier at all.  Included by lrf_api.hip after lrf_kernels.hip.
 //

@@ -1,3 +1,4 @@
+#pragma once
 // lrf_bigrank_kernels.hip — table layouts and helpers shared by the kernels for ranks above 16 (rank pitch 64): the gt table of
 // b = v.mT @ v, its builder, the generic ordered Gauss-Seidel terms (ATen-native order of tiny matrices), the LDS carve of the
 // V update.  The kernels themselves: lrf_midrank_kernels.hip (ranks 17..32); ranks 33..64 run their iterations on the

@@ -1,3 +1,4 @@
+#pragma once
 // lrf_gram_kernels.hip — the exact Gram matrix G = X^T X of the 64-column path (input of the SVD initialisation,
 // lrf/factorization/qmf.py:42-48), on the int8 matrix cores.  Included by lrf_api.hip after lrf_kernels.hip.
 //
@@ -26,6 +27,7 @@
 
 #define LRF_GRAM_BITS 35
 
+#ifndef LRF_GRAM_DEVICE_ONLY // (a second translation unit takes the device functions below without this kernel: lrf_planes_gram.hip)
 // E with max|x| < 2^E per matrix, from the largest magnitude's bit pattern (oracle: lrf_oracle_gram_exponent)
 __global__ __launch_bounds__(256) void k_gram_exponent(const float* __restrict__ X, const PlaneDesc* __restrict__ planes,
                                                        int* __restrict__ gexp)
@@ -48,6 +50,8 @@ __global__ __launch_bounds__(256) void k_gram_exponent(const float* __restrict__
         gexp[blockIdx.x] = mx ? (int)(mx >> 23) - 126 : 0;
     }
 }
+
+#endif
 
 // five signed 7-bit digits of n = clamp(rint(x * scale)), one per byte lane `b` of the packed operand dwords
 __device__ __forceinline__ void gram_digits(float x, double scale, unsigned (&pk)[5], int b)

@@ -219,7 +219,8 @@ struct EncodePlan {
 };
 int encode_rgb_prepare(lrf_ctx* c, int64_t B, int64_t H, int64_t W, const int R[3], int K, int lo, int hi, bool with_sign, bool fuse_gram,
                        EncodePlan& ep);
-bool planes_gram_eligible(const uint8_t* rgb, int64_t B, int64_t H, int64_t W);
+bool planes_gram_eligible(const uint8_t* rgb, int64_t B, int64_t H, int64_t W); // lrf_planes_gram.hip
+int planes_gram_from_rgb(lrf_ctx* c, const uint8_t* rgb, int64_t H, int64_t W, const ImageGeom& g, const Tables& t, float* X);
 
 // ---- kernels of other translation units behind launch functions ---------------------------------------------------------
 // one BCD half-iteration of a run (U update + partials of the V update): what every family's kernel takes

@@ -1,3 +1,4 @@
+#pragma once
 // lrf_kernels.hip — gfx950 (MI355X, CDNA4) kernels of the QMF hot path.
 //
 // Compiled with -ffp-contract=off: every fused multiply-add below is explicit, because the int8

@@ -1,3 +1,4 @@
+#pragma once
 // lrf_midrank_kernels.hip — the BCD half-iteration (U update + partials of the V update) for ranks 17..32, the part of
 // the reference's quality sweep (experiments/comparison/eval.py:83: linspace(0, 40, 80)) beyond quality 25.  Included by
 // lrf_api.hip after lrf_bigrank_kernels.hip, whose table layouts (rank pitch LRF_RPB = 64, gt pitch LRF_GTB_LD) and V

@@ -1,3 +1,4 @@
+#pragma once
 // lrf_planes_gram_kernel.hip — k_planes16_gram: k_planes16 (patch matrices of images whose sides are multiples of 16,
 // lrf/compression/utils.py:24-47,76-95,108-132; qmf.py:43-56) and the LUMA half of k_gram64 (the exact Gram matrix, input of the
 // SVD initialisation, lrf/factorization/qmf.py:42-48) in one kernel.  Included by lrf_encode8.hip after lrf_gram_kernels.hip and

@@ -1,3 +1,4 @@
+#pragma once
 // lrf_svd_kernels.hip — the SVD baseline codec (lrf.svd_encode / svd_decode, default RGB branch) on gfx950.
 //
 // Reference: lrf/compression/svd.py:156-193 (encode), :310-326 (decode), lrf/compression/utils.py:185-243
