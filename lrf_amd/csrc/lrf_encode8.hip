@@ -16,6 +16,9 @@ static int run_init(lrf_ctx* c, const float* X, const Tables& t, const int8_t* s
         HIP_TRY(hipFuncSetAttribute((const void*)k_init<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InitLds<16>)));
         HIP_TRY(hipFuncSetAttribute((const void*)k_init<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InitLds<32>)));
         HIP_TRY(hipFuncSetAttribute((const void*)k_init<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InitLds<64>)));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_init<16, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InitLds<16>)));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_init<32, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InitLds<32>)));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_init<64, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InitLds<64>)));
         c->attr_done |= 1u << 0;
     }
     int rmax = table_rmax(t), rp = table_rp(t), nplanes = (int)t.planes.size();
@@ -56,19 +59,28 @@ static int run_init(lrf_ctx* c, const float* X, const Tables& t, const int8_t* s
         if (init_only_fork) c->fam_parallel = false;
         if (rcf) return rcf;
     }
+    long ninit = 0;
+    for (const FamRun& r : runs) ninit += r.nbase;
+    const bool dense = ninit > 256; // more initialisation workgroups than CUs (k_init's DENSE)
     for (size_t rj = 0; rj < runs.size(); rj++) {
         const size_t ri = init_only_fork ? runs.size() - 1 - rj : rj;
         const FamRun& r = runs[ri];
         hipStream_t rs = run_stream(c, ri);
         const FamBufs fb = run_bufs(c, r, mixed);
         if (r.nbase == 0) continue; // (a sweep call: every plane of this run takes its columns from a plane of another run)
-#define LRF_LAUNCH_INIT(ZR)                                                                                          \
-    hipLaunchKernelGGL(k_init<ZR>, dim3(r.nbase), dim3(ZR > 8 ? 512 : 256), sizeof(InitLds<ZR>), rs, (const ulonglong2*)c->gpart.p, \
+#define LRF_LAUNCH_INIT(ZR, ...)                                                                                     \
+    hipLaunchKernelGGL((k_init<ZR, ##__VA_ARGS__>), dim3(r.nbase), dim3(ZR > 8 ? 512 : 256), sizeof(InitLds<ZR>), rs, (const ulonglong2*)c->gpart.p, \
                        (const int*)c->gexp.p, gram_exp, (const PlaneDesc*)c->planes.p, sign_dev, fb.vf, fb.wf, c->init_sweeps, r.pitch, r.plane0)
         if (r.rmax <= 8) LRF_LAUNCH_INIT(8);
-        else if (r.rmax <= 16) LRF_LAUNCH_INIT(16);
-        else if (r.rmax <= 32) LRF_LAUNCH_INIT(32);
-        else LRF_LAUNCH_INIT(64);
+        else if (dense) {
+            if (r.rmax <= 16) LRF_LAUNCH_INIT(16);
+            else if (r.rmax <= 32) LRF_LAUNCH_INIT(32);
+            else LRF_LAUNCH_INIT(64);
+        } else { // (no more matrices than CUs: the eight-wave workgroups without spills, k_init<.., 8, false>)
+            if (r.rmax <= 16) LRF_LAUNCH_INIT(16, 8, false);
+            else if (r.rmax <= 32) LRF_LAUNCH_INIT(32, 8, false);
+            else LRF_LAUNCH_INIT(64, 8, false);
+        }
 #undef LRF_LAUNCH_INIT
         LAUNCH_CHECK();
     }

@@ -557,8 +557,11 @@ static_assert(LRF_INIT_VPACK % 2 == 0 && LRF_INIT_VPACK >= 63 * 62 / 2 + 62 && L
 #ifndef LRF_INIT_MAXW8
 #define LRF_INIT_MAXW8 6
 #endif
-template <int ZR, int NW = (ZR > 8 ? 8 : 4)>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8 ? LRF_INIT_MINW8 : LRF_INIT_MINW4, NW == 8 ? LRF_INIT_MAXW8 : 4))) void k_init(const ulonglong2* __restrict__ Gpart, const int* __restrict__ gexp,
+// DENSE (eight-wave workgroups only): six waves per SIMD as described — for calls with more matrices than CUs, where workgroups
+// of different families share a CU; otherwise four (94 registers, no spills): a workgroup alone on its CU is a pure latency
+// chain and the spilled dwords cost it 10 % (64 x 512x768 at (16,8,8): the stage 303 us with four, 339 with six).
+template <int ZR, int NW = (ZR > 8 ? 8 : 4), bool DENSE = true>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8 ? (DENSE ? LRF_INIT_MINW8 : 4) : LRF_INIT_MINW4, NW == 8 ? LRF_INIT_MAXW8 : 4))) void k_init(const ulonglong2* __restrict__ Gpart, const int* __restrict__ gexp,
                                               int fixed_exp, const PlaneDesc* __restrict__ planes,
                                               const int8_t* __restrict__ sign, float* __restrict__ Vf,
                                               float* __restrict__ Wf, int debug_stop, int rp, int plane0 /* first plane of this launch's run */)
