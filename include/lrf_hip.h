@@ -58,7 +58,7 @@ void lrf_ctx_destroy(lrf_ctx* ctx);
 int lrf_ctx_set_stream(lrf_ctx* ctx, void* hip_stream);
 int lrf_ctx_use_own_stream(lrf_ctx* ctx);
 int lrf_ctx_synchronize(lrf_ctx* ctx);
-/* Asynchronous failures.  Large rank <= 8 calls run their iterations 2..K in ONE launch (k_bcd_p) whose waves wait for each
+/* Asynchronous failures.  Large calls run their iterations (all K at ranks <= 16, else 2..K) in ONE launch (k_bcd_p) whose waves wait for each
  * other with BOUNDED polls; a poll that expires (never observed in service; the exit every wave reaches) makes the launch
  * give up and report its number in page-locked host memory.  Because calls only enqueue, the report is read where results are
  * handed back: lrf_ctx_synchronize (after its wait), lrf_pipe_wait_next (for the piece it returns), the next persistent
