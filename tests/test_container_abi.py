@@ -51,6 +51,19 @@ def test_library_exports_every_declared_symbol():
     assert lib.lrf_version() == 1
 
 
+def test_kernel_ids_of_the_binding_are_the_header_ones():
+    """LRF_K_* (include/lrf_hip.h) index the per-kernel timers of lrf_ctx_kernel_time: the Python constants and the names bench.py
+    prints must follow the header when a kernel class is added (round 5: LRF_K_PLANES_GRAM)."""
+    from lrf_amd import _lib
+    header = open(os.path.join(ROOT, "include", "lrf_hip.h")).read()
+    ids = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(LRF_K_[A-Z_]+)\s+(\d+)", header)}
+    count = ids.pop("LRF_K_COUNT")
+    assert sorted(ids.values()) == list(range(count))
+    for name, value in ids.items():
+        assert getattr(_lib, name) == value, name
+    assert set(_lib.KERNEL_NAMES) == set(ids.values())
+
+
 def test_plane_dims_match_reference_metadata():
     from lrf_amd import _lib
     from lrf_amd.codec import parse_stream
