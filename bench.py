@@ -703,7 +703,8 @@ def main():
             "kernels": {k: {a: round(b, 5) for a, b in v.items()} for k, v in kern.items()},
             "kernels_note": "per-kernel breakdown from a separate untimed pass with every launch bracketed by events (k_bcd_persist = "
                             "the iterations in one launch where k_bcd_p runs — all K of them at ranks <= 16, the V updates inside; "
-                            "k_bcd / k_vupdate appear only where an iteration is a launch of its own); roofline.avg_launch_ms is "
+                            "k_bcd / k_vupdate appear only where an iteration is a launch of its own; k_planes_gram = k_planes16_gram, the patch "
+                            "matrices and the luma planes' Gram partials in one kernel, k_gram then covers the chroma planes only); roofline.avg_launch_ms is "
                             "measured inside the timed regions (events on the BCD launches only)",
         }
         out["ranks"] = rank_stats
