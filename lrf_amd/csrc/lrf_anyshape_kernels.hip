@@ -2173,26 +2173,42 @@ __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, 
                 __syncthreads();
                 // the earlier vectors live in global memory (L2): their loads are issued in batches (all 4 NCT pieces of a
                 // dot product at once, eight vectors per step of the update) instead of one per loop trip; same chains
-                for (int pr = wave; pr < r; pr += 4) {
-                    const double* Zp = Z + (long)pr * n;
-                    double zv[4 * NCT];
+                // (DB earlier vectors per trip and wave, their loads in flight together and their reduction trees interleaved: one at
+                // a time a trip waited for its own L2 round trip — the stage was 4.1 of k_any_eig<2>'s 9.2 ms at rank 102, side
+                // 512; each dot product's arithmetic is what it was)
+                constexpr int DB = NCT <= 2 ? 4 : 2;
+                for (int pr0 = wave; pr0 < r; pr0 += 4 * DB) {
+                    double zv[DB][4 * NCT];
 #pragma unroll
-                    for (int e = 0; e < 4 * NCT; e++) {
-                        const int i = lane + 64 * e;
-                        zv[e] = Zp[i < n ? i : n - 1];
-                    }
-                    double dsum = 0.0;
+                    for (int d = 0; d < DB; d++) {
+                        const int pr = pr0 + 4 * d;
+                        const double* Zp = Z + (long)(pr < r ? pr : r - 1) * n;
 #pragma unroll
-                    for (int e = 0; e < 4 * NCT; e++) {
-                        const int i = lane + 64 * e;
-                        if (i < n) dsum = fma(zv[e], Lv[i], dsum);
+                        for (int e = 0; e < 4 * NCT; e++) {
+                            const int i = lane + 64 * e;
+                            zv[d][e] = Zp[i < n ? i : n - 1];
+                        }
                     }
-                    dsum = wave_sum(dsum);
-                    if (lane == 0) Lw[pr] = dsum;
+                    double dsum[DB];
+#pragma unroll
+                    for (int d = 0; d < DB; d++) {
+                        dsum[d] = 0.0;
+#pragma unroll
+                        for (int e = 0; e < 4 * NCT; e++) {
+                            const int i = lane + 64 * e;
+                            if (i < n) dsum[d] = fma(zv[d][e], Lv[i], dsum[d]);
+                        }
+                    }
+#pragma unroll
+                    for (int d = 0; d < DB; d++) dsum[d] = wave_sum(dsum[d]);
+#pragma unroll
+                    for (int d = 0; d < DB; d++)
+                        if (lane == 0 && pr0 + 4 * d < r) Lw[pr0 + 4 * d] = dsum[d];
                 }
                 __syncthreads();
-                for (int p0 = 0; p0 < r; p0 += 8) {
-                    double zv[8][NCT];
+                // (two batches of eight earlier vectors in flight: the loads of batch b + 1 are issued before batch b's fmas —
+                // a batch at a time waited out one L2 round trip per eight vectors)
+                auto load_batch = [&](int p0, double (&zv)[8][NCT]) __attribute__((always_inline)) {
 #pragma unroll
                     for (int u = 0; u < 8; u++) {
                         const double* Zp = Z + (long)(p0 + u < r ? p0 + u : r - 1) * n;
@@ -2206,6 +2222,8 @@ __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, 
                             zv[u][c] = (i < n) ? zz : 0.0;
                         }
                     }
+                };
+                auto apply_batch = [&](int p0, const double (&zv)[8][NCT]) __attribute__((always_inline)) {
 #pragma unroll
                     for (int u = 0; u < 8; u++) {
                         if (p0 + u < r) {
@@ -2213,6 +2231,22 @@ __global__ __launch_bounds__(256) void k_any_eig(double* __restrict__ G, int n, 
 #pragma unroll
                             for (int c = 0; c < NCT; c++) x[c] = fma(-cf, zv[u][c], x[c]);
                         }
+                    }
+                };
+                if constexpr (NCT <= 2) {
+                    double za[8][NCT], zb[8][NCT];
+                    load_batch(0, za);
+                    for (int p0 = 0; p0 < r; p0 += 16) {
+                        if (p0 + 8 < r) load_batch(p0 + 8, zb);
+                        apply_batch(p0, za);
+                        if (p0 + 16 < r) load_batch(p0 + 16, za);
+                        if (p0 + 8 < r) apply_batch(p0 + 8, zb);
+                    }
+                } else { // (sides above 512: the second batch does not fit the registers)
+                    for (int p0 = 0; p0 < r; p0 += 8) {
+                        double za[8][NCT];
+                        load_batch(p0, za);
+                        apply_batch(p0, za);
                     }
                 }
                 __syncthreads();
